@@ -1,0 +1,23 @@
+# Builds the gfx950 C-ABI library (libyolo_hip.so) and the oracle's C helpers.
+# hipcc cross-compiles without a GPU present.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := tf2_yolo_amd/csrc
+SRCS  := $(CSRC)/runtime.hip $(CSRC)/conv.hip $(CSRC)/bn_act.hip $(CSRC)/elementwise.hip \
+         $(CSRC)/loss.hip $(CSRC)/decode_nms.hip
+OBJS  := $(SRCS:.hip=.o)
+LIB   := tf2_yolo_amd/libyolo_hip.so
+HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -munsafe-fp-atomics -Wall -Wno-unused-function
+
+all: $(LIB)
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/yolo_hip.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
+
+clean:
+	rm -f $(OBJS) $(LIB)
+
+.PHONY: all clean

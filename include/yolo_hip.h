@@ -1,0 +1,270 @@
+/*
+ * yolo_hip.h -- C-ABI of libyolo_hip.so: the MI355X (gfx950) kernels behind the
+ * tf2_YOLO drop-in (yolov{1_5,2,3,4}.Yolo / create_model / loss / metrics,
+ * utils.tools.decode / nms / soft_nms).
+ *
+ * The reference (samson6460/tf2_YOLO) is 100 % Python on top of tf.keras and has no
+ * FFI of its own, so every entry point below cites the
+ * reference call site whose arithmetic it replaces (path:line under /root/reference).
+ *
+ * Conventions (all functions):
+ *   - extern "C", plain pointers / ints / floats, no C++ or torch types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - `stream` is a hipStream_t passed as void*; work is enqueued asynchronously, the
+ *     library never synchronises the device and never allocates device memory: the
+ *     caller owns all buffers including workspaces (sizes via the *_workspace_bytes
+ *     queries or documented per function).
+ *   - return value: 0 = YOLO_OK, negative = yolo_status; the message for the last
+ *     failure on the calling thread is available from yolo_last_error().
+ *   - activations are dense NHWC float32; filters are "KRSC" = [Cout][kh][kw][Cin]
+ *     float32 (converted once from Keras HWIO by the host side).
+ */
+#ifndef YOLO_HIP_H_
+#define YOLO_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum yolo_status {
+  YOLO_OK = 0,
+  YOLO_ERR_INVALID_ARG = -1,   /* bad shape / null pointer / unsupported parameter */
+  YOLO_ERR_LAUNCH = -2,        /* hipLaunch / hip runtime error                      */
+  YOLO_ERR_WORKSPACE = -3      /* workspace too small                                */
+} yolo_status;
+
+/* activation codes shared by the bn_act / act kernels */
+enum { YOLO_ACT_LINEAR = 0, YOLO_ACT_LEAKY = 1, YOLO_ACT_MISH = 2 };
+/* head layouts */
+enum { YOLO_HEAD_V3 = 3, YOLO_HEAD_V2 = 2, YOLO_HEAD_V1 = 1, YOLO_HEAD_V4 = 4 };
+/* nms modes: utils/tools.py:687-786 (nms iou_mode=1, nms iou_mode=2 (DIoU), soft_nms) */
+enum { YOLO_NMS_HARD = 1, YOLO_NMS_SOFT = 2, YOLO_NMS_DIOU = 3 };
+
+const char* yolo_last_error(void);
+/* library/ABI version, bumped when a signature changes */
+int yolo_abi_version(void);
+/* 1 if a HIP device is visible to the calling process, 0 otherwise (never throws) */
+int yolo_device_available(void);
+
+/* ------------------------------------------------------------------------------------
+ * Convolution (replaces tf.keras Conv2D at yolov3/models/backbone.py:27-36,
+ * yolov4/models/backbone.py:63-74, yolov{1_5,2}/models/backbone.py:9-18 and the head
+ * convs yolov3/models/__init__.py:40-58).
+ *
+ * Implicit GEMM on v_mfma_f32_32x32x2_f32 (exact fp32), NHWC, im2col-free:
+ *   y[n,ho,wo,co] = bias[co] + sum_{r,s,ci} x[n, ho*sh + r - pad_t, wo*sw + s - pad_l, ci] * w[co,r,s,ci]
+ * Zero padding is implicit (pad_t/pad_l, the bottom/right pad follows from Ho/Wo), which
+ * covers Keras 'same' (asymmetric for stride 2), 'valid', and ZeroPadding2D((1,0),(1,0)).
+ * ------------------------------------------------------------------------------------ */
+typedef struct yolo_conv_desc {
+  int N, H, W, Cin;      /* input  x: [N,H,W,Cin]                  */
+  int Cout, kh, kw;      /* filter w: [Cout,kh,kw,Cin]              */
+  int Ho, Wo;            /* output y: [N,Ho,Wo,Cout]                */
+  int sh, sw;            /* strides                                 */
+  int pad_t, pad_l;      /* implicit zero padding top / left        */
+} yolo_conv_desc;
+
+/* y = conv(x, w) (+ bias if bias != NULL). If stats != NULL (double[2*Cout], zeroed by the
+ * caller) the epilogue also accumulates per-channel sum / sum-of-squares of y for
+ * training-mode BatchNormalization (yolov3/models/backbone.py:54). */
+int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const float* w,
+                    const float* bias, float* y, double* stats, void* stream);
+
+/* dx (+)= conv_transpose(dy, w).  wT is the filter re-laid as [Cin][kh][kw][Cout]
+ * (yolo_filter_transpose).  accumulate != 0 adds into dx (fan-out of a tensor). */
+int yolo_conv2d_dgrad(const yolo_conv_desc* d, const float* dy, const float* wT,
+                      float* dx, int accumulate, void* stream);
+
+/* dw += sum over pixels dy (x) x  (dw must be zeroed by the caller before the first
+ * contribution; split-K partial sums are combined with fp32 atomics).
+ * dbias (optional, [Cout]) += sum over pixels of dy. */
+int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const float* dy,
+                      float* dw, float* dbias, void* stream);
+
+/* wT[ci][r][s][co] = w[co][r][s][ci] */
+int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * BatchNormalization (training and inference) + activation (+ residual add)
+ * (replaces BatchNormalization + LeakyReLU / Mish + Add at
+ *  yolov3/models/backbone.py:39-71, yolov4/models/backbone.py:76-123).
+ * eps = 1e-3, momentum = 0.99 are the Keras defaults used by the reference.
+ * ------------------------------------------------------------------------------------ */
+
+/* per-channel sum / sum-of-squares of x[P,C] into stats (double[2*C], caller-zeroed).
+ * Only needed when the producing conv did not fuse the statistics. */
+int yolo_bn_stats(const float* x, long long P, int C, double* stats, void* stream);
+
+/* From stats: mean, biased var; writes scale = gamma/sqrt(var+eps), shift = beta - mean*scale,
+ * saves mean / invstd for backward, updates the moving statistics
+ *   moving = momentum*moving + (1-momentum)*batch   (variance fed: biased if
+ *   unbiased_moving_var == 0, Bessel-corrected otherwise)
+ * and zeroes `stats` for the next step. */
+int yolo_bn_finalize(double* stats, long long P, int C, const float* gamma, const float* beta,
+                     float eps, float momentum, int unbiased_moving_var,
+                     float* moving_mean, float* moving_var,
+                     float* scale, float* shift, float* save_mean, float* save_invstd,
+                     void* stream);
+
+/* inference: scale/shift from the moving statistics */
+int yolo_bn_fold_inference(int C, const float* gamma, const float* beta,
+                           const float* moving_mean, const float* moving_var, float eps,
+                           float* scale, float* shift, void* stream);
+
+/* out = act(scale*x + shift) (+ residual if residual != NULL); x, out: [P,C] */
+int yolo_bn_act_fwd(const float* x, long long P, int C, const float* scale, const float* shift,
+                    int act, const float* residual, float* out, void* stream);
+
+/* Backward of out = act(BN_train(x)) given dout = dL/dout (the residual branch, if any,
+ * receives dout unchanged and is handled by the caller).
+ *   pass 1 (reduce): dgamma/dbeta partial sums -> red (double[2*C], caller-zeroed)
+ *   pass 2 (apply) : dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma, dbeta
+ *                    are ACCUMULATED (+=) into the flat gradient buffer.
+ * dx may alias dout. */
+int yolo_bn_act_bwd_reduce(const float* x, const float* dout, long long P, int C,
+                           const float* scale, const float* shift,
+                           const float* save_mean, const float* save_invstd,
+                           int act, double* red, void* stream);
+int yolo_bn_act_bwd_apply(const float* x, const float* dout, long long P, int C,
+                          const float* gamma, const float* scale, const float* shift,
+                          const float* save_mean, const float* save_invstd,
+                          int act, double* red, float* dgamma, float* dbeta,
+                          float* dx, void* stream);
+
+/* plain activation (no BN) forward / backward on [n] elements; used by conv(+bias)+act
+ * units without BN, if any */
+int yolo_act_fwd(const float* x, long long n, int act, float* out, void* stream);
+int yolo_act_bwd(const float* x, const float* dout, long long n, int act, float* dx, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Glue ops (UpSampling2D, Concatenate, MaxPooling2D, space_to_depth, Add):
+ *   yolov3/models/darknet.py:83-93, yolov4/models/backbone.py:176-185,
+ *   yolov2/models/backbone.py:44-65, yolov2/models/darknet.py:46-49.
+ * ------------------------------------------------------------------------------------ */
+/* dst[:, c_off:c_off+Csrc] = src   (P pixels; src dense [P,Csrc], dst dense [P,Cdst]) */
+int yolo_copy_channels_in(const float* src, long long P, int Csrc, float* dst, int Cdst,
+                          int c_off, void* stream);
+/* dst (+)= src[:, c_off:c_off+Cdst]   (src dense [P,Csrc], dst dense [P,Cdst]) */
+int yolo_copy_channels_out(const float* src, long long P, int Csrc, int c_off, float* dst,
+                           int Cdst, int accumulate, void* stream);
+/* nearest 2x: y[n,2h+a,2w+b,c] = x[n,h,w,c]; written into channel slice of y ([.,.,.,Cy] at c_off) */
+int yolo_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, int Cy, int c_off,
+                        void* stream);
+/* dx (+)= sum of the 4 children of dy's channel slice */
+int yolo_upsample2x_bwd(const float* dy, int N, int H, int W, int C, int Cy, int c_off, float* dx,
+                        int accumulate, void* stream);
+/* a (+)= b over n elements */
+int yolo_axpy(float* a, const float* b, long long n, void* stream);
+/* max-pool, window k, stride s, -inf padding pad_t/pad_l (Keras 'same'/'valid' resolved by host).
+ * argmax (int32 flat input offset per output element, -1 if window empty) is saved for backward;
+ * y is written into channel slice [c_off, c_off+C) of a [.,.,.,Cy] tensor. */
+int yolo_maxpool_fwd(const float* x, int N, int H, int W, int C, int k, int s, int pad_t, int pad_l,
+                     int Ho, int Wo, float* y, int Cy, int c_off, int* argmax, void* stream);
+/* dx[argmax] += dy (dx caller-initialised) */
+int yolo_maxpool_bwd(const float* dy, int N, int Ho, int Wo, int C, int Cy, int c_off,
+                     const int* argmax, float* dx, void* stream);
+/* tf.nn.space_to_depth(x, 2): y[n,h,w,(dy*2+dx)*C+c] = x[n,2h+dy,2w+dx,c], into slice of Cy at c_off */
+int yolo_space_to_depth2_fwd(const float* x, int N, int H, int W, int C, float* y, int Cy, int c_off,
+                             void* stream);
+int yolo_space_to_depth2_bwd(const float* dy, int N, int H, int W, int C, int Cy, int c_off, float* dx,
+                             int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Detection head activations (yolov3/models/__init__.py:40-65, yolov4/models/__init__.py:41-66,
+ * yolov2/models/darknet.py:79-102, yolov1_5/models/darknet.py:37-55).
+ * t: raw head conv output [P, A*(5+C)] (v1: [P, 5B+C]); y: activated prediction, same shape.
+ *   v3/v4: xy=sigmoid, wh=exp(t)*anchor, conf=sigmoid, class=sigmoid
+ *   v2   : xy=sigmoid, wh=exp(t)*anchor, conf=sigmoid, class=softmax
+ *   v1   : first 5B channels sigmoid, last C channels softmax
+ * anchors: device float[A*2] (w,h) (ignored for v1).
+ * ------------------------------------------------------------------------------------ */
+int yolo_head_act_fwd(const float* t, long long P, int A, int C, int version,
+                      const float* anchors, float* y, void* stream);
+/* dt = dy * dy/dt ; danchors (optional, v4 trainable Anchor layer) += sum dy*exp(t) */
+int yolo_head_act_bwd(const float* y, const float* dy, long long P, int A, int C, int version,
+                      const float* anchors, float* dt, float* danchors, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Anchor-grid losses, forward + backward in one pass over the cells
+ * (wrap_yolo_loss: yolov3/losses/loss.py:40-164, yolov4/losses/loss.py:64-169,
+ *  yolov2/losses/loss.py:40-137, yolov1_5/losses/loss.py:40-118).
+ * y_true: [N,gh,gw,5+C]; y_pred: [N,gh,gw,A*(5+C)] (v1: [N,gh,gw,5B+C]) -- POST-activation,
+ * exactly what the reference closure receives.
+ * loss_out: device double[8]: [0]=total loss, [1..] = weighted-free parts
+ *   v2/v3: xy, wh, conf_obj, conf_noobj, class, reg ; v4: box, conf_obj, conf_noobj, class, reg
+ * dpred (optional): dL/dy_pred (same shape as y_pred), multiplied by grad_scale.
+ * workspace: yolo_loss_workspace_bytes(cells) bytes, device.
+ * ------------------------------------------------------------------------------------ */
+typedef struct yolo_loss_cfg {
+  int version;            /* 1,2,3,4                                                  */
+  int N, gh, gw, A, C;    /* batch, grid, anchors (v1: boxes B), classes              */
+  float anchors[32];      /* A pairs (w,h); ignored by v1                             */
+  int   use_anchors;      /* 0 => panchors = 1 (yolov3/losses/loss.py:52-53)          */
+  float binary_weight;
+  float loss_weight[4];   /* v1-v3: xy,wh,conf,prob ; v4: box,conf,prob               */
+  float ignore_thresh;
+  int   use_focal_loss;   /* v3 only                                                  */
+  float focal_gamma;      /* v3, v4                                                   */
+  int   use_scale;        /* v3 (v2: always on)                                       */
+  float wh_reg_weight;    /* v4 (v2/v3 fixed 0.01)                                    */
+  float truth_thresh;     /* v4                                                       */
+  float label_smooth;     /* v4                                                       */
+} yolo_loss_cfg;
+
+size_t yolo_loss_workspace_bytes(const yolo_loss_cfg* cfg);
+int yolo_loss_fwd_bwd(const yolo_loss_cfg* cfg, const float* y_true, const float* y_pred,
+                      double* loss_out, float* dpred, float grad_scale,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* Metrics (yolov3/metrics/yolo_metrics.py:9-115, yolov1_5/metrics/yolo_metrics.py:9-107).
+ * out: device double[8]:
+ *   [0] sum over cells of binary_accuracy(c_true, max_b c_pred)   (obj_acc numerator; / cells)
+ *   [1] sum(max_b iou * obj)      [2] sum(obj)
+ *   [3] sum([argmax p_t == argmax p_p] * obj)  (over anchors; v1: per cell)
+ *   [4] #[max_b(iou*same_class*obj) >= recall_thresh]
+ *   [5] cells */
+int yolo_metrics(const yolo_loss_cfg* cfg, const float* y_true, const float* y_pred,
+                 float recall_thresh, double* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimizer (Keras Adam defaults: README.md:241; beta1=.9 beta2=.999 eps=1e-7, bias-corrected)
+ *   g <- g*grad_scale ; m,v update ; p -= lr_t * m/(sqrt(v)+eps) ; g <- 0 (if zero_grad)
+ * ------------------------------------------------------------------------------------ */
+int yolo_adam_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1,
+                   float beta2, float eps, int step, float grad_scale, int zero_grad, void* stream);
+int yolo_sgd_step(float* p, float* g, long long n, float lr, float grad_scale, int zero_grad,
+                  void* stream);
+int yolo_fill(float* p, long long n, float value, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * decode + NMS (utils/tools.py:370-438, 630-786), bit-exact index selection.
+ * ------------------------------------------------------------------------------------ */
+/* One level: pred [gh,gw,A*(5+C)] float32 (version 2/3/4) or [gh,gw,5B+C] (version 1).
+ * Appends rows (x,y,w,h,conf,class,prob) as float64 to rows_out[7*row] starting at row *count
+ * (device int, caller-zeroed before the first level), in the reference's C order
+ * (y, x, box, class). Rows beyond max_rows are counted but not written. */
+int yolo_decode_level(const float* pred, int gh, int gw, int A, int C, int version,
+                      float threshold, double* rows_out, int max_rows, int* count,
+                      void* workspace, size_t workspace_bytes, void* stream);
+/* same, for float64 predictions (the reference's decode also runs on float64 label tensors,
+ * utils/tools.py:441-470 vis_img on ground truth): product and threshold in float64 */
+int yolo_decode_level_f64(const double* pred, int gh, int gw, int A, int C, int version,
+                          double threshold, double* rows_out, int max_rows, int* count,
+                          void* workspace, size_t workspace_bytes, void* stream);
+size_t yolo_decode_workspace_bytes(int gh, int gw, int A, int C);
+
+/* NMS over n decoded rows (device float64 [n,7]); keep_out: device uint8[n] (1 = kept).
+ * The caller gathers kept rows class by class in ascending class id, original order inside
+ * a class (utils/tools.py:730-732). */
+size_t yolo_nms_workspace_bytes(int n, int class_num);
+int yolo_nms(const double* rows, int n, int class_num, int mode, double nms_threshold,
+             double conf_threshold, double sigma, unsigned char* keep_out,
+             void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLO_HIP_H_ */

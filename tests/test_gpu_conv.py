@@ -1,0 +1,104 @@
+"""GPU parity of the implicit-GEMM conv kernels (fwd / dgrad / wgrad) against the torch-CPU
+float64 oracle (oracle/layers.py, Keras padding semantics). Tolerance: fp32 1e-4 relative to
+the tensor scale (BASELINE.json north_star)."""
+import pytest
+import torch
+
+from oracle import layers as L
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+# (N, H, W, Cin, Cout, k, stride, padding, bias)
+CASES = [
+    (2, 16, 16, 32, 64, 3, 1, "same", False),       # plain 3x3
+    (2, 16, 16, 64, 32, 1, 1, "same", False),       # 1x1, Cout = 32 tile
+    (2, 17, 13, 32, 64, 3, 2, "darknet_s2", False),  # v3 down-sampling, odd sizes
+    (2, 16, 16, 32, 128, 3, 2, "darknet_s2", False),
+    (1, 20, 20, 3, 32, 3, 1, "same", False),        # Cin = 3 stem (flat-K path)
+    (2, 14, 14, 64, 64, 3, 2, "same", True),        # v1: 3x3 s2 'same' (asymmetric pad), bias
+    (1, 28, 28, 3, 64, 7, 2, "same", True),         # v1 stem 7x7 s2 'same'
+    (2, 13, 13, 128, 255, 1, 1, "same", True),      # v3 head: Cout = 255
+    (2, 7, 7, 96, 160, 3, 1, "same", False),        # Cin multiple of 32 but not of 64; M tail
+    (3, 9, 11, 256, 128, 1, 1, "valid", False),
+    (1, 13, 13, 64, 125, 1, 1, "same", True),       # v2 head width
+    (1, 5, 5, 1024, 11, 1, 1, "same", True),        # v1 head (tiny Cout)
+]
+
+
+def _mk(case, seed=0):
+    n, h, w, cin, cout, k, s, pad, bias = case
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, h, w, cin, generator=g, dtype=torch.float64)
+    wk = torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) / (k * k * cin) ** 0.5
+    b = torch.randn(cout, generator=g, dtype=torch.float64) if bias else None
+    return x, wk, b
+
+
+def _krsc(w_hwio):
+    return w_hwio.permute(3, 0, 1, 2).contiguous()
+
+
+def _relerr(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_fwd(case):
+    from tf2_yolo_amd import ops
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case)
+    ref = L.conv2d(x, wk, b, stride=s, padding=pad)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    assert (d.Ho, d.Wo) == (ref.shape[1], ref.shape[2])
+    y = ops.conv2d_fwd(d, x.float().cuda(), _krsc(wk).float().cuda(), None if b is None else b.float().cuda())
+    torch.cuda.synchronize()
+    assert _relerr(y.double().cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_dgrad_wgrad(case):
+    from tf2_yolo_amd import ops
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=1)
+    x.requires_grad_(True)
+    wk.requires_grad_(True)
+    if b is not None:
+        b.requires_grad_(True)
+    ref = L.conv2d(x, wk, b, stride=s, padding=pad)
+    g = torch.Generator().manual_seed(2)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    wd = _krsc(wk.detach()).float().cuda()
+    dyd = dy.float().cuda()
+    # wgrad (+ bias grad)
+    dw = torch.zeros_like(wd)
+    db = torch.zeros(cout, device="cuda") if bias else None
+    ops.conv2d_wgrad(d, x.detach().float().cuda(), dyd, dw, db)
+    torch.cuda.synchronize()
+    assert _relerr(dw.double().cpu(), _krsc(wk.grad)) < TOL
+    if bias:
+        assert _relerr(db.double().cpu(), b.grad) < TOL
+    # dgrad (not defined for the flat-K stem in the product: the image has no gradient)
+    if cin % 32 == 0 and (cout % 32 == 0 or k == 1):
+        wT = ops.filter_transpose(wd, cout, k * k, cin)
+        dx = ops.conv2d_dgrad(d, dyd, wT)
+        torch.cuda.synchronize()
+        assert _relerr(dx.double().cpu(), x.grad) < TOL
+        # accumulate form: dx += ...
+        dx2 = dx.clone()
+        ops.conv2d_dgrad(d, dyd, wT, dx=dx2, accumulate=True)
+        torch.cuda.synchronize()
+        assert _relerr(dx2.double().cpu(), 2 * x.grad) < TOL
+
+
+def test_conv_rejects_bad_descriptor():
+    from tf2_yolo_amd import ops
+    from tf2_yolo_amd._lib import YoloHipError
+    d = ops.conv_desc((1, 8, 8, 32), 32, 3, 3, 1, "same")
+    x = torch.zeros(1, 8, 8, 16, device="cuda")
+    w = torch.zeros(32, 3, 3, 32, device="cuda")
+    with pytest.raises(YoloHipError):
+        ops.conv2d_fwd(d, x, w)

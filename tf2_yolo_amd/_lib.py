@@ -1,0 +1,112 @@
+"""ctypes binding of libyolo_hip.so (C-ABI declared in include/yolo_hip.h).
+
+The product path has NO CPU fallback: if the HIP library is missing or a call fails,
+`YoloHipError` is raised. (The CPU restatement under /oracle is test infrastructure and
+is never imported from here.)
+"""
+import ctypes
+import os
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong,
+                    c_size_t, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
+
+ACT_LINEAR, ACT_LEAKY, ACT_MISH = 0, 1, 2
+NMS_HARD, NMS_SOFT, NMS_DIOU = 1, 2, 3
+
+
+class YoloHipError(RuntimeError):
+    pass
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int) for n in
+                ("N", "H", "W", "Cin", "Cout", "kh", "kw", "Ho", "Wo", "sh", "sw", "pad_t", "pad_l")]
+
+
+class LossCfg(Structure):
+    _fields_ = [("version", c_int), ("N", c_int), ("gh", c_int), ("gw", c_int), ("A", c_int),
+                ("C", c_int), ("anchors", c_float * 32), ("use_anchors", c_int),
+                ("binary_weight", c_float), ("loss_weight", c_float * 4),
+                ("ignore_thresh", c_float), ("use_focal_loss", c_int), ("focal_gamma", c_float),
+                ("use_scale", c_int), ("wh_reg_weight", c_float), ("truth_thresh", c_float),
+                ("label_smooth", c_float)]
+
+
+_P = c_void_p
+_LL = c_longlong
+# name -> (restype, argtypes); must list EVERY symbol declared in include/yolo_hip.h
+SIGNATURES = {
+    "yolo_last_error": (c_char_p, []),
+    "yolo_abi_version": (c_int, []),
+    "yolo_device_available": (c_int, []),
+    "yolo_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "yolo_conv2d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P]),
+    "yolo_conv2d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "yolo_filter_transpose": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
+    "yolo_bn_stats": (c_int, [_P, _LL, c_int, _P, _P]),
+    "yolo_bn_finalize": (c_int, [_P, _LL, c_int, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "yolo_bn_fold_inference": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
+    "yolo_bn_act_fwd": (c_int, [_P, _LL, c_int, _P, _P, c_int, _P, _P, _P]),
+    "yolo_bn_act_bwd_reduce": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P]),
+    "yolo_bn_act_bwd_apply": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
+    "yolo_act_fwd": (c_int, [_P, _LL, c_int, _P, _P]),
+    "yolo_act_bwd": (c_int, [_P, _P, _LL, c_int, _P, _P]),
+    "yolo_copy_channels_in": (c_int, [_P, _LL, c_int, _P, c_int, c_int, _P]),
+    "yolo_copy_channels_out": (c_int, [_P, _LL, c_int, c_int, _P, c_int, c_int, _P]),
+    "yolo_upsample2x_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "yolo_upsample2x_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "yolo_axpy": (c_int, [_P, _P, _LL, _P]),
+    "yolo_maxpool_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 _P, c_int, c_int, _P, _P]),
+    "yolo_maxpool_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "yolo_space_to_depth2_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
+    "yolo_space_to_depth2_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
+    "yolo_head_act_fwd": (c_int, [_P, _LL, c_int, c_int, c_int, _P, _P, _P]),
+    "yolo_head_act_bwd": (c_int, [_P, _P, _LL, c_int, c_int, c_int, _P, _P, _P, _P]),
+    "yolo_loss_workspace_bytes": (c_size_t, [POINTER(LossCfg)]),
+    "yolo_loss_fwd_bwd": (c_int, [POINTER(LossCfg), _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
+    "yolo_metrics": (c_int, [POINTER(LossCfg), _P, _P, c_float, _P, _P]),
+    "yolo_adam_step": (c_int, [_P, _P, _P, _P, _LL, c_float, c_float, c_float, c_float, c_int, c_float, c_int, _P]),
+    "yolo_sgd_step": (c_int, [_P, _P, _LL, c_float, c_float, c_int, _P]),
+    "yolo_fill": (c_int, [_P, _LL, c_float, _P]),
+    "yolo_decode_level": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, _P, _P, c_size_t, _P]),
+    "yolo_decode_level_f64": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_double, _P, c_int, _P, _P,
+                                      c_size_t, _P]),
+    "yolo_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "yolo_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "yolo_nms": (c_int, [_P, c_int, c_int, c_int, c_double, c_double, c_double, _P, _P, c_size_t, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libyolo_hip.so and declare every prototype. Raises YoloHipError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise YoloHipError(
+            f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
+            "there is no CPU fallback for the product path")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise YoloHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise YoloHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().yolo_last_error()
+        raise YoloHipError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,319 @@
+// Training / inference BatchNormalization fused with the activation (LeakyReLU 0.1 / Mish)
+// and the residual Add. HBM-bound streaming kernels: 16 B per lane, grid-stride, per-channel
+// statistics accumulated in fp64 so that the 1e-4 parity bar holds through 72 layers.
+//
+// Replaces BatchNormalization + LeakyReLU / Mish (+ Add) of
+//   yolov3/models/backbone.py:39-71, yolov4/models/backbone.py:22-37,76-123,
+//   yolov{1_5,2}/models/backbone.py:9-18.
+#include "common.hpp"
+
+namespace yolo {
+
+__device__ __forceinline__ float softplus_f(float x) {
+  // tf.nn.softplus: log(1 + exp(x)), evaluated stably
+  return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+}
+__device__ __forceinline__ float act_fwd(float z, int act) {
+  if (act == YOLO_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
+  if (act == YOLO_ACT_MISH) return z * tanhf(softplus_f(z));
+  return z;
+}
+__device__ __forceinline__ float act_grad(float z, int act) {
+  if (act == YOLO_ACT_LEAKY) return z > 0.f ? 1.f : 0.1f;
+  if (act == YOLO_ACT_MISH) {
+    const float t = tanhf(softplus_f(z));
+    const float sg = 1.f / (1.f + expf(-z));
+    return t + z * (1.f - t * t) * sg;
+  }
+  return 1.f;
+}
+
+// Column layout shared by the per-channel reductions: a block covers `cw` float4 columns
+// (cw = min(C/4, 256)) x (256/cw) pixel rows per pass; grid.y walks column chunks.
+struct ColGeom {
+  int cw, rpp;
+};
+static inline ColGeom col_geom(int C4) {
+  ColGeom g;
+  g.cw = C4 < 256 ? C4 : 256;
+  g.rpp = 256 / g.cw;
+  return g;
+}
+
+template <int NQ>
+__device__ __forceinline__ void block_col_reduce(double (&v)[NQ][4], int cw, int rpp, int row_lane, int col,
+                                                 bool active, double* smem /* [NQ*4][256] */,
+                                                 double* out /* [NQ][C] */, int C, int c4) {
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) smem[(q * 4 + e) * 256 + tid] = active ? v[q][e] : 0.0;
+  __syncthreads();
+  if (active && row_lane == 0) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        double s = 0.0;
+        for (int r = 0; r < rpp; ++r) s += smem[(q * 4 + e) * 256 + r * cw + col];
+        atomicAdd(&out[(long long)q * C + c4 * 4 + e], s);
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, long long P, int C, int cw,
+                                                       int rpp, double* __restrict__ stats) {
+  __shared__ double smem[8 * 256];
+  const int tid = threadIdx.x;
+  const int row_lane = tid / cw, col = tid - row_lane * cw;
+  const int C4 = C >> 2;
+  const int c4 = blockIdx.y * cw + col;
+  const bool active = (row_lane < rpp) && (c4 < C4);
+  double v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (active) {
+    for (long long p = (long long)blockIdx.x * rpp + row_lane; p < P; p += (long long)gridDim.x * rpp) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(x + p * C + c4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double d = (double)t[e];
+        v[0][e] += d;
+        v[1][e] += d * d;
+      }
+    }
+  }
+  block_col_reduce<2>(v, cw, rpp, row_lane, col, active, smem, stats, C, c4);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                   float momentum, int unbiased, float* __restrict__ mmean, float* __restrict__ mvar,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
+                                   float* __restrict__ sinv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = stats[c] / (double)P;
+  double var = stats[C + c] / (double)P - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double inv = 1.0 / sqrt(var + (double)eps);
+  const float sc = (float)((double)gamma[c] * inv);
+  scale[c] = sc;
+  shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * inv);
+  smean[c] = (float)mean;
+  sinv[c] = (float)inv;
+  if (mmean != nullptr) {
+    double fed = var;
+    if (unbiased && P > 1) fed = var * (double)P / (double)(P - 1);
+    mmean[c] = (float)((double)momentum * mmean[c] + (1.0 - (double)momentum) * mean);
+    mvar[c] = (float)((double)momentum * mvar[c] + (1.0 - (double)momentum) * fed);
+  }
+}
+
+__global__ void bn_fold_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mmean, const float* __restrict__ mvar, float eps,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double inv = 1.0 / sqrt((double)mvar[c] + (double)eps);
+  scale[c] = (float)((double)gamma[c] * inv);
+  shift[c] = (float)((double)beta[c] - (double)mmean[c] * (double)gamma[c] * inv);
+}
+
+__global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict__ x, long long n4, int C4,
+                                                         const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int act,
+                                                         const float* __restrict__ res, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4];
+    const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = act_fwd(fmaf(sc[e], xv[e], sh[e]), act);
+    if (res != nullptr) {
+      const f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += r[e];
+    }
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dout, long long P, int C,
+                                                            int cw, int rpp, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ smean,
+                                                            const float* __restrict__ sinv, int act,
+                                                            double* __restrict__ red) {
+  __shared__ double smem[8 * 256];
+  const int tid = threadIdx.x;
+  const int row_lane = tid / cw, col = tid - row_lane * cw;
+  const int C4 = C >> 2;
+  const int c4 = blockIdx.y * cw + col;
+  const bool active = (row_lane < rpp) && (c4 < C4);
+  double v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  if (active) {
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4];
+    const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
+    const f32x4 mu = reinterpret_cast<const f32x4*>(smean)[c4];
+    const f32x4 iv = reinterpret_cast<const f32x4*>(sinv)[c4];
+    for (long long p = (long long)blockIdx.x * rpp + row_lane; p < P; p += (long long)gridDim.x * rpp) {
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * C + c4 * 4);
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(dout + p * C + c4 * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float z = fmaf(sc[e], xv[e], sh[e]);
+        const float dz = dv[e] * act_grad(z, act);
+        const float xh = (xv[e] - mu[e]) * iv[e];
+        v[0][e] += (double)dz;
+        v[1][e] += (double)dz * (double)xh;
+      }
+    }
+  }
+  block_col_reduce<2>(v, cw, rpp, row_lane, col, active, smem, red, C, c4);
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x,
+                                                           const float* __restrict__ dout, long long n4, int C4,
+                                                           double invP, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ smean,
+                                                           const float* __restrict__ sinv, int act,
+                                                           const double* __restrict__ red, float* __restrict__ dx) {
+  const int C = C4 * 4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+    const f32x4 dv = reinterpret_cast<const f32x4*>(dout)[i];
+    const f32x4 sc = reinterpret_cast<const f32x4*>(scale)[c4];
+    const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
+    const f32x4 mu = reinterpret_cast<const f32x4*>(smean)[c4];
+    const f32x4 iv = reinterpret_cast<const f32x4*>(sinv)[c4];
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float z = fmaf(sc[e], xv[e], sh[e]);
+      const float dz = dv[e] * act_grad(z, act);
+      const float xh = (xv[e] - mu[e]) * iv[e];
+      const float mdz = (float)(red[c4 * 4 + e] * invP);
+      const float mdzx = (float)(red[C + c4 * 4 + e] * invP);
+      o[e] = sc[e] * (dz - mdz - xh * mdzx);
+    }
+    reinterpret_cast<f32x4*>(dx)[i] = o;
+  }
+}
+
+__global__ void bn_bwd_params_kernel(int C, const double* __restrict__ red, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (dbeta) dbeta[c] += (float)red[c];
+  if (dgamma) dgamma[c] += (float)red[C + c];
+}
+
+__global__ void act_fwd_kernel(const float* __restrict__ x, long long n, int act, float* __restrict__ out) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = act_fwd(x[i], act);
+}
+__global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dout, long long n, int act,
+                               float* __restrict__ dx) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    dx[i] = dout[i] * act_grad(x[i], act);
+}
+
+static int reduce_grid_x(long long P, int rpp) {
+  long long g = (P + (long long)rpp * 64 - 1) / ((long long)rpp * 64);  // >= 64 rows per thread
+  if (g > 512) g = 512;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+extern "C" int yolo_bn_stats(const float* x, long long P, int C, double* stats, void* stream) {
+  YOLO_REQUIRE(x && stats && P > 0 && C > 0, "bn_stats: bad args");
+  YOLO_REQUIRE(C % 4 == 0, "bn_stats: C=%d must be a multiple of 4", C);
+  const ColGeom g = col_geom(C / 4);
+  dim3 grid(reduce_grid_x(P, g.rpp), (C / 4 + g.cw - 1) / g.cw);
+  hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, as_stream(stream), x, P, C, g.cw, g.rpp, stats);
+  return check_launch("bn_stats_kernel");
+}
+
+extern "C" int yolo_bn_finalize(double* stats, long long P, int C, const float* gamma, const float* beta, float eps,
+                                float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
+                                float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+  YOLO_REQUIRE(stats && gamma && beta && scale && shift && save_mean && save_invstd && P > 0 && C > 0,
+               "bn_finalize: bad args");
+  YOLO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must come in pairs");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), stats, P, C, gamma,
+                     beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var, scale, shift, save_mean,
+                     save_invstd);
+  return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int yolo_bn_fold_inference(int C, const float* gamma, const float* beta, const float* moving_mean,
+                                      const float* moving_var, float eps, float* scale, float* shift, void* stream) {
+  YOLO_REQUIRE(C > 0 && gamma && beta && moving_mean && moving_var && scale && shift, "bn_fold: bad args");
+  hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), C, gamma, beta,
+                     moving_mean, moving_var, eps, scale, shift);
+  return check_launch("bn_fold_kernel");
+}
+
+extern "C" int yolo_bn_act_fwd(const float* x, long long P, int C, const float* scale, const float* shift, int act,
+                               const float* residual, float* out, void* stream) {
+  YOLO_REQUIRE(x && scale && shift && out && P > 0 && C > 0, "bn_act_fwd: bad args");
+  YOLO_REQUIRE(C % 4 == 0, "bn_act_fwd: C=%d must be a multiple of 4", C);
+  YOLO_REQUIRE(act >= 0 && act <= 2, "bn_act_fwd: bad activation %d", act);
+  const long long n4 = P * (C / 4);
+  hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, as_stream(stream), x, n4, C / 4,
+                     scale, shift, act, residual, out);
+  return check_launch("bn_act_fwd_kernel");
+}
+
+extern "C" int yolo_bn_act_bwd_reduce(const float* x, const float* dout, long long P, int C, const float* scale,
+                                      const float* shift, const float* save_mean, const float* save_invstd, int act,
+                                      double* red, void* stream) {
+  YOLO_REQUIRE(x && dout && scale && shift && save_mean && save_invstd && red && P > 0 && C > 0,
+               "bn_act_bwd_reduce: bad args");
+  YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_reduce: C=%d must be a multiple of 4", C);
+  const ColGeom g = col_geom(C / 4);
+  dim3 grid(reduce_grid_x(P, g.rpp), (C / 4 + g.cw - 1) / g.cw);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, dout, P, C, g.cw, g.rpp, scale,
+                     shift, save_mean, save_invstd, act, red);
+  return check_launch("bn_bwd_reduce_kernel");
+}
+
+extern "C" int yolo_bn_act_bwd_apply(const float* x, const float* dout, long long P, int C, const float* gamma,
+                                     const float* scale, const float* shift, const float* save_mean,
+                                     const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,
+                                     float* dx, void* stream) {
+  (void)gamma;
+  YOLO_REQUIRE(x && dout && scale && shift && save_mean && save_invstd && red && dx && P > 0 && C > 0,
+               "bn_act_bwd_apply: bad args");
+  YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_apply: C=%d must be a multiple of 4", C);
+  const long long n4 = P * (C / 4);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, st, x, dout, n4, C / 4,
+                     1.0 / (double)P, scale, shift, save_mean, save_invstd, act, red, dx);
+  if (int rc = check_launch("bn_bwd_apply_kernel")) return rc;
+  if (dgamma || dbeta) {
+    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, red, dgamma, dbeta);
+    return check_launch("bn_bwd_params_kernel");
+  }
+  return YOLO_OK;
+}
+
+extern "C" int yolo_act_fwd(const float* x, long long n, int act, float* out, void* stream) {
+  YOLO_REQUIRE(x && out && n > 0, "act_fwd: bad args");
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), x, n, act, out);
+  return check_launch("act_fwd_kernel");
+}
+extern "C" int yolo_act_bwd(const float* x, const float* dout, long long n, int act, float* dx, void* stream) {
+  YOLO_REQUIRE(x && dout && dx && n > 0, "act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), x, dout, n, act, dx);
+  return check_launch("act_bwd_kernel");
+}

@@ -1,0 +1,707 @@
+// Implicit-GEMM convolution for gfx950 on the exact-fp32 matrix instruction
+// v_mfma_f32_32x32x2_f32 (64 FLOP/clk/SIMD, 157 TFLOP/s chip peak).
+//
+// Replaces tf.keras Conv2D forward and the TF autodiff conv gradients used by
+//   yolov3/models/backbone.py:27-36 (DarknetConv2D), yolov4/models/backbone.py:63-74,
+//   yolov1_5/models/backbone.py:9-16, yolov2/models/backbone.py:11-18,
+//   head convs yolov3/models/__init__.py:40-58.
+//
+// One "gather" kernel serves forward, stride-1 dgrad and stride-2 dgrad (the latter as
+// s*s parity classes with sub-filters), because all three are
+//     dst[n, y*osy+ooy, x*osx+oox, co] (+)= bias[co] +
+//         sum_{t in taps} sum_{c} src[n, y*sy+oy_t, x*sx+ox_t, c] * W[co][woff_t + c]
+// over an output grid (y, x) in [0,Hg) x [0,Wg): no im2col buffer, no padded copy, the
+// zero padding is a bounds test on the source pixel.
+//
+// GEMM view: M = N*Hg*Wg output pixels (rows, A operand), N = Cout (columns, B operand),
+// K = ntaps*Cs. A block owns a BM x BN tile; K is walked in BK = 32 slices that never
+// straddle a tap (Cs % 32 == 0; otherwise the FLAT variant decodes k -> (tap, c) per
+// element, used for the Cin = 3 stem and the 255-channel head gradient).
+//
+// Data path per K slice: global (16 B/lane, rows of 128 B) -> registers -> LDS
+// [rows][32+4] (pad 4 floats: the ds_read_b128 fragment reads of 16 distinct rows hit 16
+// distinct 4-bank groups, conflict-free) -> one ds_read_b128 per 32-row fragment per 8 k
+// -> 4 MFMAs per fragment pair. The k order inside a slice is permuted identically for A
+// and B (lane half h reads k = 8q+4h..8q+4h+3), which the contraction does not care about.
+// Double-buffered LDS, one barrier per slice, next slice's global loads in flight during
+// the 64 MFMAs (4096 cycles) of the current one.
+#include "common.hpp"
+
+namespace yolo {
+
+constexpr int MAX_TAPS = 49;
+
+struct Tap {
+  int oy, ox, woff;
+};
+
+struct GatherConvArgs {
+  const float* src;
+  const float* wgt;
+  const float* bias;
+  float* dst;
+  long long M;  // N*Hg*Wg
+  int N, Hs, Ws, Cs;
+  int Hg, Wg;
+  int sy, sx;
+  int Hd, Wd, Cd;
+  int osy, osx, ooy, oox;
+  int Cout, ldw;
+  int ntaps, accumulate;
+  int kw, pad_t, pad_l;  // FLAT mode: tap t = (r*kw+s), oy = r-pad_t, ox = s-pad_l
+  int tiles_n;
+  int nblocks;
+  Tap taps[MAX_TAPS];
+};
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
+// logical tiles so tiles that share A rows / B columns hit the same L2. Bijective for any
+// grid size (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+template <int BM, int BN, int WGM, int WGN, bool FLAT>
+__global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a) {
+  constexpr int BK = 32;
+  constexpr int LD = BK + 4;
+  constexpr int TM = BM / WGM / 32;
+  constexpr int TN = BN / WGN / 32;
+  constexpr int AR = BM / 32;  // A rows staged per thread
+  constexpr int BR = BN / 32;  // B rows staged per thread
+  static_assert(WGM * WGN == 4, "4 waves per block");
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BUF = (BM + BN) * LD;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int tile = xcd_remap(blockIdx.x, a.nblocks);
+  const int tile_n = tile % a.tiles_n;
+  const int tile_m = tile / a.tiles_n;
+  const long long m0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const int lrow = tid >> 3;
+  const int kcol = (tid & 7) * 4;
+
+  // Per-thread descriptors of the A rows it stages (fixed for the whole K loop).
+  int rowbase[AR];  // n*Hs
+  int ys0[AR], xs0[AR];
+  const int HgWg = a.Hg * a.Wg;
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    const long long m = m0 + lrow + 32 * i;
+    if (m < a.M) {
+      const int n = (int)(m / HgWg);
+      const int rem = (int)(m - (long long)n * HgWg);
+      const int y = rem / a.Wg;
+      const int x = rem - y * a.Wg;
+      rowbase[i] = n * a.Hs;
+      ys0[i] = y * a.sy;
+      xs0[i] = x * a.sx;
+    } else {
+      rowbase[i] = 0;
+      ys0[i] = -(1 << 28);  // fails every bounds test
+      xs0[i] = 0;
+    }
+  }
+
+  const int Ktot = a.ntaps * a.Cs;
+  const int cpt = FLAT ? 1 : a.Cs / BK;                  // K slices per tap
+  const int nk = FLAT ? (Ktot + BK - 1) / BK : a.ntaps * cpt;
+
+  f32x4 ra[AR], rb[BR];
+
+  auto load_slice = [&](int kt) {
+    if constexpr (!FLAT) {
+      const int tap = kt / cpt;
+      const int c0 = (kt - tap * cpt) * BK;
+      const int oy = a.taps[tap].oy, ox = a.taps[tap].ox, woff = a.taps[tap].woff;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int ys = ys0[i] + oy, xs = xs0[i] + ox;
+        const bool ok = ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
+        const long long off = ((long long)(rowbase[i] + ys) * a.Ws + xs) * a.Cs + c0 + kcol;
+        const float* p = ok ? (a.src + off) : a.src;
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < BR; ++j) {
+        const int co = n0 + lrow + 32 * j;
+        const bool ok = co < a.Cout;
+        const float* p = ok ? (a.wgt + (long long)co * a.ldw + woff + c0 + kcol) : a.wgt;
+        f32x4 v = *reinterpret_cast<const f32x4*>(p);
+        rb[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+      const int kbase = kt * BK + kcol;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = kbase + e;
+        const bool kok = k < Ktot;
+        const int tap = kok ? k / a.Cs : 0;
+        const int c = k - tap * a.Cs;
+        const int r = tap / a.kw;
+        const int s = tap - r * a.kw;
+        const int oy = r - a.pad_t, ox = s - a.pad_l;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+          const int ys = ys0[i] + oy, xs = xs0[i] + ox;
+          const bool ok = kok && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
+          const long long off = ((long long)(rowbase[i] + ys) * a.Ws + xs) * a.Cs + c;
+          const float* p = ok ? (a.src + off) : a.src;
+          const float v = *p;
+          ra[i][e] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+          const int co = n0 + lrow + 32 * j;
+          const bool ok = kok && (co < a.Cout);
+          const float* p = ok ? (a.wgt + (long long)co * a.ldw + k) : a.wgt;
+          const float v = *p;
+          rb[j][e] = ok ? v : 0.f;
+        }
+      }
+    }
+  };
+
+  auto store_slice = [&](int buf) {
+    float* sA = smem + buf * BUF;
+    float* sB = sA + BM * LD;
+#pragma unroll
+    for (int i = 0; i < AR; ++i)
+      *reinterpret_cast<f32x4*>(&sA[(lrow + 32 * i) * LD + kcol]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < BR; ++j)
+      *reinterpret_cast<f32x4*>(&sB[(lrow + 32 * j) * LD + kcol]) = rb[j];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int frag_row = lane & 31;
+  const int frag_k = (lane >> 5) * 4;
+
+  load_slice(0);
+  store_slice(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_slice(kt + 1);
+
+    const float* sA = smem + buf * BUF + (wm * TM * 32 + frag_row) * LD + frag_k;
+    const float* sB = smem + buf * BUF + BM * LD + (wn * TN * 32 + frag_row) * LD + frag_k;
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LD + q * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * LD + q * 8);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+
+    if (kt + 1 < nk) store_slice(buf ^ 1);
+    __syncthreads();
+  }
+
+  // Epilogue. Row -> destination offset table through LDS (the K loop is done with it).
+  long long* rowoff = reinterpret_cast<long long*>(smem);
+  for (int r = tid; r < BM; r += 256) {
+    const long long m = m0 + r;
+    long long off = -1;
+    if (m < a.M) {
+      const int n = (int)(m / HgWg);
+      const int rem = (int)(m - (long long)n * HgWg);
+      const int y = rem / a.Wg;
+      const int x = rem - y * a.Wg;
+      off = (((long long)n * a.Hd + (y * a.osy + a.ooy)) * a.Wd + (x * a.osx + a.oox)) * a.Cd;
+    }
+    rowoff[r] = off;
+  }
+  __syncthreads();
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+    const bool cok = col < a.Cout;
+    const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        const long long off = rowoff[row];
+        if (cok && off >= 0) {
+          float v = acc[i][j][r] + bv;
+          if (a.accumulate) v += a.dst[off + col];
+          a.dst[off + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool FLAT>
+static int launch_gather(GatherConvArgs& a, hipStream_t st) {
+  const long long tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.Cout + BN - 1) / BN;
+  const long long nb = tiles_m * a.tiles_n;
+  if (nb <= 0 || nb > 0x7fffffffLL) {
+    set_error("conv: bad grid %lld", nb);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  a.nblocks = (int)nb;
+  constexpr size_t lds = 2 * (BM + BN) * 36 * sizeof(float);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_kernel<BM, BN, WGM, WGN, FLAT>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gather_conv_kernel<BM, BN, WGM, WGN, FLAT>), dim3((unsigned)nb), dim3(256), lds, st, a);
+  return check_launch("gather_conv_kernel");
+}
+
+static int dispatch_gather(GatherConvArgs& a, bool flat, hipStream_t st) {
+  // every configuration keeps LDS <= 80 KB so that two workgroups share a CU
+  if (flat) {
+    if (a.Cout <= 32) return launch_gather<128, 32, 4, 1, true>(a, st);
+    if (a.Cout <= 64) return launch_gather<128, 64, 2, 2, true>(a, st);
+    return launch_gather<128, 128, 2, 2, true>(a, st);
+  }
+  if (a.Cout <= 32) return launch_gather<128, 32, 4, 1, false>(a, st);
+  if (a.Cout <= 64) return launch_gather<128, 64, 2, 2, false>(a, st);
+  return launch_gather<128, 128, 2, 2, false>(a, st);
+}
+
+static int validate_desc(const yolo_conv_desc* d) {
+  YOLO_REQUIRE(d != nullptr, "conv: null descriptor");
+  YOLO_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "conv: non-positive dims");
+  YOLO_REQUIRE(d->kh > 0 && d->kw > 0 && d->kh * d->kw <= MAX_TAPS, "conv: kernel %dx%d unsupported", d->kh, d->kw);
+  YOLO_REQUIRE(d->sh >= 1 && d->sw >= 1 && d->sh <= 2 && d->sw <= 2, "conv: stride %dx%d unsupported", d->sh, d->sw);
+  YOLO_REQUIRE(d->Ho > 0 && d->Wo > 0, "conv: bad output size");
+  YOLO_REQUIRE(d->pad_t >= 0 && d->pad_l >= 0 && d->pad_t < d->kh && d->pad_l < d->kw, "conv: bad padding");
+  // every output pixel's window must start inside the (virtually) padded input
+  YOLO_REQUIRE((long long)(d->Ho - 1) * d->sh - d->pad_t < d->H && (long long)(d->Wo - 1) * d->sw - d->pad_l < d->W,
+               "conv: output %dx%d too large for input %dx%d", d->Ho, d->Wo, d->H, d->W);
+  YOLO_REQUIRE((long long)d->N * d->H * d->W * d->Cin < (1LL << 31) &&
+               (long long)d->N * d->Ho * d->Wo * d->Cout < (1LL << 31), "conv: tensor too large");
+  return YOLO_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// wgrad: dW[co][t][ci] += sum_p dy[p][co] * src[p -> tap t][ci].
+// GEMM view: rows = co (A operand, from dy), cols = ci within one tap (B operand, gathered
+// from src), contraction over pixels p, split over blocks (grid.y) and combined with fp32
+// atomics (one 128-B segment per lane-half per store, the full-rate shape).
+// Both operands arrive pixel-major, so the LDS images are [32 pixels][BM|BN] and the
+// fragments are ds_read_b32 with consecutive lanes on consecutive banks.
+// ---------------------------------------------------------------------------------------
+struct WgradArgs {
+  const float* src;
+  const float* dy;
+  float* dw;
+  long long M;  // N*Hg*Wg pixels
+  int N, Hs, Ws, Cs;
+  int Hg, Wg;
+  int sy, sx;
+  int Cout, ldw;
+  int ntaps;
+  int kw, pad_t, pad_l;  // BFLAT column decode
+  int tiles_co, tiles_ci;  // tiles_ci = column tiles per tap (or total in BFLAT)
+  long long chunk;         // pixels per split (multiple of 32)
+  Tap taps[MAX_TAPS];
+};
+
+template <int BM, int BN, int WGM, int WGN, bool ASCALAR, bool BFLAT>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+  constexpr int BK = 32;
+  constexpr int TM = BM / WGM / 32;
+  constexpr int TN = BN / WGN / 32;
+  constexpr int AF4 = BM / 4;            // float4 per pixel row of A
+  constexpr int ARP = 256 / AF4;         // pixel rows per pass
+  constexpr int AP = (BK + ARP - 1) / ARP;
+  constexpr int BF4 = BN / 4;
+  constexpr int BRP = 256 / BF4;
+  constexpr int BP = (BK + BRP - 1) / BRP;
+  static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(ARP <= BK && BRP <= BK, "tile too narrow");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int BUF = BK * (BM + BN);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int tile_co = blockIdx.x % a.tiles_co;
+  const int rest = blockIdx.x / a.tiles_co;
+  int tap = 0, ci0 = 0, oy = 0, ox = 0, woff = 0;
+  if constexpr (!BFLAT) {
+    tap = rest / a.tiles_ci;
+    ci0 = (rest - tap * a.tiles_ci) * BN;
+    oy = a.taps[tap].oy;
+    ox = a.taps[tap].ox;
+    woff = a.taps[tap].woff;
+  } else {
+    ci0 = rest * BN;  // flat column index j0 over ntaps*Cs
+  }
+  const int co0 = tile_co * BM;
+  const long long p_begin = (long long)blockIdx.y * a.chunk;
+  long long p_end = p_begin + a.chunk;
+  if (p_end > a.M) p_end = a.M;
+  if (p_begin >= p_end) return;
+  const int nk = (int)((p_end - p_begin + BK - 1) / BK);
+
+  const int a_row = tid / AF4, a_col = (tid % AF4) * 4;
+  const int b_row = tid / BF4, b_col = (tid % BF4) * 4;
+  const int HgWg = a.Hg * a.Wg;
+  const int Ktot = a.ntaps * a.Cs;
+
+  f32x4 ra[AP], rb[BP];
+
+  auto load_slice = [&](int kt) {
+    const long long pbase = p_begin + (long long)kt * BK;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const long long p = pbase + a_row + i * ARP;
+      const bool pok = p < p_end;
+      if constexpr (!ASCALAR) {
+        const bool ok = pok && (co0 + a_col < a.Cout);
+        const float* ptr = ok ? (a.dy + p * a.Cout + co0 + a_col) : a.dy;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ptr);
+        ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = pok && (co0 + a_col + e < a.Cout);
+          const float* ptr = ok ? (a.dy + p * a.Cout + co0 + a_col + e) : a.dy;
+          const float v = *ptr;
+          ra[i][e] = ok ? v : 0.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const long long p = pbase + b_row + i * BRP;
+      const bool pok = p < p_end;
+      const long long pp = pok ? p : 0;
+      const int n = (int)(pp / HgWg);
+      const int rem = (int)(pp - (long long)n * HgWg);
+      const int y = rem / a.Wg;
+      const int x = rem - y * a.Wg;
+      if constexpr (!BFLAT) {
+        const int ys = y * a.sy + oy, xs = x * a.sx + ox;
+        const bool ok = pok && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws) &&
+                        (ci0 + b_col < a.Cs);
+        const long long off = ((long long)(n * a.Hs + ys) * a.Ws + xs) * a.Cs + ci0 + b_col;
+        const float* ptr = ok ? (a.src + off) : a.src;
+        f32x4 v = *reinterpret_cast<const f32x4*>(ptr);
+        rb[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = ci0 + b_col + e;
+          const bool jok = j < Ktot;
+          const int t = jok ? j / a.Cs : 0;
+          const int c = j - t * a.Cs;
+          const int r = t / a.kw;
+          const int s = t - r * a.kw;
+          const int ys = y * a.sy + r - a.pad_t, xs = x * a.sx + s - a.pad_l;
+          const bool ok = pok && jok && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
+          const long long off = ((long long)(n * a.Hs + ys) * a.Ws + xs) * a.Cs + c;
+          const float* ptr = ok ? (a.src + off) : a.src;
+          const float v = *ptr;
+          rb[i][e] = ok ? v : 0.f;
+        }
+      }
+    }
+  };
+
+  auto store_slice = [&](int buf) {
+    float* sA = smem + buf * BUF;
+    float* sB = sA + BK * BM;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int r = a_row + i * ARP;
+      if (r < BK) *reinterpret_cast<f32x4*>(&sA[r * BM + a_col]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int r = b_row + i * BRP;
+      if (r < BK) *reinterpret_cast<f32x4*>(&sB[r * BN + b_col]) = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int fr = lane & 31, fh = lane >> 5;
+
+  load_slice(0);
+  store_slice(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_slice(kt + 1);
+    const float* sA = smem + buf * BUF + fh * BM + wm * TM * 32 + fr;
+    const float* sB = smem + buf * BUF + BK * BM + fh * BN + wn * TN * 32 + fr;
+#pragma unroll
+    for (int s = 0; s < BK / 2; ++s) {
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = sA[2 * s * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = sB[2 * s * BN + j * 32];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) store_slice(buf ^ 1);
+    __syncthreads();
+  }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cj = ci0 + (wn * TN + j) * 32 + (lane & 31);
+    const bool cok = BFLAT ? (cj < Ktot) : (cj < a.Cs);
+    const int wcol = BFLAT ? cj : (woff + cj);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (cok && co < a.Cout) atomicAdd(&a.dw[(long long)co * a.ldw + wcol], acc[i][j][r]);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN, bool ASCALAR, bool BFLAT>
+static int launch_wgrad(WgradArgs& a, hipStream_t st) {
+  a.tiles_co = (a.Cout + BM - 1) / BM;
+  const int cols = BFLAT ? a.ntaps * a.Cs : a.Cs;
+  a.tiles_ci = (cols + BN - 1) / BN;
+  const long long tiles = (long long)a.tiles_co * a.tiles_ci * (BFLAT ? 1 : a.ntaps);
+  // split the pixel contraction so that the grid has ~4 blocks per CU
+  long long splits = (1024 + tiles - 1) / tiles;
+  const long long max_splits = (a.M + 255) / 256;  // at least 8 K-slices per block
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  long long chunk = (a.M + splits - 1) / splits;
+  chunk = (chunk + 31) / 32 * 32;
+  splits = (a.M + chunk - 1) / chunk;
+  a.chunk = chunk;
+  if (tiles > 0x7fffffffLL || splits > 65535) {
+    set_error("wgrad: bad grid %lld x %lld", tiles, splits);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  constexpr size_t lds = 2 * 32 * (BM + BN) * sizeof(float);
+  hipLaunchKernelGGL((wgrad_kernel<BM, BN, WGM, WGN, ASCALAR, BFLAT>), dim3((unsigned)tiles, (unsigned)splits),
+                     dim3(256), lds, st, a);
+  return check_launch("wgrad_kernel");
+}
+
+template <bool ASCALAR, bool BFLAT>
+static int dispatch_wgrad(WgradArgs& a, hipStream_t st) {
+  const int cols = BFLAT ? a.ntaps * a.Cs : a.Cs;
+  if (a.Cout <= 32) return launch_wgrad<32, 128, 1, 4, ASCALAR, BFLAT>(a, st);
+  if (cols <= 32) return launch_wgrad<128, 32, 4, 1, ASCALAR, BFLAT>(a, st);
+  if (a.Cout <= 64 && cols <= 64) return launch_wgrad<64, 64, 2, 2, ASCALAR, BFLAT>(a, st);
+  if (a.Cout <= 64) return launch_wgrad<64, 128, 2, 2, ASCALAR, BFLAT>(a, st);
+  if (cols <= 64) return launch_wgrad<128, 64, 2, 2, ASCALAR, BFLAT>(a, st);
+  return launch_wgrad<128, 128, 2, 2, ASCALAR, BFLAT>(a, st);
+}
+
+// wT[ci][t][co] = w[co][t][ci]
+__global__ void filter_transpose_kernel(const float* __restrict__ w, float* __restrict__ wT, int Cout, int taps,
+                                        int Cin) {
+  __shared__ float tile[32][33];
+  const int t = blockIdx.z;
+  const int co0 = blockIdx.y * 32, ci0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    tile[r][tx] = (co < Cout && ci < Cin) ? w[((long long)co * taps + t) * Cin + ci] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    if (ci < Cin && co < Cout) wT[((long long)ci * taps + t) * Cout + co] = tile[tx][r];
+  }
+}
+
+// column sums of dy[P][C] into out[C] (fp32 atomics); used for conv bias gradients
+__global__ void colsum_kernel(const float* __restrict__ x, long long P, int C, float* __restrict__ out) {
+  // block: 256 threads = (256/cw) pixel rows x cw channel lanes, cw = min(C,256) rounded to pow2<=256
+  const int c = blockIdx.y * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (long long p = (long long)blockIdx.x * blockDim.y + threadIdx.y; p < P; p += (long long)gridDim.x * blockDim.y)
+    s += x[p * C + c];
+  atomicAdd(&out[c], s);
+}
+
+}  // namespace yolo
+
+using namespace yolo;
+
+extern "C" int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                               double* stats, void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x && w && y, "conv_fwd: null pointer");
+  GatherConvArgs a{};
+  a.src = x;
+  a.wgt = w;
+  a.bias = bias;
+  a.dst = y;
+  a.N = d->N; a.Hs = d->H; a.Ws = d->W; a.Cs = d->Cin;
+  a.Hg = d->Ho; a.Wg = d->Wo;
+  a.sy = d->sh; a.sx = d->sw;
+  a.Hd = d->Ho; a.Wd = d->Wo; a.Cd = d->Cout;
+  a.osy = 1; a.osx = 1; a.ooy = 0; a.oox = 0;
+  a.Cout = d->Cout;
+  a.ldw = d->kh * d->kw * d->Cin;
+  a.ntaps = d->kh * d->kw;
+  a.accumulate = 0;
+  a.kw = d->kw; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+  a.M = (long long)d->N * d->Ho * d->Wo;
+  for (int r = 0; r < d->kh; ++r)
+    for (int s = 0; s < d->kw; ++s) a.taps[r * d->kw + s] = Tap{r - d->pad_t, s - d->pad_l, (r * d->kw + s) * d->Cin};
+  const bool flat = (d->Cin % 32) != 0;
+  if (int rc = dispatch_gather(a, flat, as_stream(stream))) return rc;
+  if (stats != nullptr) return yolo_bn_stats(y, a.M, d->Cout, stats, stream);
+  return YOLO_OK;
+}
+
+extern "C" int yolo_conv2d_dgrad(const yolo_conv_desc* d, const float* dy, const float* wT, float* dx, int accumulate,
+                                 void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(dy && wT && dx, "conv_dgrad: null pointer");
+  // hi = ho*sh + r - pad_t  =>  for input-row parity class py (hi = y*sh + py) the taps with
+  // (py + pad_t - r) % sh == 0 contribute from ho = y + (py + pad_t - r)/sh.
+  const bool flat = (d->Cout % 32) != 0;
+  YOLO_REQUIRE(!flat || (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1),
+               "conv_dgrad: Cout %% 32 != 0 only supported for 1x1 stride-1 (head) convs");
+  for (int py = 0; py < d->sh; ++py) {
+    for (int px = 0; px < d->sw; ++px) {
+      GatherConvArgs a{};
+      a.src = dy;
+      a.wgt = wT;
+      a.bias = nullptr;
+      a.dst = dx;
+      a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
+      a.Hg = (d->H - py + d->sh - 1) / d->sh;
+      a.Wg = (d->W - px + d->sw - 1) / d->sw;
+      if (a.Hg <= 0 || a.Wg <= 0) continue;
+      a.sy = 1; a.sx = 1;
+      a.Hd = d->H; a.Wd = d->W; a.Cd = d->Cin;
+      a.osy = d->sh; a.osx = d->sw; a.ooy = py; a.oox = px;
+      a.Cout = d->Cin;
+      a.ldw = d->kh * d->kw * d->Cout;
+      a.accumulate = accumulate;
+      a.kw = 1; a.pad_t = 0; a.pad_l = 0;
+      a.M = (long long)d->N * a.Hg * a.Wg;
+      int nt = 0;
+      for (int r = 0; r < d->kh; ++r) {
+        const int ty = py + d->pad_t - r;
+        if (((ty % d->sh) + d->sh) % d->sh != 0) continue;
+        for (int s = 0; s < d->kw; ++s) {
+          const int tx = px + d->pad_l - s;
+          if (((tx % d->sw) + d->sw) % d->sw != 0) continue;
+          // exact division (ty, tx are multiples of the stride, possibly negative)
+          a.taps[nt++] = Tap{ty / d->sh, tx / d->sw, (r * d->kw + s) * d->Cout};
+        }
+      }
+      a.ntaps = nt;
+      if (nt == 0) {
+        // this parity class receives no gradient: write zeros unless accumulating
+        if (!accumulate) {
+          a.ntaps = 1;
+          a.taps[0] = Tap{-(1 << 20), -(1 << 20), 0};  // always out of bounds => zeros
+        } else {
+          continue;
+        }
+      }
+      if (int rc = dispatch_gather(a, flat, as_stream(stream))) return rc;
+    }
+  }
+  return YOLO_OK;
+}
+
+extern "C" int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                 void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x && dy && dw, "conv_wgrad: null pointer");
+  WgradArgs a{};
+  a.src = x;
+  a.dy = dy;
+  a.dw = dw;
+  a.N = d->N; a.Hs = d->H; a.Ws = d->W; a.Cs = d->Cin;
+  a.Hg = d->Ho; a.Wg = d->Wo;
+  a.sy = d->sh; a.sx = d->sw;
+  a.Cout = d->Cout;
+  a.ldw = d->kh * d->kw * d->Cin;
+  a.ntaps = d->kh * d->kw;
+  a.kw = d->kw; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
+  a.M = (long long)d->N * d->Ho * d->Wo;
+  for (int r = 0; r < d->kh; ++r)
+    for (int s = 0; s < d->kw; ++s) a.taps[r * d->kw + s] = Tap{r - d->pad_t, s - d->pad_l, (r * d->kw + s) * d->Cin};
+  const bool ascalar = (d->Cout % 4) != 0;
+  const bool bflat = (d->Cin % 4) != 0;
+  int rc;
+  hipStream_t st = as_stream(stream);
+  if (ascalar && bflat) rc = dispatch_wgrad<true, true>(a, st);
+  else if (ascalar) rc = dispatch_wgrad<true, false>(a, st);
+  else if (bflat) rc = dispatch_wgrad<false, true>(a, st);
+  else rc = dispatch_wgrad<false, false>(a, st);
+  if (rc) return rc;
+  if (dbias != nullptr) {
+    int cw = 32;
+    while (cw < d->Cout && cw < 256) cw <<= 1;
+    dim3 block(cw, 256 / cw);
+    const int gy = (d->Cout + cw - 1) / cw;
+    long long gx = (a.M + block.y * 64 - 1) / (block.y * 64);
+    if (gx > 1024) gx = 1024;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx, gy), block, 0, st, dy, a.M, d->Cout, dbias);
+    return check_launch("colsum_kernel");
+  }
+  return YOLO_OK;
+}
+
+extern "C" int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream) {
+  YOLO_REQUIRE(w && wT && Cout > 0 && taps > 0 && Cin > 0, "filter_transpose: bad args");
+  dim3 grid((Cin + 31) / 32, (Cout + 31) / 32, taps);
+  hipLaunchKernelGGL(filter_transpose_kernel, grid, dim3(256), 0, as_stream(stream), w, wT, Cout, taps, Cin);
+  return check_launch("filter_transpose_kernel");
+}

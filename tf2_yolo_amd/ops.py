@@ -1,0 +1,333 @@
+"""Host-side operator layer: torch tensors in, C-ABI calls out.
+
+torch is plumbing only (device memory, streams). Every function enqueues hand-written HIP
+kernels from libyolo_hip.so on torch's current stream and raises `YoloHipError` on failure;
+nothing here computes on the CPU or through torch operators.
+"""
+import ctypes
+from ctypes import byref, c_void_p
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, LossCfg, YoloHipError, check
+
+BN_EPS = 1e-3       # Keras BatchNormalization default
+BN_MOMENTUM = 0.99
+
+
+def _stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return c_void_p(0)
+    return c_void_p(t.data_ptr())
+
+
+def _chk_f32(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise YoloHipError("expected a contiguous float32 CUDA tensor, got "
+                               f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+def same_pad(size, k, s):
+    """Keras/TF 'same' padding: returns (out, pad_before); the smaller half goes before."""
+    out = -(-size // s)
+    total = max((out - 1) * s + k - size, 0)
+    return out, total // 2
+
+
+def conv_desc(x_shape, cout, kh, kw, stride, padding):
+    """padding: 'same' | 'valid' | 'darknet_s2' (ZeroPadding2D(((1,0),(1,0))) + valid)."""
+    n, h, w, cin = x_shape
+    if padding == "same":
+        ho, pt = same_pad(h, kh, stride)
+        wo, pl = same_pad(w, kw, stride)
+    elif padding == "valid":
+        ho, wo, pt, pl = (h - kh) // stride + 1, (w - kw) // stride + 1, 0, 0
+    elif padding == "darknet_s2":
+        ho, wo, pt, pl = (h + 1 - kh) // stride + 1, (w + 1 - kw) // stride + 1, 1, 1
+    else:
+        raise ValueError(f"bad padding {padding}")
+    return ConvDesc(n, h, w, cin, cout, kh, kw, ho, wo, stride, stride, pt, pl)
+
+
+def conv2d_fwd(d, x, w, bias=None, out=None, stats=None):
+    _chk_f32(x, w, bias)
+    if out is None:
+        out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=x.device, dtype=torch.float32)
+    if x.numel() != d.N * d.H * d.W * d.Cin or w.numel() != d.Cout * d.kh * d.kw * d.Cin:
+        raise YoloHipError("conv2d_fwd: tensor sizes do not match the descriptor")
+    if out.numel() != d.N * d.Ho * d.Wo * d.Cout:
+        raise YoloHipError("conv2d_fwd: output size does not match the descriptor")
+    check(_lib.load().yolo_conv2d_fwd(byref(d), _p(x), _p(w), _p(bias), _p(out), _p(stats), _stream()),
+          "yolo_conv2d_fwd")
+    return out
+
+
+def filter_transpose(w, cout, taps, cin, out=None):
+    _chk_f32(w)
+    if out is None:
+        out = torch.empty(cin * taps * cout, device=w.device, dtype=torch.float32)
+    check(_lib.load().yolo_filter_transpose(_p(w), _p(out), cout, taps, cin, _stream()), "yolo_filter_transpose")
+    return out
+
+
+def conv2d_dgrad(d, dy, wT, dx=None, accumulate=False):
+    _chk_f32(dy, wT)
+    if dx is None:
+        dx = torch.empty((d.N, d.H, d.W, d.Cin), device=dy.device, dtype=torch.float32)
+        accumulate = False
+    if dy.numel() != d.N * d.Ho * d.Wo * d.Cout or dx.numel() != d.N * d.H * d.W * d.Cin:
+        raise YoloHipError("conv2d_dgrad: tensor sizes do not match the descriptor")
+    check(_lib.load().yolo_conv2d_dgrad(byref(d), _p(dy), _p(wT), _p(dx), int(bool(accumulate)), _stream()),
+          "yolo_conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(d, x, dy, dw, dbias=None):
+    _chk_f32(x, dy, dw, dbias)
+    if dw.numel() != d.Cout * d.kh * d.kw * d.Cin:
+        raise YoloHipError("conv2d_wgrad: dw size does not match the descriptor")
+    check(_lib.load().yolo_conv2d_wgrad(byref(d), _p(x), _p(dy), _p(dw), _p(dbias), _stream()), "yolo_conv2d_wgrad")
+    return dw
+
+
+def bn_stats(x, C, stats):
+    P = x.numel() // C
+    check(_lib.load().yolo_bn_stats(_p(x), P, C, _p(stats), _stream()), "yolo_bn_stats")
+
+
+def bn_finalize(stats, P, C, gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd,
+                eps=BN_EPS, momentum=BN_MOMENTUM, unbiased=False):
+    check(_lib.load().yolo_bn_finalize(_p(stats), P, C, _p(gamma), _p(beta), eps, momentum, int(unbiased),
+                                       _p(moving_mean), _p(moving_var), _p(scale), _p(shift), _p(save_mean),
+                                       _p(save_invstd), _stream()), "yolo_bn_finalize")
+
+
+def bn_fold_inference(C, gamma, beta, moving_mean, moving_var, scale, shift, eps=BN_EPS):
+    check(_lib.load().yolo_bn_fold_inference(C, _p(gamma), _p(beta), _p(moving_mean), _p(moving_var), eps,
+                                             _p(scale), _p(shift), _stream()), "yolo_bn_fold_inference")
+
+
+def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    P = x.numel() // C
+    check(_lib.load().yolo_bn_act_fwd(_p(x), P, C, _p(scale), _p(shift), act, _p(residual), _p(out), _stream()),
+          "yolo_bn_act_fwd")
+    return out
+
+
+def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dx=None):
+    if dx is None:
+        dx = torch.empty_like(x)
+    P = x.numel() // C
+    lib = _lib.load()
+    check(lib.yolo_bn_act_bwd_reduce(_p(x), _p(dout), P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
+                                     act, _p(red), _stream()), "yolo_bn_act_bwd_reduce")
+    check(lib.yolo_bn_act_bwd_apply(_p(x), _p(dout), P, C, _p(gamma), _p(scale), _p(shift), _p(save_mean),
+                                    _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta), _p(dx), _stream()),
+          "yolo_bn_act_bwd_apply")
+    return dx
+
+
+def act_fwd(x, act, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.load().yolo_act_fwd(_p(x), x.numel(), act, _p(out), _stream()), "yolo_act_fwd")
+    return out
+
+
+def act_bwd(x, dout, act, dx=None):
+    if dx is None:
+        dx = torch.empty_like(x)
+    check(_lib.load().yolo_act_bwd(_p(x), _p(dout), x.numel(), act, _p(dx), _stream()), "yolo_act_bwd")
+    return dx
+
+
+def copy_channels_in(src, Csrc, dst, Cdst, c_off):
+    P = src.numel() // Csrc
+    if dst.numel() != P * Cdst:
+        raise YoloHipError("copy_channels_in: pixel counts differ")
+    check(_lib.load().yolo_copy_channels_in(_p(src), P, Csrc, _p(dst), Cdst, c_off, _stream()),
+          "yolo_copy_channels_in")
+
+
+def copy_channels_out(src, Csrc, c_off, dst, Cdst, accumulate=False):
+    P = src.numel() // Csrc
+    if dst.numel() != P * Cdst:
+        raise YoloHipError("copy_channels_out: pixel counts differ")
+    check(_lib.load().yolo_copy_channels_out(_p(src), P, Csrc, c_off, _p(dst), Cdst, int(bool(accumulate)),
+                                             _stream()), "yolo_copy_channels_out")
+
+
+def upsample2x_fwd(x, y, Cy, c_off):
+    n, h, w, c = x.shape
+    if y.numel() != n * 4 * h * w * Cy:
+        raise YoloHipError("upsample2x_fwd: bad output size")
+    check(_lib.load().yolo_upsample2x_fwd(_p(x), n, h, w, c, _p(y), Cy, c_off, _stream()), "yolo_upsample2x_fwd")
+
+
+def upsample2x_bwd(dy, Cy, c_off, dx, accumulate=False):
+    n, h, w, c = dx.shape
+    if dy.numel() != n * 4 * h * w * Cy:
+        raise YoloHipError("upsample2x_bwd: bad input size")
+    check(_lib.load().yolo_upsample2x_bwd(_p(dy), n, h, w, c, Cy, c_off, _p(dx), int(bool(accumulate)), _stream()),
+          "yolo_upsample2x_bwd")
+
+
+def axpy(a, b):
+    if a.numel() != b.numel():
+        raise YoloHipError("axpy: size mismatch")
+    check(_lib.load().yolo_axpy(_p(a), _p(b), a.numel(), _stream()), "yolo_axpy")
+
+
+def fill(t, value):
+    check(_lib.load().yolo_fill(_p(t), t.numel(), float(value), _stream()), "yolo_fill")
+
+
+def maxpool_fwd(x, k, s, pad_t, pad_l, Ho, Wo, y, Cy, c_off, argmax):
+    n, h, w, c = x.shape
+    if y.numel() != n * Ho * Wo * Cy or (argmax is not None and argmax.numel() != n * Ho * Wo * c):
+        raise YoloHipError("maxpool_fwd: bad output size")
+    check(_lib.load().yolo_maxpool_fwd(_p(x), n, h, w, c, k, s, pad_t, pad_l, Ho, Wo, _p(y), Cy, c_off,
+                                       _p(argmax), _stream()), "yolo_maxpool_fwd")
+
+
+def maxpool_bwd(dy, N, Ho, Wo, C, Cy, c_off, argmax, dx):
+    check(_lib.load().yolo_maxpool_bwd(_p(dy), N, Ho, Wo, C, Cy, c_off, _p(argmax), _p(dx), _stream()),
+          "yolo_maxpool_bwd")
+
+
+def space_to_depth2_fwd(x, y, Cy, c_off):
+    n, h, w, c = x.shape
+    check(_lib.load().yolo_space_to_depth2_fwd(_p(x), n, h, w, c, _p(y), Cy, c_off, _stream()),
+          "yolo_space_to_depth2_fwd")
+
+
+def space_to_depth2_bwd(dy, Cy, c_off, dx, accumulate=False):
+    n, h, w, c = dx.shape
+    check(_lib.load().yolo_space_to_depth2_bwd(_p(dy), n, h, w, c, Cy, c_off, _p(dx), int(bool(accumulate)),
+                                               _stream()), "yolo_space_to_depth2_bwd")
+
+
+def head_act_fwd(t, A, C, version, anchors_dev, out=None):
+    if out is None:
+        out = torch.empty_like(t)
+    D = (5 * A + C) if version == 1 else A * (5 + C)
+    P = t.numel() // D
+    check(_lib.load().yolo_head_act_fwd(_p(t), P, A, C, version, _p(anchors_dev), _p(out), _stream()),
+          "yolo_head_act_fwd")
+    return out
+
+
+def head_act_bwd(y, dy, A, C, version, anchors_dev, dt=None, danchors=None):
+    if dt is None:
+        dt = torch.empty_like(y)
+    D = (5 * A + C) if version == 1 else A * (5 + C)
+    P = y.numel() // D
+    check(_lib.load().yolo_head_act_bwd(_p(y), _p(dy), P, A, C, version, _p(anchors_dev), _p(dt), _p(danchors),
+                                        _stream()), "yolo_head_act_bwd")
+    return dt
+
+
+def make_loss_cfg(version, N, gh, gw, A, C, anchors=None, binary_weight=1.0, loss_weight=(1, 1, 1, 1),
+                  ignore_thresh=0.6, use_focal_loss=False, focal_gamma=2.0, use_scale=True, wh_reg_weight=0.01,
+                  truth_thresh=1.0, label_smooth=0.0):
+    cfg = LossCfg()
+    cfg.version, cfg.N, cfg.gh, cfg.gw, cfg.A, cfg.C = version, N, gh, gw, A, C
+    if anchors is not None:
+        flat = [float(v) for pair in anchors for v in pair]
+        if len(flat) != 2 * A or len(flat) > 32:
+            raise ValueError(f"need {A} (w,h) anchors, at most 16; got {len(flat) // 2}")
+        for i, v in enumerate(flat):
+            cfg.anchors[i] = v
+        cfg.use_anchors = 1
+    else:
+        cfg.use_anchors = 0
+    cfg.binary_weight = float(binary_weight)
+    lw = list(loss_weight) + [0.0] * (4 - len(loss_weight))
+    for i in range(4):
+        cfg.loss_weight[i] = float(lw[i])
+    cfg.ignore_thresh = float(ignore_thresh)
+    cfg.use_focal_loss = int(bool(use_focal_loss))
+    cfg.focal_gamma = float(focal_gamma)
+    cfg.use_scale = int(bool(use_scale))
+    cfg.wh_reg_weight = float(wh_reg_weight)
+    cfg.truth_thresh = float(truth_thresh)
+    cfg.label_smooth = float(label_smooth)
+    return cfg
+
+
+def loss_fwd_bwd(cfg, y_true, y_pred, loss_out=None, dpred=None, grad_scale=1.0, want_grad=True):
+    _chk_f32(y_true, y_pred, dpred)
+    cells = cfg.N * cfg.gh * cfg.gw
+    pd = (5 * cfg.A + cfg.C) if cfg.version == 1 else cfg.A * (5 + cfg.C)
+    if y_true.numel() != cells * (5 + cfg.C) or y_pred.numel() != cells * pd:
+        raise YoloHipError(f"loss: tensor sizes do not match cfg (cells={cells}, C={cfg.C}, A={cfg.A})")
+    if loss_out is None:
+        loss_out = torch.empty(8, device=y_pred.device, dtype=torch.float64)
+    if want_grad and dpred is None:
+        dpred = torch.empty_like(y_pred)
+    check(_lib.load().yolo_loss_fwd_bwd(byref(cfg), _p(y_true), _p(y_pred), _p(loss_out),
+                                        _p(dpred if want_grad else None), float(grad_scale), c_void_p(0), 0,
+                                        _stream()), "yolo_loss_fwd_bwd")
+    return loss_out, dpred
+
+
+def metrics(cfg, y_true, y_pred, recall_thresh=0.5, out=None):
+    _chk_f32(y_true, y_pred)
+    if out is None:
+        out = torch.empty(8, device=y_pred.device, dtype=torch.float64)
+    check(_lib.load().yolo_metrics(byref(cfg), _p(y_true), _p(y_pred), float(recall_thresh), _p(out), _stream()),
+          "yolo_metrics")
+    return out
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, zero_grad=True):
+    check(_lib.load().yolo_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step),
+                                     float(grad_scale), int(bool(zero_grad)), _stream()), "yolo_adam_step")
+
+
+def sgd_step(p, g, lr, grad_scale=1.0, zero_grad=True):
+    check(_lib.load().yolo_sgd_step(_p(p), _p(g), p.numel(), lr, float(grad_scale), int(bool(zero_grad)), _stream()),
+          "yolo_sgd_step")
+
+
+def decode_level(pred, A, C, version, threshold, rows, max_rows, count, workspace):
+    gh, gw = pred.shape[0], pred.shape[1]
+    lib = _lib.load()
+    if pred.dtype == torch.float32:
+        check(lib.yolo_decode_level(_p(pred), gh, gw, A, C, version, float(threshold), _p(rows), max_rows,
+                                    _p(count), _p(workspace), workspace.numel() * workspace.element_size(),
+                                    _stream()), "yolo_decode_level")
+    elif pred.dtype == torch.float64:
+        check(lib.yolo_decode_level_f64(_p(pred), gh, gw, A, C, version, float(threshold), _p(rows), max_rows,
+                                        _p(count), _p(workspace), workspace.numel() * workspace.element_size(),
+                                        _stream()), "yolo_decode_level_f64")
+    else:
+        raise YoloHipError(f"decode: unsupported dtype {pred.dtype}")
+
+
+def decode_workspace_bytes(gh, gw, A, C):
+    return int(_lib.load().yolo_decode_workspace_bytes(gh, gw, A, C))
+
+
+def nms_keep(rows, class_num, mode, nms_threshold, conf_threshold=0.5, sigma=0.5):
+    """rows: float64 CUDA tensor [n,7]; returns uint8 keep mask [n]."""
+    n = rows.shape[0]
+    keep = torch.empty(n, device=rows.device, dtype=torch.uint8)
+    if n == 0:
+        return keep
+    lib = _lib.load()
+    nbytes = int(lib.yolo_nms_workspace_bytes(n, class_num))
+    ws = torch.empty(nbytes, device=rows.device, dtype=torch.uint8)
+    check(lib.yolo_nms(_p(rows), n, class_num, mode, float(nms_threshold), float(conf_threshold), float(sigma),
+                       _p(keep), _p(ws), nbytes, _stream()), "yolo_nms")
+    return keep
