@@ -1,0 +1,574 @@
+"""Static-graph executor for the YOLO training / inference hot path.
+
+The reference builds tf.keras graphs (yolov3/models/*.py etc.) and lets Keras run
+forward / autodiff / optimizer. Here a model is a flat list of units built once by
+`GraphBuilder`; `Network.forward` / `Network.backward` walk it and enqueue the HIP kernels of
+libyolo_hip.so on the current stream. Design points (MI355X-first):
+
+  * NHWC fp32 activations, KRSC filters; all trainable parameters live in ONE flat buffer
+    (`params`), with matching flat `grads`, Adam `m`/`v`: one optimizer launch per step and
+    contiguous gradient buckets for the RCCL all-reduce (reverse construction order ==
+    backward completion order).
+  * every conv output and activation of a training step stays resident (288 GB HBM: no
+    recompute, no offload); buffers are allocated once per batch size and reused.
+  * conv+BN+activation(+residual Add) is one unit: conv kernel (BN statistics accumulated in
+    fp64), a per-channel finalize, one fused normalise+activate(+add) pass.
+  * gradient fan-out (residual skips, FPN taps) is resolved with "first writer aliases,
+    later writers accumulate in place", so identity branches cost no copies.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import ACT_LEAKY, ACT_LINEAR, ACT_MISH, YoloHipError
+
+ACT_NAMES = {ACT_LINEAR: "linear", ACT_LEAKY: "leaky", ACT_MISH: "mish"}
+
+
+# --------------------------------------------------------------------------------------------
+# parameter store
+# --------------------------------------------------------------------------------------------
+class ParamSpec:
+    __slots__ = ("name", "shape", "offset", "size", "init", "trainable")
+
+    def __init__(self, name, shape, offset, init, trainable):
+        self.name, self.shape, self.offset = name, tuple(shape), offset
+        self.size = int(np.prod(shape))
+        self.init, self.trainable = init, trainable
+
+
+class ParamStore:
+    """Flat fp32 storage. Offsets are padded to 64 floats so every slice is 256-B aligned."""
+
+    def __init__(self):
+        self.specs = {}
+        self.order = []
+        self.total = 0
+
+    def add(self, name, shape, init):
+        if name in self.specs:
+            raise ValueError(f"duplicate parameter {name}")
+        spec = ParamSpec(name, shape, self.total, init, True)
+        self.specs[name] = spec
+        self.order.append(name)
+        self.total += (spec.size + 63) // 64 * 64
+        return spec
+
+    def materialize(self, device, rng):
+        host = np.zeros(self.total, dtype=np.float32)
+        for name in self.order:
+            s = self.specs[name]
+            host[s.offset:s.offset + s.size] = s.init(rng, s.shape).reshape(-1)
+        self.data = torch.from_numpy(host).to(device)
+        return self.data
+
+    def view(self, name):
+        s = self.specs[name]
+        return self.data[s.offset:s.offset + s.size]
+
+
+def init_zeros(rng, shape):
+    return np.zeros(shape, dtype=np.float32)
+
+
+def init_ones(rng, shape):
+    return np.ones(shape, dtype=np.float32)
+
+
+def he_normal_krsc(rng, shape):
+    """Keras he_normal: truncated normal (|z| <= 2), stddev = sqrt(2/fan_in)/0.87962566
+    (SURVEY.md Appendix B); shape is KRSC so fan_in = kh*kw*Cin."""
+    cout, kh, kw, cin = shape
+    std = math.sqrt(2.0 / (kh * kw * cin)) / 0.87962566103423978
+    z = rng.standard_normal(shape)
+    bad = np.abs(z) > 2.0
+    while bad.any():
+        z[bad] = rng.standard_normal(int(bad.sum()))
+        bad = np.abs(z) > 2.0
+    return (z * std).astype(np.float32)
+
+
+def random_normal_002(rng, shape):
+    """yolov4/models/backbone.py:68: RandomNormal(mean=0.0, stddev=0.02)."""
+    return (rng.standard_normal(shape) * 0.02).astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# graph description
+# --------------------------------------------------------------------------------------------
+class TensorRef:
+    """Symbolic activation: spatial shape without the batch dimension."""
+    __slots__ = ("tid", "h", "w", "c", "name", "producer")
+
+    def __init__(self, tid, h, w, c, name, producer=None):
+        self.tid, self.h, self.w, self.c, self.name, self.producer = tid, h, w, c, name, producer
+
+    @property
+    def shape(self):
+        return (None, self.h, self.w, self.c)
+
+
+class Unit:
+    kind = "unit"
+
+    def __init__(self, name):
+        self.name = name
+        self.inputs = []
+        self.out = None
+
+    def param_names(self):
+        return []
+
+
+class ConvUnit(Unit):
+    """conv [+bias] [+BatchNorm] [+activation] [+residual add]."""
+    kind = "conv"
+
+    def __init__(self, name, src, cout, k, stride, padding, bn, act, bias, residual, kernel_init):
+        super().__init__(name)
+        self.src, self.cout, self.k, self.stride, self.padding = src, cout, k, stride, padding
+        self.bn, self.act, self.bias, self.residual = bn, act, bias, residual
+        self.kernel_init = kernel_init
+        self.inputs = [src] + ([residual] if residual is not None else [])
+
+
+class HeadUnit(Unit):
+    """All per-anchor 1x1 head convs of one output level fused into one [A*(5+C)] x Cin GEMM
+    plus the per-channel activations (yolov3/models/__init__.py:40-65)."""
+    kind = "head"
+
+    def __init__(self, name, src, A, C, version, anchors, level, kernel_init):
+        super().__init__(name)
+        self.src, self.A, self.C, self.version, self.level = src, A, C, version, level
+        self.kernel_init = kernel_init
+        self.anchors = [tuple(map(float, a)) for a in anchors] if anchors is not None else None
+        self.inputs = [src]
+
+
+class UpsampleUnit(Unit):
+    kind = "upsample"
+
+    def __init__(self, name, src):
+        super().__init__(name)
+        self.src = src
+        self.inputs = [src]
+
+
+class ConcatUnit(Unit):
+    kind = "concat"
+
+    def __init__(self, name, srcs):
+        super().__init__(name)
+        self.srcs = list(srcs)
+        self.inputs = list(srcs)
+
+
+class MaxPoolUnit(Unit):
+    kind = "maxpool"
+
+    def __init__(self, name, src, k, stride, padding):
+        super().__init__(name)
+        self.src, self.k, self.stride, self.padding = src, k, stride, padding
+        self.inputs = [src]
+
+
+class SpaceToDepthUnit(Unit):
+    kind = "space_to_depth"
+
+    def __init__(self, name, src):
+        super().__init__(name)
+        self.src = src
+        self.inputs = [src]
+
+
+class GraphBuilder:
+    """Functional-style builder, one call per reference layer group."""
+
+    def __init__(self, input_shape, kernel_init=he_normal_krsc):
+        h, w, c = input_shape
+        self.tensors = []
+        self.units = []
+        self.kernel_init = kernel_init
+        self.input = self._tensor(h, w, c, "input")
+        self.outputs = []
+
+    def _tensor(self, h, w, c, name, producer=None):
+        t = TensorRef(len(self.tensors), h, w, c, name, producer)
+        self.tensors.append(t)
+        return t
+
+    def _push(self, unit, h, w, c):
+        unit.out = self._tensor(h, w, c, unit.name, unit)
+        self.units.append(unit)
+        return unit.out
+
+    def conv(self, src, cout, k, name, stride=1, padding=None, bn=True, act=ACT_LEAKY, bias=False, residual=None,
+             kernel_init=None):
+        if padding is None:
+            padding = "same"
+        d = ops.conv_desc((1, src.h, src.w, src.c), cout, k, k, stride, padding)
+        if residual is not None and (residual.h, residual.w, residual.c) != (d.Ho, d.Wo, cout):
+            raise ValueError(f"{name}: residual shape mismatch")
+        u = ConvUnit(name, src, cout, k, stride, padding, bn, act, bias, residual, kernel_init or self.kernel_init)
+        return self._push(u, d.Ho, d.Wo, cout)
+
+    def upsample(self, src, name):
+        return self._push(UpsampleUnit(name, src), src.h * 2, src.w * 2, src.c)
+
+    def concat(self, srcs, name):
+        h, w = srcs[0].h, srcs[0].w
+        for s in srcs:
+            if (s.h, s.w) != (h, w):
+                raise ValueError(f"{name}: concat of different spatial sizes")
+        return self._push(ConcatUnit(name, srcs), h, w, sum(s.c for s in srcs))
+
+    def maxpool(self, src, k, name, stride=None, padding="valid"):
+        stride = stride or k
+        if padding == "same":
+            ho, wo = -(-src.h // stride), -(-src.w // stride)
+        else:
+            ho, wo = (src.h - k) // stride + 1, (src.w - k) // stride + 1
+        return self._push(MaxPoolUnit(name, src, k, stride, padding), ho, wo, src.c)
+
+    def space_to_depth(self, src, name):
+        return self._push(SpaceToDepthUnit(name, src), src.h // 2, src.w // 2, src.c * 4)
+
+    def head(self, src, A, C, version, anchors, name, level):
+        cout = (5 * A + C) if version == 1 else A * (5 + C)
+        out = self._push(HeadUnit(name, src, A, C, version, anchors, level, self.kernel_init), src.h, src.w, cout)
+        self.outputs.append(out)
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# runtime
+# --------------------------------------------------------------------------------------------
+class Network:
+    def __init__(self, builder, device="cuda", seed=1234, unbiased_moving_var=False):
+        if not torch.cuda.is_available():
+            raise YoloHipError("tf2_yolo_amd needs a HIP device: there is no CPU fallback")
+        self.device = torch.device(device)
+        self.tensors = builder.tensors
+        self.units = builder.units
+        self.input = builder.input
+        self.outputs = list(builder.outputs)
+        self.unbiased_moving_var = unbiased_moving_var
+        self.params = ParamStore()   # trainable
+        self.state = ParamStore()    # BN moving statistics (not trainable, not all-reduced)
+        self._declare_params()
+        rng = np.random.default_rng(seed)
+        self.params.materialize(self.device, rng)
+        self.state.materialize(self.device, rng)
+        self.grads = torch.zeros_like(self.params.data)
+        self._wT = torch.empty(self._wT_total, device=self.device, dtype=torch.float32)
+        self._wT_valid = False
+        self._bn_f32 = torch.zeros(max(self._bn_f32_total, 1), device=self.device, dtype=torch.float32)
+        self._bn_f64 = torch.zeros(max(self._bn_f64_total, 1), device=self.device, dtype=torch.float64)
+        self._anchors_dev = {}
+        for u in self.units:
+            if u.kind == "head" and u.anchors is not None:
+                self._anchors_dev[u.name] = torch.tensor(np.array(u.anchors, dtype=np.float32).reshape(-1),
+                                                         device=self.device)
+        self.batch = None
+        self.act = {}
+        self.training = False
+        self.grad_ready_hook = None   # called as hook(unit) after a unit's parameter grads are enqueued
+        self._infer_scale_valid = False
+        # consumers per tensor decide whether a tensor needs a gradient at all
+        self._needs_grad = self._compute_needs_grad()
+
+    # ---- construction -------------------------------------------------------------------
+    def _declare_params(self):
+        wT = 0
+        f32 = 0
+        f64 = 0
+        for u in self.units:
+            if u.kind == "conv":
+                cin = u.src.c
+                u.p_kernel = self.params.add(f"{u.name}_conv/kernel", (u.cout, u.k, u.k, cin), u.kernel_init)
+                u.p_bias = self.params.add(f"{u.name}_conv/bias", (u.cout,), init_zeros) if u.bias else None
+                if u.bn:
+                    u.p_gamma = self.params.add(f"{u.name}_bn/gamma", (u.cout,), init_ones)
+                    u.p_beta = self.params.add(f"{u.name}_bn/beta", (u.cout,), init_zeros)
+                    u.s_mean = self.state.add(f"{u.name}_bn/moving_mean", (u.cout,), init_zeros)
+                    u.s_var = self.state.add(f"{u.name}_bn/moving_variance", (u.cout,), init_ones)
+                    u.bn_f32_off = f32
+                    f32 += 4 * u.cout            # scale, shift, save_mean, save_invstd
+                    u.bn_f64_off = f64
+                    f64 += 4 * u.cout            # stats[2C], red[2C]
+                u.wT_off = wT
+                wT += u.cout * u.k * u.k * cin
+            elif u.kind == "head":
+                cin = u.src.c
+                cout = u.out.c
+                u.p_kernel = self.params.add(f"{u.name}/kernel", (cout, 1, 1, cin), u.kernel_init)
+                u.p_bias = self.params.add(f"{u.name}/bias", (cout,), init_zeros)
+                u.wT_off = wT
+                wT += cout * cin
+        self._wT_total = wT
+        self._bn_f32_total = f32
+        self._bn_f64_total = f64
+
+    def _compute_needs_grad(self):
+        needs = {self.input.tid: False}
+        for u in self.units:
+            has_params = u.kind in ("conv", "head")
+            needs[u.out.tid] = has_params or any(needs[t.tid] for t in u.inputs)
+        return needs
+
+    @property
+    def num_params(self):
+        return sum(self.params.specs[n].size for n in self.params.order)
+
+    @property
+    def num_state(self):
+        return sum(self.state.specs[n].size for n in self.state.order)
+
+    # ---- buffers ------------------------------------------------------------------------
+    def allocate(self, N):
+        if self.batch == N:
+            return
+        self.batch = N
+        self.act = {}
+        dev = self.device
+        for u in self.units:
+            oh, ow, oc = u.out.h, u.out.w, u.out.c
+            if u.kind == "conv":
+                u.desc = ops.conv_desc((N, u.src.h, u.src.w, u.src.c), u.cout, u.k, u.k, u.stride, u.padding)
+                u.y = torch.empty((N, oh, ow, oc), device=dev, dtype=torch.float32)
+                needs_a = u.bn or u.act != ACT_LINEAR
+                u.a = torch.empty((N, oh, ow, oc), device=dev, dtype=torch.float32) if needs_a else u.y
+                self.act[u.out.tid] = u.a
+            elif u.kind == "head":
+                u.desc = ops.conv_desc((N, u.src.h, u.src.w, u.src.c), oc, 1, 1, 1, "same")
+                u.t = torch.empty((N, oh, ow, oc), device=dev, dtype=torch.float32)
+                u.yact = torch.empty((N, oh, ow, oc), device=dev, dtype=torch.float32)
+                self.act[u.out.tid] = u.yact
+            elif u.kind == "maxpool":
+                u.buf = torch.empty((N, oh, ow, oc), device=dev, dtype=torch.float32)
+                u.argmax = torch.empty((N, oh, ow, oc), device=dev, dtype=torch.int32)
+                if u.padding == "same":
+                    _, u.pad_t = ops.same_pad(u.src.h, u.k, u.stride)
+                    _, u.pad_l = ops.same_pad(u.src.w, u.k, u.stride)
+                else:
+                    u.pad_t = u.pad_l = 0
+                self.act[u.out.tid] = u.buf
+            else:
+                u.buf = torch.empty((N, oh, ow, oc), device=dev, dtype=torch.float32)
+                self.act[u.out.tid] = u.buf
+
+    def _bn_bufs(self, u):
+        c = u.cout
+        b = self._bn_f32[u.bn_f32_off:u.bn_f32_off + 4 * c]
+        d = self._bn_f64[u.bn_f64_off:u.bn_f64_off + 4 * c]
+        return b[0:c], b[c:2 * c], b[2 * c:3 * c], b[3 * c:4 * c], d[0:2 * c], d[2 * c:4 * c]
+
+    def mark_params_changed(self):
+        self._wT_valid = False
+        self._infer_scale_valid = False
+
+    # ---- forward ------------------------------------------------------------------------
+    def forward(self, x, training=False):
+        """x: float32 CUDA tensor [N,H,W,C]. Returns the list of head outputs (coarse -> fine)."""
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise YoloHipError("forward expects a float32 CUDA tensor")
+        x = x.contiguous()
+        N = x.shape[0]
+        if tuple(x.shape[1:]) != (self.input.h, self.input.w, self.input.c):
+            raise YoloHipError(f"input shape {tuple(x.shape[1:])} != model input "
+                               f"{(self.input.h, self.input.w, self.input.c)}")
+        self.allocate(N)
+        self.training = training
+        self.act[self.input.tid] = x
+        if training:
+            self._bn_f64.zero_()
+            self._infer_scale_valid = False  # moving statistics (and the shared scale/shift) change
+        P = self.params
+        for u in self.units:
+            if u.kind == "conv":
+                xin = self.act[u.src.tid]
+                w = P.view(u.p_kernel.name)
+                bias = P.view(u.p_bias.name) if u.p_bias is not None else None
+                if u.bn:
+                    scale, shift, smean, sinv, stats, _ = self._bn_bufs(u)
+                    gamma, beta = P.view(u.p_gamma.name), P.view(u.p_beta.name)
+                    if training:
+                        ops.conv2d_fwd(u.desc, xin, w, bias, out=u.y, stats=stats)
+                        ops.bn_finalize(stats, u.y.numel() // u.cout, u.cout, gamma, beta,
+                                        self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
+                                        scale, shift, smean, sinv, unbiased=self.unbiased_moving_var)
+                    else:
+                        ops.conv2d_fwd(u.desc, xin, w, bias, out=u.y)
+                        if not self._infer_scale_valid:
+                            ops.bn_fold_inference(u.cout, gamma, beta, self.state.view(u.s_mean.name),
+                                                  self.state.view(u.s_var.name), scale, shift)
+                    res = self.act[u.residual.tid] if u.residual is not None else None
+                    ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a)
+                else:
+                    ops.conv2d_fwd(u.desc, xin, w, bias, out=u.y)
+                    if u.act != ACT_LINEAR:
+                        ops.act_fwd(u.y, u.act, out=u.a)
+                    if u.residual is not None:
+                        raise YoloHipError("residual without BN is not used by any reference graph")
+            elif u.kind == "head":
+                xin = self.act[u.src.tid]
+                ops.conv2d_fwd(u.desc, xin, P.view(u.p_kernel.name), P.view(u.p_bias.name), out=u.t)
+                ops.head_act_fwd(u.t, u.A, u.C, u.version, self._anchors_dev.get(u.name), out=u.yact)
+            elif u.kind == "upsample":
+                ops.upsample2x_fwd(self.act[u.src.tid], u.buf, u.out.c, 0)
+            elif u.kind == "concat":
+                off = 0
+                for s in u.srcs:
+                    ops.copy_channels_in(self.act[s.tid], s.c, u.buf, u.out.c, off)
+                    off += s.c
+            elif u.kind == "maxpool":
+                ops.maxpool_fwd(self.act[u.src.tid], u.k, u.stride, u.pad_t, u.pad_l, u.out.h, u.out.w, u.buf,
+                                u.out.c, 0, u.argmax if training else None)
+            elif u.kind == "space_to_depth":
+                ops.space_to_depth2_fwd(self.act[u.src.tid], u.buf, u.out.c, 0)
+            else:
+                raise YoloHipError(f"unknown unit kind {u.kind}")
+        if not training:
+            self._infer_scale_valid = True
+        return [self.act[t.tid] for t in self.outputs]
+
+    # ---- backward -----------------------------------------------------------------------
+    def _add_grad(self, grads, t, buf):
+        """Contribute `buf` (same shape as tensor t) to dL/dt: alias if first, else add in place."""
+        if not self._needs_grad[t.tid]:
+            return
+        cur = grads.get(t.tid)
+        if cur is None:
+            grads[t.tid] = buf
+        else:
+            ops.axpy(cur, buf)
+
+    def _refresh_wT(self):
+        if self._wT_valid:
+            return
+        for u in self.units:
+            if u.kind == "conv":
+                n = u.cout * u.k * u.k * u.src.c
+                ops.filter_transpose(self.params.view(u.p_kernel.name), u.cout, u.k * u.k, u.src.c,
+                                     out=self._wT[u.wT_off:u.wT_off + n])
+            elif u.kind == "head":
+                n = u.out.c * u.src.c
+                ops.filter_transpose(self.params.view(u.p_kernel.name), u.out.c, 1, u.src.c,
+                                     out=self._wT[u.wT_off:u.wT_off + n])
+        self._wT_valid = True
+
+    def _gview(self, spec):
+        return self.grads[spec.offset:spec.offset + spec.size]
+
+    def backward(self, douts):
+        """douts: list of dL/d(output) tensors (one per head, same order as forward's result).
+        Parameter gradients are ACCUMULATED into self.grads (zeroed by the optimizer step)."""
+        if not self.training:
+            raise YoloHipError("backward() requires a preceding forward(training=True)")
+        self._refresh_wT()
+        grads = {}
+        for t, g in zip(self.outputs, douts):
+            grads[t.tid] = g
+        N = self.batch
+        for u in reversed(self.units):
+            dout = grads.pop(u.out.tid, None)
+            if dout is None:
+                continue  # output unused by the loss
+            if u.kind == "conv":
+                xin = self.act[u.src.tid]
+                if u.bn:
+                    scale, shift, smean, sinv, _, red = self._bn_bufs(u)
+                    if u.residual is not None:
+                        self._add_grad(grads, u.residual, dout)
+                    dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
+                                        sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta))
+                else:
+                    dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
+                ops.conv2d_wgrad(u.desc, xin, dy, self._gview(u.p_kernel),
+                                 self._gview(u.p_bias) if u.p_bias is not None else None)
+                self._dgrad(grads, u, dy, u.cout * u.k * u.k * u.src.c)
+            elif u.kind == "head":
+                xin = self.act[u.src.tid]
+                dt = ops.head_act_bwd(u.yact, dout, u.A, u.C, u.version, self._anchors_dev.get(u.name))
+                ops.conv2d_wgrad(u.desc, xin, dt, self._gview(u.p_kernel), self._gview(u.p_bias))
+                self._dgrad(grads, u, dt, u.out.c * u.src.c)
+            elif u.kind == "upsample":
+                if self._needs_grad[u.src.tid]:
+                    cur = grads.get(u.src.tid)
+                    if cur is None:
+                        cur = torch.empty((N, u.src.h, u.src.w, u.src.c), device=self.device, dtype=torch.float32)
+                        ops.upsample2x_bwd(dout, u.out.c, 0, cur, accumulate=False)
+                        grads[u.src.tid] = cur
+                    else:
+                        ops.upsample2x_bwd(dout, u.out.c, 0, cur, accumulate=True)
+            elif u.kind == "concat":
+                off = 0
+                for s in u.srcs:
+                    if self._needs_grad[s.tid]:
+                        cur = grads.get(s.tid)
+                        if cur is None:
+                            cur = torch.empty((N, s.h, s.w, s.c), device=self.device, dtype=torch.float32)
+                            ops.copy_channels_out(dout, u.out.c, off, cur, s.c, accumulate=False)
+                            grads[s.tid] = cur
+                        else:
+                            ops.copy_channels_out(dout, u.out.c, off, cur, s.c, accumulate=True)
+                    off += s.c
+            elif u.kind == "maxpool":
+                if self._needs_grad[u.src.tid]:
+                    cur = grads.get(u.src.tid)
+                    if cur is None:
+                        cur = torch.zeros((N, u.src.h, u.src.w, u.src.c), device=self.device, dtype=torch.float32)
+                        grads[u.src.tid] = cur
+                    ops.maxpool_bwd(dout, N, u.out.h, u.out.w, u.out.c, u.out.c, 0, u.argmax, cur)
+            elif u.kind == "space_to_depth":
+                if self._needs_grad[u.src.tid]:
+                    cur = grads.get(u.src.tid)
+                    if cur is None:
+                        cur = torch.empty((N, u.src.h, u.src.w, u.src.c), device=self.device, dtype=torch.float32)
+                        ops.space_to_depth2_bwd(dout, u.out.c, 0, cur, accumulate=False)
+                        grads[u.src.tid] = cur
+                    else:
+                        ops.space_to_depth2_bwd(dout, u.out.c, 0, cur, accumulate=True)
+            if self.grad_ready_hook is not None and u.kind in ("conv", "head"):
+                self.grad_ready_hook(u)
+
+    def _dgrad(self, grads, u, dy, wsize):
+        if not self._needs_grad[u.src.tid]:
+            return
+        wT = self._wT[u.wT_off:u.wT_off + wsize]
+        cur = grads.get(u.src.tid)
+        if cur is None:
+            grads[u.src.tid] = ops.conv2d_dgrad(u.desc, dy, wT)
+        else:
+            ops.conv2d_dgrad(u.desc, dy, wT, dx=cur, accumulate=True)
+
+    # ---- weights ------------------------------------------------------------------------
+    def named_weights(self):
+        """name -> numpy array in KERAS layout (kernel HWIO), for .npz interchange."""
+        out = {}
+        for store in (self.params, self.state):
+            for name in store.order:
+                s = store.specs[name]
+                a = store.view(name).detach().cpu().numpy().reshape(s.shape)
+                if name.endswith("/kernel"):
+                    a = np.transpose(a, (1, 2, 3, 0))  # KRSC -> HWIO
+                out[name] = a.copy()
+        return out
+
+    def load_named_weights(self, weights, strict=True):
+        for store in (self.params, self.state):
+            for name in store.order:
+                if name not in weights:
+                    if strict:
+                        raise KeyError(f"missing weight {name}")
+                    continue
+                s = store.specs[name]
+                a = np.asarray(weights[name], dtype=np.float32)
+                if name.endswith("/kernel"):
+                    a = np.transpose(a, (3, 0, 1, 2))  # HWIO -> KRSC
+                if tuple(a.shape) != s.shape:
+                    raise ValueError(f"{name}: shape {a.shape} != {s.shape}")
+                store.view(name).copy_(torch.from_numpy(np.ascontiguousarray(a)).reshape(-1))
+        self.mark_params_changed()
