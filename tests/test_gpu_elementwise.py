@@ -1,0 +1,186 @@
+"""GPU parity of BN(+act, +residual), glue ops, head activations and Adam against the torch-CPU
+float64 oracle (oracle/layers.py). fp32 tolerance 1e-4 relative to the tensor scale."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import layers as L
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _rel(a, b):
+    return (a.double().cpu() - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("C,act,use_res", [(32, 1, False), (64, 1, True), (96, 2, False), (128, 2, True),
+                                           (1024, 1, False), (2048, 1, False)])
+def test_bn_act_train_fwd_bwd(C, act, use_res):
+    from tf2_yolo_amd import ops
+    g = torch.Generator().manual_seed(C + act)
+    N, H, W = 3, 7, 5
+    x = (torch.randn(N, H, W, C, generator=g, dtype=torch.float64) * 2 + 0.7).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = torch.randn(C, generator=g, dtype=torch.float64).requires_grad_(True)
+    res = torch.randn(N, H, W, C, generator=g, dtype=torch.float64) if use_res else None
+    z, mean, var = L.batchnorm_train(x, gamma, beta)
+    a = L.leaky(z) if act == 1 else L.mish(z)
+    out = a + res if use_res else a
+    dout = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    out.backward(dout)
+
+    dev = "cuda"
+    xd = x.detach().float().to(dev)
+    P = N * H * W
+    stats = torch.zeros(2 * C, device=dev, dtype=torch.float64)
+    red = torch.zeros(2 * C, device=dev, dtype=torch.float64)
+    f = lambda: torch.empty(C, device=dev)
+    scale, shift, smean, sinv = f(), f(), f(), f()
+    mm = torch.zeros(C, device=dev)
+    mv = torch.ones(C, device=dev)
+    gd, bd = gamma.detach().float().to(dev), beta.detach().float().to(dev)
+    ops.bn_stats(xd, C, stats)
+    ops.bn_finalize(stats, P, C, gd, bd, mm, mv, scale, shift, smean, sinv)
+    o = ops.bn_act_fwd(xd, C, scale, shift, act, None if res is None else res.float().to(dev))
+    assert _rel(o, out.detach()) < TOL
+    assert _rel(smean, mean.detach()) < TOL
+    assert _rel(mm, 0.01 * mean.detach()) < TOL
+    assert _rel(mv, 0.99 + 0.01 * var.detach()) < TOL
+    dg = torch.zeros(C, device=dev)
+    db = torch.zeros(C, device=dev)
+    dx = ops.bn_act_bwd(xd, dout.float().to(dev), C, gd, scale, shift, smean, sinv, act, red, dg, db)
+    assert _rel(dx, x.grad) < TOL
+    assert _rel(dg, gamma.grad) < TOL
+    assert _rel(db, beta.grad) < TOL
+    # unbiased moving-variance switch
+    mm2, mv2 = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    stats.zero_()
+    ops.bn_stats(xd, C, stats)
+    ops.bn_finalize(stats, P, C, gd, bd, mm2, mv2, scale, shift, smean, sinv, unbiased=True)
+    assert _rel(mv2, 0.99 + 0.01 * var.detach() * P / (P - 1)) < TOL
+
+
+def test_bn_inference_fold():
+    from tf2_yolo_amd import ops
+    C = 64
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 5, 5, C, generator=g, dtype=torch.float64)
+    gamma, beta = torch.rand(C, generator=g, dtype=torch.float64) + .5, torch.randn(C, generator=g, dtype=torch.float64)
+    mm, mv = torch.randn(C, generator=g, dtype=torch.float64), torch.rand(C, generator=g, dtype=torch.float64) + .1
+    ref = L.leaky(L.batchnorm_infer(x, gamma, beta, mm, mv))
+    scale, shift = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_fold_inference(C, gamma.float().cuda(), beta.float().cuda(), mm.float().cuda(), mv.float().cuda(), scale, shift)
+    o = ops.bn_act_fwd(x.float().cuda(), C, scale, shift, 1)
+    assert _rel(o, ref) < TOL
+
+
+def test_upsample_concat_s2d_maxpool():
+    from tf2_yolo_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 6, 4, 8, generator=g, dtype=torch.float64).requires_grad_(True)
+    y = torch.randn(2, 12, 8, 12, generator=g, dtype=torch.float64).requires_grad_(True)
+    up = L.upsample2x(x)
+    cat = torch.cat([up, y], dim=-1)
+    dcat = torch.randn(cat.shape, generator=g, dtype=torch.float64)
+    cat.backward(dcat)
+    xd, yd = x.detach().float().cuda(), y.detach().float().cuda()
+    upd = torch.empty(2, 12, 8, 8, device="cuda")
+    ops.upsample2x_fwd(xd, upd, 8, 0)
+    catd = torch.empty(2, 12, 8, 20, device="cuda")
+    ops.copy_channels_in(upd, 8, catd, 20, 0)
+    ops.copy_channels_in(yd, 12, catd, 20, 8)
+    assert torch.equal(catd.double().cpu(), cat.detach().float().double())
+    dcd = dcat.float().cuda()
+    dup = torch.empty(2, 12, 8, 8, device="cuda")
+    ops.copy_channels_out(dcd, 20, 0, dup, 8)
+    dy = torch.empty(2, 12, 8, 12, device="cuda")
+    ops.copy_channels_out(dcd, 20, 8, dy, 12)
+    dx = torch.empty(2, 6, 4, 8, device="cuda")
+    ops.upsample2x_bwd(dup, 8, 0, dx)
+    assert _rel(dx, x.grad) < 1e-6 and _rel(dy, y.grad) < 1e-6
+    ops.upsample2x_bwd(dup, 8, 0, dx, accumulate=True)
+    assert _rel(dx, 2 * x.grad) < 1e-6
+    # space_to_depth
+    s = torch.randn(2, 6, 4, 5, generator=g, dtype=torch.float64).requires_grad_(True)
+    sd = L.space_to_depth2(s)
+    ds = torch.randn(sd.shape, generator=g, dtype=torch.float64)
+    sd.backward(ds)
+    o = torch.empty(2, 3, 2, 20, device="cuda")
+    ops.space_to_depth2_fwd(s.detach().float().cuda(), o, 20, 0)
+    assert torch.equal(o.double().cpu(), sd.detach().float().double())
+    dsx = torch.empty(2, 6, 4, 5, device="cuda")
+    ops.space_to_depth2_bwd(ds.float().cuda(), 20, 0, dsx)
+    assert _rel(dsx, s.grad) < 1e-6
+    # max-pool: 2x2 s2 valid (odd size floors), SPP 5/9/13 s1 same, 2x2 s1 same
+    for (k, st, pad, hh, ww) in [(2, 2, "valid", 7, 6), (5, 1, "same", 7, 6), (13, 1, "same", 7, 6),
+                                 (2, 1, "same", 5, 5), (2, 2, "same", 7, 7)]:
+        m = torch.randn(2, hh, ww, 6, generator=g, dtype=torch.float64).requires_grad_(True)
+        ref = L.maxpool(m, k, st, pad)
+        dref = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+        ref.backward(dref)
+        Ho, Wo = ref.shape[1], ref.shape[2]
+        pt = L.same_pad(hh, k, st)[1] if pad == "same" else 0
+        pl = L.same_pad(ww, k, st)[1] if pad == "same" else 0
+        md = m.detach().float().cuda()
+        out = torch.empty(2, Ho, Wo, 6, device="cuda")
+        arg = torch.empty(2, Ho, Wo, 6, device="cuda", dtype=torch.int32)
+        ops.maxpool_fwd(md, k, st, pt, pl, Ho, Wo, out, 6, 0, arg)
+        assert torch.equal(out.double().cpu(), ref.detach().float().double())
+        dm = torch.zeros(2, hh, ww, 6, device="cuda")
+        ops.maxpool_bwd(dref.float().cuda(), 2, Ho, Wo, 6, 6, 0, arg, dm)
+        assert _rel(dm, m.grad) < 1e-5
+
+
+@pytest.mark.parametrize("version,A,C", [(3, 3, 80), (4, 3, 7), (2, 5, 20), (1, 2, 1), (1, 2, 4)])
+def test_head_act(version, A, C):
+    from tf2_yolo_amd import ops
+    g = torch.Generator().manual_seed(version * 10 + C)
+    P = 2 * 5 * 5
+    D = 5 * A + C if version == 1 else A * (5 + C)
+    t = torch.randn(P, D, generator=g, dtype=torch.float64).requires_grad_(True)
+    anchors = torch.rand(A, 2, generator=g, dtype=torch.float64) + 0.1
+    if version == 1:
+        y = torch.cat([torch.sigmoid(t[:, :5 * A]), torch.softmax(t[:, 5 * A:], dim=-1)], dim=-1)
+    else:
+        tt = t.reshape(P, A, 5 + C)
+        cls = torch.softmax(tt[..., 5:], dim=-1) if version == 2 else torch.sigmoid(tt[..., 5:])
+        y = torch.cat([torch.sigmoid(tt[..., 0:2]), torch.exp(tt[..., 2:4]) * anchors, torch.sigmoid(tt[..., 4:5]),
+                       cls], dim=-1).reshape(P, D)
+    dy = torch.randn(P, D, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    anc = anchors.float().reshape(-1).cuda() if version != 1 else None
+    td = t.detach().float().cuda()
+    yd = ops.head_act_fwd(td, A, C, version, anc)
+    assert _rel(yd, y.detach()) < TOL
+    dt = ops.head_act_bwd(yd, dy.float().cuda(), A, C, version, anc)
+    assert _rel(dt, t.grad) < TOL
+    if version == 4:
+        da = torch.zeros(2 * A, device="cuda")
+        ops.head_act_bwd(yd, dy.float().cuda(), A, C, version, anc, danchors=da)
+        tt = t.detach().reshape(P, A, 5 + C)
+        ref = (dy.reshape(P, A, 5 + C)[..., 2:4] * torch.exp(tt[..., 2:4])).sum(0).reshape(-1)
+        assert _rel(da, ref) < TOL
+
+
+def test_adam_matches_keras_formula():
+    from tf2_yolo_amd import ops
+    n = 1000 * 4 + 3
+    rng = np.random.default_rng(0)
+    p, gsum = rng.standard_normal(n), None
+    pd = torch.tensor(p, dtype=torch.float32, device="cuda")
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    pm, mm, vv = p.astype(np.float64).copy(), np.zeros(n), np.zeros(n)
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-7
+    for step in range(1, 4):
+        g = rng.standard_normal(n)
+        gd = torch.tensor(g, dtype=torch.float32, device="cuda")
+        ops.adam_step(pd, gd, m, v, lr, step, grad_scale=0.5)
+        assert float(gd.abs().max()) == 0.0       # zero_grad
+        gg = g * 0.5
+        mm = b1 * mm + (1 - b1) * gg
+        vv = b2 * vv + (1 - b2) * gg * gg
+        lr_t = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        pm -= lr_t * mm / (np.sqrt(vv) + eps)
+    assert np.abs(pd.cpu().numpy() - pm).max() < 1e-5
