@@ -1,0 +1,210 @@
+"""Model graphs restated on torch CPU (float64 by default) from the reference definitions:
+
+  v3   yolov3/models/backbone.py:27-95, yolov3/models/darknet.py:71-104, yolov3/models/__init__.py:13-70
+  v4   yolov4/models/backbone.py:22-185, yolov4/models/darknet.py:72-146, yolov4/models/__init__.py:14-71
+  v2   yolov2/models/backbone.py:11-73, yolov2/models/darknet.py:32-106
+  v1.5 yolov1_5/models/backbone.py:9-48, yolov1_5/models/darknet.py:26-55
+
+Weights come in as {"<keras layer name>/<index>": ndarray} in Keras layouts (Conv kernel HWIO
+[, bias]; BN gamma, beta, moving_mean, moving_variance), i.e. what Model.save_weights writes.
+v1.5 / v2 layers are unnamed in the reference; the names used here are this repo's.
+Every function returns (outputs, new_moving) where new_moving maps bn layer name ->
+(moving_mean, moving_variance) after the Keras update when training=True.
+"""
+import torch
+
+from . import layers as L
+
+
+class _Ctx:
+    def __init__(self, weights, training, dtype, unbiased_moving_var=False):
+        self.w = {k: torch.as_tensor(v, dtype=dtype) if not torch.is_tensor(v) else v for k, v in weights.items()}
+        self.training = training
+        self.moving = {}
+        self.unbiased = unbiased_moving_var
+
+    def conv(self, x, name, stride=1, padding="same", bias=False):
+        b = self.w[f"{name}/1"] if bias else None
+        return L.conv2d(x, self.w[f"{name}/0"], b, stride=stride, padding=padding)
+
+    def bn(self, x, name):
+        gamma, beta = self.w[f"{name}/0"], self.w[f"{name}/1"]
+        mm, mv = self.w[f"{name}/2"], self.w[f"{name}/3"]
+        if self.training:
+            y, mean, var = L.batchnorm_train(x, gamma, beta)
+            n = x.numel() // x.shape[-1]
+            fed = var * n / (n - 1) if self.unbiased else var
+            self.moving[name] = (L.moving_update(mm, mean.detach()), L.moving_update(mv, fed.detach()))
+            return y
+        return L.batchnorm_infer(x, gamma, beta, mm, mv)
+
+    def cbl(self, x, name, stride=1, padding="same", act="leaky", bias=False):
+        """conv -> BatchNormalization -> LeakyReLU(0.1) | Mish"""
+        x = self.conv(x, f"{name}_conv", stride, padding, bias)
+        x = self.bn(x, f"{name}_bn")
+        return L.leaky(x) if act == "leaky" else L.mish(x)
+
+
+def _head_v234(c, x, i_out, anchors, version):
+    """per anchor: xy sigmoid, wh exp*anchor, conf sigmoid, class sigmoid (v2: softmax); Concatenate."""
+    outs = []
+    for j, box in enumerate(anchors):
+        p = f"out{i_out}_box{j + 1}"
+        xy = torch.sigmoid(c.conv(x, f"{p}_xy_conv", bias=True))
+        wh = torch.exp(c.conv(x, f"{p}_wh_conv", bias=True)) * torch.tensor(box, dtype=x.dtype)
+        cf = torch.sigmoid(c.conv(x, f"{p}_conf_conv", bias=True))
+        pr = c.conv(x, f"{p}_prob_conv", bias=True)
+        pr = torch.softmax(pr, dim=-1) if version == 2 else torch.sigmoid(pr)
+        outs += [xy, wh, cf, pr]
+    return torch.cat(outs, dim=-1)
+
+
+# ------------------------------------------- v3 -------------------------------------------------
+def yolov3_forward(weights, x, anchors, training=False, unbiased_moving_var=False):
+    c = _Ctx(weights, training, x.dtype, unbiased_moving_var)
+
+    def resblock_body(t, blocks, name):
+        t = c.cbl(t, f"{name}_dn", stride=2, padding="darknet_s2")
+        for i in range(blocks):
+            m = c.cbl(t, f"{name}_{i + 1}_1x1")
+            m = c.cbl(m, f"{name}_{i + 1}_3x3")
+            t = t + m
+        return t
+
+    def last_layers(t, name):
+        for s in ("1_1x1", "1_3x3", "2_1x1", "2_3x3", "3_1x1"):
+            t = c.cbl(t, f"{name}_{s}")
+        return t, c.cbl(t, f"{name}_3_3x3")
+
+    t = c.cbl(x, "conv1")
+    t = resblock_body(t, 1, "block1")
+    t = resblock_body(t, 2, "block2")
+    t3 = resblock_body(t, 8, "block3")
+    t4 = resblock_body(t3, 8, "block4")
+    t5 = resblock_body(t4, 4, "block5")
+    t, o1 = last_layers(t5, "last1")
+    t = L.upsample2x(c.cbl(t, "up1"))
+    t = torch.cat([t, t4], dim=-1)
+    t, o2 = last_layers(t, "last2")
+    t = L.upsample2x(c.cbl(t, "up2"))
+    t = torch.cat([t, t3], dim=-1)
+    t, o3 = last_layers(t, "last3")
+    outs = []
+    per = len(anchors) // 3
+    for i, o in enumerate((o1, o2, o3)):
+        outs.append(_head_v234(c, o, i + 1, anchors[i * per:(i + 1) * per], 3))
+    return outs, c.moving
+
+
+# ------------------------------------------- v4 -------------------------------------------------
+def yolov4_forward(weights, x, anchors, training=False, unbiased_moving_var=False):
+    c = _Ctx(weights, training, x.dtype, unbiased_moving_var)
+
+    def resstage(t, blocks, name):
+        t = c.cbl(t, f"{name}_dn", stride=2, padding="darknet_s2", act="mish")
+        cross = c.cbl(t, f"{name}_cross", act="mish")
+        t = c.cbl(t, f"{name}_pre", act="mish")
+        for i in range(blocks):
+            skip = t
+            t = c.cbl(t, f"{name}_block{i + 1}_1x1", act="mish")
+            t = c.cbl(t, f"{name}_block{i + 1}_3x3", act="mish")
+            t = t + skip
+        t = c.cbl(t, f"{name}_post", act="mish")
+        t = torch.cat([t, cross], dim=-1)
+        return c.cbl(t, f"{name}_out", act="mish")
+
+    def last_layers(t, name):
+        for s in ("1", "2", "3", "4", "5"):
+            t = c.cbl(t, f"{name}_{s}")
+        return t
+
+    t = c.cbl(x, "conv1", act="mish")
+    t = resstage(t, 1, "stage1")
+    t = resstage(t, 2, "stage2")
+    t3 = resstage(t, 8, "stage3")
+    t4 = resstage(t3, 8, "stage4")
+    t5 = resstage(t4, 4, "stage5")
+    s = c.cbl(t5, "pan_td1_1")
+    s = c.cbl(s, "pan_td1_2")
+    s = c.cbl(s, "pan_td1_spp_pre")
+    s = torch.cat([L.maxpool(s, 13, 1, "same"), L.maxpool(s, 9, 1, "same"), L.maxpool(s, 5, 1, "same"), s], dim=-1)
+    s = c.cbl(s, "pan_td1_3")
+    s = c.cbl(s, "pan_td1_4")
+    s = c.cbl(s, "pan_td1_5")
+    s_up = L.upsample2x(c.cbl(s, "pan_td1_up"))
+    m = c.cbl(t4, "pan_td2_pre")
+    m = torch.cat([m, s_up], dim=-1)
+    m = last_layers(m, "pan_td2")
+    m_up = L.upsample2x(c.cbl(m, "pan_td2_up"))
+    l = c.cbl(t3, "pan_td3_pre")
+    l = torch.cat([l, m_up], dim=-1)
+    l = last_layers(l, "pan_td3")
+    out_l = c.cbl(l, "pan_out_l")
+    l_dn = c.cbl(l, "pan_bu1_dn", stride=2, padding="darknet_s2")
+    m = torch.cat([l_dn, m], dim=-1)
+    m = last_layers(m, "pan_bu1")
+    out_m = c.cbl(m, "pan_out_m")
+    m_dn = c.cbl(m, "pan_bu2_dn", stride=2, padding="darknet_s2")
+    s = torch.cat([m_dn, s], dim=-1)
+    s = last_layers(s, "pan_bu2")
+    out_s = c.cbl(s, "pan_out_s")
+    outs = []
+    per = len(anchors) // 3
+    for i, o in enumerate((out_s, out_m, out_l)):
+        outs.append(_head_v234(c, o, i + 1, anchors[i * per:(i + 1) * per], 4))
+    return outs, c.moving
+
+
+# ------------------------------------------- v2 -------------------------------------------------
+def yolov2_forward(weights, x, anchors, training=False, unbiased_moving_var=False):
+    c = _Ctx(weights, training, x.dtype, unbiased_moving_var)
+
+    def cbl(t, name):
+        return c.cbl(t, name, bias=True)
+
+    t = cbl(x, "conv1")
+    t = L.maxpool(t, 2, 2)
+    t = cbl(t, "conv2")
+    t = L.maxpool(t, 2, 2)
+    for n in ("conv3_1", "conv3_2", "conv3_3"):
+        t = cbl(t, n)
+    t = L.maxpool(t, 2, 2)
+    for n in ("conv4_1", "conv4_2", "conv4_3"):
+        t = cbl(t, n)
+    t = L.maxpool(t, 2, 2)
+    for n in ("conv5_1", "conv5_2", "conv5_3", "conv5_4", "conv5_5"):
+        t = cbl(t, n)
+    passthrough = t
+    t = L.maxpool(t, 2, 2)
+    for n in ("conv6_1", "conv6_2", "conv6_3", "conv6_4", "conv6_5", "conv7_1", "conv7_2"):
+        t = cbl(t, n)
+    p = L.space_to_depth2(cbl(passthrough, "passthrough_conv"))
+    t = cbl(torch.cat([p, t], dim=-1), "conv8")
+    return [_head_v234(c, t, 1, anchors, 2)], c.moving
+
+
+# ------------------------------------------- v1.5 -----------------------------------------------
+def yolov1_5_forward(weights, x, training=False, unbiased_moving_var=False):
+    c = _Ctx(weights, training, x.dtype, unbiased_moving_var)
+
+    def cbl(t, name, stride=1):
+        return c.cbl(t, name, stride=stride, bias=True)
+
+    t = cbl(x, "conv1", 2)
+    t = L.maxpool(t, 2, 2)
+    t = cbl(t, "conv2")
+    t = L.maxpool(t, 2, 2)
+    for n in ("conv3_1", "conv3_2", "conv3_3", "conv3_4"):
+        t = cbl(t, n)
+    t = L.maxpool(t, 2, 2)
+    for i in range(1, 10):
+        t = cbl(t, f"conv4_{i}")
+    t = L.maxpool(t, 2, 2)
+    for n in ("conv5_1", "conv5_2", "conv5_3", "conv5_4", "conv5_5"):
+        t = cbl(t, n)
+    t = cbl(t, "conv5_6", 2)
+    t = cbl(t, "conv6_1")
+    t = cbl(t, "conv6_2")
+    xywhc = torch.sigmoid(c.conv(t, "out1_xywhc_conv", bias=True))
+    prob = torch.softmax(c.conv(t, "out1_prob_conv", bias=True), dim=-1)
+    return [torch.cat([xywhc, prob], dim=-1)], c.moving

@@ -1,0 +1,361 @@
+"""Keras-like Model shell over the HIP executor: the object `Yolo.create_model` hands back.
+
+Mirrors the slice of tf.keras.Model the reference's README drives (README.md:241-336):
+compile / fit / train_on_batch / evaluate / predict / __call__, load_weights / save_weights
+(.npz keyed by Keras layer names; h5py is not available), get_layer(name).get_weights() /
+.set_weights(), .output[i].shape, .layers, count_params().
+"""
+import time
+
+import numpy as np
+import torch
+
+from . import dp as dp_mod
+from . import optimizers as opt_mod
+from ._lib import YoloHipError
+from .engine import Network
+
+
+def _to_input(x):
+    if torch.is_tensor(x):
+        return x.to(device="cuda", dtype=torch.float32).contiguous()
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(x, dtype=np.float32))).cuda()
+
+
+class LayerView:
+    """get_layer(name) result: Keras-style weight access onto slices of the flat buffers."""
+
+    def __init__(self, model, name, getter, setter, trainable=True):
+        self.model, self.name, self._get, self._set, self.trainable = model, name, getter, setter, trainable
+
+    def get_weights(self):
+        return self._get()
+
+    def set_weights(self, weights):
+        self._set(weights)
+        self.model.net.mark_params_changed()
+
+
+class Model:
+    def __init__(self, builder, version, seed=1234, unbiased_moving_var=False):
+        self.net = Network(builder, seed=seed, unbiased_moving_var=unbiased_moving_var)
+        self.version = version
+        self.single_output = len(self.net.outputs) == 1 and version in (1, 2)
+        self.optimizer = None
+        self.loss = None
+        self.metrics = None
+        self._reducer = None
+        self._loss_bufs = None
+        self.stop_training = False
+        self.history = None
+
+    # ---- structure ----
+    @property
+    def input_shape(self):
+        return (None, self.net.input.h, self.net.input.w, self.net.input.c)
+
+    @property
+    def output(self):
+        outs = self.net.outputs
+        return outs[0] if self.single_output else list(outs)
+
+    @property
+    def output_shape(self):
+        outs = [o.shape for o in self.net.outputs]
+        return outs[0] if self.single_output else outs
+
+    def count_params(self):
+        return self.net.num_params + self.net.num_state
+
+    def trainable_count(self):
+        return self.net.num_params
+
+    @property
+    def layers(self):
+        return [self.get_layer(n) for n in self.layer_names()]
+
+    def layer_names(self):
+        names = []
+        for u in self.net.units:
+            if u.kind == "conv":
+                names.append(f"{u.name}_conv")
+                if u.bn:
+                    names.append(f"{u.name}_bn")
+            elif u.kind == "head":
+                names += self._head_layer_names(u)
+            else:
+                names.append(u.name)
+        return names
+
+    def _head_layer_names(self, u):
+        i = u.level + 1
+        if u.version == 1:
+            return [f"out{i}_xywhc_conv", f"out{i}_prob_conv"]
+        names = []
+        for j in range(u.A):
+            names += [f"out{i}_box{j + 1}_{p}_conv" for p in ("xy", "wh", "conf", "prob")]
+            if u.version == 4:
+                names.append(f"out{i}_box{j + 1}_anchor")
+        return names
+
+    def _head_rows(self, u, lname):
+        """row range of the fused head kernel that a Keras head layer owns"""
+        D = 5 + u.C
+        if u.version == 1:
+            return (0, 5 * u.A) if lname.endswith("_xywhc_conv") else (5 * u.A, 5 * u.A + u.C)
+        j = int(lname.split("_box")[1].split("_")[0]) - 1
+        part = lname.split("_")[-2]
+        lo, hi = {"xy": (0, 2), "wh": (2, 4), "conf": (4, 5), "prob": (5, D)}[part]
+        return j * D + lo, j * D + hi
+
+    def get_layer(self, name=None, index=None):
+        if name is None:
+            name = self.layer_names()[index]
+        net = self.net
+        for u in net.units:
+            if u.kind == "conv" and name == f"{u.name}_conv":
+                def get(u=u):
+                    k = net.params.view(u.p_kernel.name).cpu().numpy().reshape(u.p_kernel.shape)
+                    out = [np.transpose(k, (1, 2, 3, 0)).copy()]
+                    if u.p_bias is not None:
+                        out.append(net.params.view(u.p_bias.name).cpu().numpy().copy())
+                    return out
+
+                def set_(w, u=u):
+                    k = np.transpose(np.asarray(w[0], dtype=np.float32), (3, 0, 1, 2))
+                    net.params.view(u.p_kernel.name).copy_(torch.from_numpy(np.ascontiguousarray(k)).reshape(-1))
+                    if u.p_bias is not None:
+                        net.params.view(u.p_bias.name).copy_(torch.from_numpy(np.asarray(w[1], dtype=np.float32)))
+                return LayerView(self, name, get, set_)
+            if u.kind == "conv" and u.bn and name == f"{u.name}_bn":
+                def get(u=u):
+                    return [net.params.view(u.p_gamma.name).cpu().numpy().copy(),
+                            net.params.view(u.p_beta.name).cpu().numpy().copy(),
+                            net.state.view(u.s_mean.name).cpu().numpy().copy(),
+                            net.state.view(u.s_var.name).cpu().numpy().copy()]
+
+                def set_(w, u=u):
+                    for view, a in zip((net.params.view(u.p_gamma.name), net.params.view(u.p_beta.name),
+                                        net.state.view(u.s_mean.name), net.state.view(u.s_var.name)), w):
+                        view.copy_(torch.from_numpy(np.asarray(a, dtype=np.float32)))
+                return LayerView(self, name, get, set_)
+            if u.kind == "head" and name in self._head_layer_names(u):
+                if name.endswith("_anchor"):
+                    j = int(name.split("_box")[1].split("_")[0]) - 1
+
+                    def get(u=u, j=j):
+                        a = net._anchors_dev[u.name].cpu().numpy().reshape(-1, 2)[j]
+                        return [a.reshape(1, 1, 1, 2).copy()]
+
+                    def set_(w, u=u, j=j):
+                        a = np.asarray(w[0], dtype=np.float32).reshape(2)
+                        net._anchors_dev[u.name][2 * j:2 * j + 2] = torch.from_numpy(a).cuda()
+                        u.anchors[j] = (float(a[0]), float(a[1]))
+                    return LayerView(self, name, get, set_, trainable=False)
+                lo, hi = self._head_rows(u, name)
+                cin = u.src.c
+
+                def get(u=u, lo=lo, hi=hi, cin=cin):
+                    k = net.params.view(u.p_kernel.name).cpu().numpy().reshape(-1, cin)[lo:hi]
+                    b = net.params.view(u.p_bias.name).cpu().numpy()[lo:hi]
+                    return [k.T.reshape(1, 1, cin, hi - lo).copy(), b.copy()]
+
+                def set_(w, u=u, lo=lo, hi=hi, cin=cin):
+                    k = np.asarray(w[0], dtype=np.float32).reshape(cin, hi - lo).T
+                    net.params.view(u.p_kernel.name).reshape(-1, cin)[lo:hi] = torch.from_numpy(
+                        np.ascontiguousarray(k)).cuda()
+                    net.params.view(u.p_bias.name)[lo:hi] = torch.from_numpy(np.asarray(w[1], dtype=np.float32)).cuda()
+                return LayerView(self, name, get, set_)
+            if u.kind not in ("conv", "head") and name == u.name:
+                return LayerView(self, name, lambda: [], lambda w: None, trainable=False)
+        raise ValueError(f"No such layer: {name}")
+
+    def get_weights(self):
+        out = []
+        for n in self.layer_names():
+            out += self.get_layer(n).get_weights()
+        return out
+
+    def set_weights(self, weights):
+        i = 0
+        for n in self.layer_names():
+            layer = self.get_layer(n)
+            k = len(layer.get_weights())
+            if k:
+                layer.set_weights(weights[i:i + k])
+                i += k
+
+    def set_body_weights(self, other):
+        """`model_body.set_weights(pretrained_body.get_weights())` (yolov3/__init__.py:170-171): copy every
+        non-head layer from another Model of the same body, by layer name."""
+        for n in other.layer_names():
+            if n.startswith("out") and ("_box" in n or n.endswith(("_xywhc_conv", "_prob_conv"))):
+                continue
+            w = other.get_layer(n).get_weights()
+            if w:
+                self.get_layer(n).set_weights(w)
+
+    def set_anchors_trainable(self, trainable):
+        """yolov4/__init__.py:150-159. The head-activation backward kernel produces d(anchor)
+        (yolo_head_act_bwd `danchors`); training them is not wired into the optimizer yet."""
+        if trainable:
+            raise YoloHipError("trainable anchors are not supported yet (anchors stay constants)")
+
+    def save_weights(self, path):
+        """.npz keyed '<keras layer name>/<index>' (h5py is unavailable: SURVEY.md section 5)."""
+        d = {}
+        for n in self.layer_names():
+            for i, a in enumerate(self.get_layer(n).get_weights()):
+                d[f"{n}/{i}"] = a
+        np.savez(path, **d)
+
+    def load_weights(self, path):
+        if str(path).endswith((".h5", ".hdf5")):
+            raise YoloHipError("HDF5 weights need h5py, which is not available here; convert to .npz "
+                               "(keys '<layer name>/<index>')")
+        d = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        for n in self.layer_names():
+            layer = self.get_layer(n)
+            k = len(layer.get_weights())
+            if k and f"{n}/0" in d:
+                layer.set_weights([d[f"{n}/{i}"] for i in range(k)])
+
+    # ---- inference ----
+    def __call__(self, x, training=False):
+        outs = self.net.forward(_to_input(x), training=training)
+        return outs[0] if self.single_output else outs
+
+    def predict(self, x, batch_size=32, verbose=0, **_):
+        if hasattr(x, "__getitem__") and hasattr(x, "__len__") and not isinstance(x, (np.ndarray, torch.Tensor)):
+            chunks = [x[i][0] for i in range(len(x))]     # Sequence of (img, label) batches
+        else:
+            n = len(x)
+            chunks = [x[i:i + batch_size] for i in range(0, n, batch_size)]
+        outs = None
+        for c in chunks:
+            o = self.net.forward(_to_input(c), training=False)
+            o = [t.cpu().numpy() for t in o]
+            outs = [[a] for a in o] if outs is None else [acc + [a] for acc, a in zip(outs, o)]
+        res = [np.concatenate(a, axis=0) for a in outs]
+        return res[0] if self.single_output else res
+
+    # ---- training ----
+    def compile(self, optimizer="adam", loss=None, metrics=None, **_):
+        if isinstance(optimizer, str):
+            optimizer = {"adam": opt_mod.Adam, "sgd": opt_mod.SGD}[optimizer.lower()]()
+        self.optimizer = optimizer
+        self.optimizer.bind(self.net)
+        nout = len(self.net.outputs)
+        self.loss = list(loss) if isinstance(loss, (list, tuple)) else [loss] * nout
+        if len(self.loss) != nout:
+            raise ValueError(f"need {nout} losses, got {len(self.loss)}")
+        if metrics is None:
+            metrics = [[] for _ in range(nout)]
+        elif nout == 1 and (not metrics or not isinstance(metrics[0], (list, tuple))):
+            metrics = [list(metrics)]
+        self.metrics = [list(m) for m in metrics]
+        self._loss_bufs = [torch.zeros(8, device="cuda", dtype=torch.float64) for _ in range(nout)]
+        self._dpred = None
+
+    def enable_data_parallel(self, process_group=None, bucket_bytes=48 << 20):
+        """Call after compile() in a torch.distributed job (one process per GPU)."""
+        segs, units = dp_mod.network_segments(self.net)
+        self._reducer = dp_mod.GradReducer(self.net.grads, segs, process_group, bucket_bytes)
+        index = {id(u): i for i, u in enumerate(units)}
+        self.net.grad_ready_hook = lambda u: self._reducer.segment_done(index[id(u)])
+        dp_mod.broadcast_parameters([self.net.params.data, self.net.state.data], 0, process_group)
+        self.net.mark_params_changed()
+
+    def _labels(self, y):
+        ys = [y] if not isinstance(y, (list, tuple)) else list(y)
+        out = []
+        for a in ys:
+            if torch.is_tensor(a):
+                out.append(a.to(device="cuda", dtype=torch.float32).contiguous())
+            else:
+                out.append(torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).cuda())
+        return out
+
+    def train_step_device(self, x, y_list, with_metrics=False):
+        """One optimizer step on device-resident float32 tensors. Returns the per-output loss
+        buffers (device float64[8], element 0 = loss) without synchronising."""
+        if self.optimizer is None:
+            raise YoloHipError("compile() the model before training")
+        outs = self.net.forward(x, training=True)
+        if self._dpred is None or self._dpred[0].shape != outs[0].shape:
+            self._dpred = [torch.empty_like(o) for o in outs]
+        for i, (o, yt) in enumerate(zip(outs, y_list)):
+            self.loss[i].fwd_bwd(yt, o, grad_scale=1.0, dpred=self._dpred[i], loss_out=self._loss_bufs[i])
+        mvals = None
+        if with_metrics:
+            mvals = [[m(yt, o) for m in ms] for ms, o, yt in zip(self.metrics, outs, y_list)]
+        self.net.backward(self._dpred)
+        scale = self._reducer.finish() if self._reducer is not None else 1.0
+        self.optimizer.step(grad_scale=scale)
+        return self._loss_bufs, mvals
+
+    def train_on_batch(self, x, y, return_dict=False, **_):
+        bufs, mvals = self.train_step_device(_to_input(x), self._labels(y), with_metrics=bool(self.metrics))
+        losses = [float(b[0].item()) for b in bufs]
+        total = sum(losses)
+        flat = [float(v.item()) for ms in (mvals or []) for v in ms]
+        res = [total] + (losses if len(losses) > 1 else []) + flat
+        return res if len(res) > 1 else res[0]
+
+    def test_on_batch(self, x, y):
+        outs = self.net.forward(_to_input(x), training=False)
+        ys = self._labels(y)
+        losses = [float(l(yt, o).item()) for l, o, yt in zip(self.loss, outs, ys)]
+        mvals = [float(m(yt, o).item()) for ms, o, yt in zip(self.metrics, outs, ys) for m in ms]
+        return [sum(losses)] + (losses if len(losses) > 1 else []) + mvals
+
+    def _iter_batches(self, x, y, batch_size, shuffle, rng):
+        if y is None:   # Sequence-like: x[i] -> (img, labels)
+            order = np.arange(len(x))
+            for i in order:
+                yield x[int(i)]
+            if hasattr(x, "on_epoch_end"):
+                x.on_epoch_end()
+            return
+        n = len(x)
+        order = rng.permutation(n) if shuffle else np.arange(n)
+        ys = y if isinstance(y, (list, tuple)) else [y]
+        for i in range(0, n, batch_size):
+            sel = order[i:i + batch_size]
+            yb = [a[sel] for a in ys]
+            yield x[sel], (yb if isinstance(y, (list, tuple)) else yb[0])
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, validation_data=None, shuffle=True,
+            initial_epoch=0, callbacks=None, **_):
+        batch_size = batch_size or 32
+        rng = np.random.default_rng(0)
+        hist = {"loss": []}
+        for ep in range(initial_epoch, epochs):
+            t0 = time.time()
+            tot, nb = 0.0, 0
+            for xb, yb in self._iter_batches(x, y, batch_size, shuffle, rng):
+                r = self.train_on_batch(xb, yb)
+                tot += r[0] if isinstance(r, list) else r
+                nb += 1
+            hist["loss"].append(tot / max(nb, 1))
+            msg = f"Epoch {ep + 1}/{epochs} - {time.time() - t0:.1f}s - loss: {hist['loss'][-1]:.4f}"
+            if validation_data is not None:
+                v = self.evaluate(validation_data[0], validation_data[1], batch_size=batch_size, verbose=0)
+                hist.setdefault("val_loss", []).append(v[0] if isinstance(v, list) else v)
+                msg += f" - val_loss: {hist['val_loss'][-1]:.4f}"
+            if verbose:
+                print(msg)
+        self.history = type("History", (), {"history": hist})()
+        return self.history
+
+    def evaluate(self, x=None, y=None, batch_size=None, verbose=1, **_):
+        batch_size = batch_size or 32
+        acc, nb = None, 0
+        for xb, yb in self._iter_batches(x, y, batch_size, False, None):
+            r = self.test_on_batch(xb, yb)
+            acc = r if acc is None else [a + b for a, b in zip(acc, r)]
+            nb += 1
+        res = [a / max(nb, 1) for a in acc]
+        if verbose:
+            print("evaluate:", res)
+        return res if len(res) > 1 else res[0]

@@ -1,0 +1,45 @@
+"""Optimizers over the flat parameter buffer (one fused HIP launch per step).
+
+`Adam` mirrors tf.keras.optimizers.Adam (README.md:241: `Adam(lr=1e-4)`): defaults beta_1=0.9,
+beta_2=0.999, epsilon=1e-7, bias-corrected, no weight decay."""
+import torch
+
+from . import ops
+
+
+class Optimizer:
+    def bind(self, net):
+        self.net = net
+
+    def step(self, grad_scale=1.0):
+        raise NotImplementedError
+
+
+class Adam(Optimizer):
+    def __init__(self, learning_rate=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, lr=None, **_):
+        self.learning_rate = float(lr if lr is not None else learning_rate)
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+        self.iterations = 0
+        self.m = self.v = None
+
+    def bind(self, net):
+        self.net = net
+        self.m = torch.zeros_like(net.params.data)
+        self.v = torch.zeros_like(net.params.data)
+
+    def step(self, grad_scale=1.0):
+        self.iterations += 1
+        ops.adam_step(self.net.params.data, self.net.grads, self.m, self.v, self.learning_rate, self.iterations,
+                      self.beta_1, self.beta_2, self.epsilon, grad_scale=grad_scale, zero_grad=True)
+        self.net.mark_params_changed()
+
+
+class SGD(Optimizer):
+    def __init__(self, learning_rate=0.01, lr=None, **_):
+        self.learning_rate = float(lr if lr is not None else learning_rate)
+        self.iterations = 0
+
+    def step(self, grad_scale=1.0):
+        self.iterations += 1
+        ops.sgd_step(self.net.params.data, self.net.grads, self.learning_rate, grad_scale=grad_scale, zero_grad=True)
+        self.net.mark_params_changed()
