@@ -65,6 +65,16 @@ def leaky(x, alpha=0.1):
     return torch.where(x > 0, x, alpha * x)
 
 
+def leaky_masked(x, positive_mask, alpha=0.1):
+    """LeakyReLU with the branch chosen by `positive_mask` instead of by sign(x).
+
+    Test device for end-to-end gradient parity: an fp32 execution and this fp64 oracle can disagree
+    on sign(x) only where |x| is within fp32 rounding of 0 (the caller asserts that); forcing the
+    device's branch pattern changes the forward value by <= 0.9*|x| ~ 1e-6 there but removes the
+    O(1) gradient discontinuity that any two executions of a ReLU network are subject to."""
+    return torch.where(positive_mask, x, alpha * x)
+
+
 def softplus(x):
     return torch.clamp(x, min=0) + torch.log1p(torch.exp(-x.abs()))
 

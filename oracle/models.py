@@ -8,8 +8,8 @@
 Weights come in as {"<keras layer name>/<index>": ndarray} in Keras layouts (Conv kernel HWIO
 [, bias]; BN gamma, beta, moving_mean, moving_variance), i.e. what Model.save_weights writes.
 v1.5 / v2 layers are unnamed in the reference; the names used here are this repo's.
-Every function returns (outputs, new_moving) where new_moving maps bn layer name ->
-(moving_mean, moving_variance) after the Keras update when training=True.
+Every function returns (outputs, ctx); ctx.moving maps bn layer name -> (moving_mean,
+moving_variance) after the Keras update when training=True.
 """
 import torch
 
@@ -17,11 +17,14 @@ from . import layers as L
 
 
 class _Ctx:
-    def __init__(self, weights, training, dtype, unbiased_moving_var=False):
+    def __init__(self, weights, training, dtype, unbiased_moving_var=False, leaky_masks=None):
         self.w = {k: torch.as_tensor(v, dtype=dtype) if not torch.is_tensor(v) else v for k, v in weights.items()}
         self.training = training
         self.moving = {}
         self.unbiased = unbiased_moving_var
+        self.leaky_masks = leaky_masks      # {unit name: bool tensor}: see layers.leaky_masked
+        self.mask_disagree = {}             # unit name -> largest |z| where the forced branch differs
+        self.acts = {}                      # unit name -> activation (debug / per-layer parity)
 
     def conv(self, x, name, stride=1, padding="same", bias=False):
         b = self.w[f"{name}/1"] if bias else None
@@ -42,7 +45,17 @@ class _Ctx:
         """conv -> BatchNormalization -> LeakyReLU(0.1) | Mish"""
         x = self.conv(x, f"{name}_conv", stride, padding, bias)
         x = self.bn(x, f"{name}_bn")
-        return L.leaky(x) if act == "leaky" else L.mish(x)
+        if act != "leaky":
+            out = L.mish(x)
+        elif self.leaky_masks is not None and name in self.leaky_masks:
+            m = self.leaky_masks[name]
+            bad = (x.detach() > 0) != m
+            self.mask_disagree[name] = float(x.detach().abs()[bad].max()) if bad.any() else 0.0
+            out = L.leaky_masked(x, m)
+        else:
+            out = L.leaky(x)
+        self.acts[name] = out.detach()
+        return out
 
 
 def _head_v234(c, x, i_out, anchors, version):
@@ -60,8 +73,8 @@ def _head_v234(c, x, i_out, anchors, version):
 
 
 # ------------------------------------------- v3 -------------------------------------------------
-def yolov3_forward(weights, x, anchors, training=False, unbiased_moving_var=False):
-    c = _Ctx(weights, training, x.dtype, unbiased_moving_var)
+def yolov3_forward(weights, x, anchors, training=False, unbiased_moving_var=False, leaky_masks=None):
+    c = _Ctx(weights, training, x.dtype, unbiased_moving_var, leaky_masks)
 
     def resblock_body(t, blocks, name):
         t = c.cbl(t, f"{name}_dn", stride=2, padding="darknet_s2")
@@ -93,12 +106,12 @@ def yolov3_forward(weights, x, anchors, training=False, unbiased_moving_var=Fals
     per = len(anchors) // 3
     for i, o in enumerate((o1, o2, o3)):
         outs.append(_head_v234(c, o, i + 1, anchors[i * per:(i + 1) * per], 3))
-    return outs, c.moving
+    return outs, c
 
 
 # ------------------------------------------- v4 -------------------------------------------------
-def yolov4_forward(weights, x, anchors, training=False, unbiased_moving_var=False):
-    c = _Ctx(weights, training, x.dtype, unbiased_moving_var)
+def yolov4_forward(weights, x, anchors, training=False, unbiased_moving_var=False, leaky_masks=None):
+    c = _Ctx(weights, training, x.dtype, unbiased_moving_var, leaky_masks)
 
     def resstage(t, blocks, name):
         t = c.cbl(t, f"{name}_dn", stride=2, padding="darknet_s2", act="mish")
@@ -152,12 +165,12 @@ def yolov4_forward(weights, x, anchors, training=False, unbiased_moving_var=Fals
     per = len(anchors) // 3
     for i, o in enumerate((out_s, out_m, out_l)):
         outs.append(_head_v234(c, o, i + 1, anchors[i * per:(i + 1) * per], 4))
-    return outs, c.moving
+    return outs, c
 
 
 # ------------------------------------------- v2 -------------------------------------------------
-def yolov2_forward(weights, x, anchors, training=False, unbiased_moving_var=False):
-    c = _Ctx(weights, training, x.dtype, unbiased_moving_var)
+def yolov2_forward(weights, x, anchors, training=False, unbiased_moving_var=False, leaky_masks=None):
+    c = _Ctx(weights, training, x.dtype, unbiased_moving_var, leaky_masks)
 
     def cbl(t, name):
         return c.cbl(t, name, bias=True)
@@ -180,12 +193,12 @@ def yolov2_forward(weights, x, anchors, training=False, unbiased_moving_var=Fals
         t = cbl(t, n)
     p = L.space_to_depth2(cbl(passthrough, "passthrough_conv"))
     t = cbl(torch.cat([p, t], dim=-1), "conv8")
-    return [_head_v234(c, t, 1, anchors, 2)], c.moving
+    return [_head_v234(c, t, 1, anchors, 2)], c
 
 
 # ------------------------------------------- v1.5 -----------------------------------------------
-def yolov1_5_forward(weights, x, training=False, unbiased_moving_var=False):
-    c = _Ctx(weights, training, x.dtype, unbiased_moving_var)
+def yolov1_5_forward(weights, x, training=False, unbiased_moving_var=False, leaky_masks=None):
+    c = _Ctx(weights, training, x.dtype, unbiased_moving_var, leaky_masks)
 
     def cbl(t, name, stride=1):
         return c.cbl(t, name, stride=stride, bias=True)
@@ -207,4 +220,4 @@ def yolov1_5_forward(weights, x, training=False, unbiased_moving_var=False):
     t = cbl(t, "conv6_2")
     xywhc = torch.sigmoid(c.conv(t, "out1_xywhc_conv", bias=True))
     prob = torch.softmax(c.conv(t, "out1_prob_conv", bias=True), dim=-1)
-    return [torch.cat([xywhc, prob], dim=-1)], c.moving
+    return [torch.cat([xywhc, prob], dim=-1)], c
