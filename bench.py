@@ -1,0 +1,165 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec training YOLOv3 416x416 bs=32/GPU (BASELINE.json).
+
+One "step" = forward (training-mode BN) + the three fused loss/gradient kernels + backward +
+gradient all-reduce (N > 1, RCCL over xGMI, overlapped) + Adam, on a synthetic batch that is
+already resident in HBM. Prints ONE JSON line (rank 0) with the `roofline` of the dominant kernel
+(the fp32 MFMA implicit-GEMM conv) measured with HIP events inside the timed region, and, at
+N = 1, a `cpu_baseline` (the torch-CPU restatement of the same training step on the host cores;
+tf.keras is not installable here).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
+BATCH = 32
+HW = 416
+CLASSES = 80
+
+
+def cpu_baseline(threads):
+    """Bounded sample of the SAME workload on the host CPU: one training step (forward, loss,
+    autograd backward) of the torch-CPU restatement of the reference graph at batch 2, fp32."""
+    from oracle import losses as OL
+    from oracle import models as OM
+    from tf2_yolo_amd import graphs, labels
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(1234)
+    n = 2
+    x, ys = labels.synthetic_batch(rng, n, (HW, HW), CLASSES)
+    b = graphs.build_yolov3((HW, HW, 3), CLASSES)
+    w = {}
+    for u in b.units:
+        if u.kind == "conv":
+            cin = u.src.c
+            w[f"{u.name}_conv/0"] = torch.randn(u.k, u.k, cin, u.cout) * (2.0 / (u.k * u.k * cin)) ** 0.5
+            w[f"{u.name}_bn/0"], w[f"{u.name}_bn/1"] = torch.ones(u.cout), torch.zeros(u.cout)
+            w[f"{u.name}_bn/2"], w[f"{u.name}_bn/3"] = torch.zeros(u.cout), torch.ones(u.cout)
+        elif u.kind == "head":
+            cin = u.src.c
+            for j in range(u.A):
+                for part, c in (("xy", 2), ("wh", 2), ("conf", 1), ("prob", u.C)):
+                    w[f"out{u.level + 1}_box{j + 1}_{part}_conv/0"] = torch.randn(1, 1, cin, c) * (2.0 / cin) ** 0.5
+                    w[f"out{u.level + 1}_box{j + 1}_{part}_conv/1"] = torch.zeros(c)
+    for v in w.values():
+        v.requires_grad_(True)
+    anchors = graphs.V3_DEFAULT_ANCHORS
+    lossf = [OL.wrap_yolo_loss_v3((13 * 2 ** i, 13 * 2 ** i), 3, CLASSES, anchors=anchors[3 * i:3 * i + 3],
+                                  loss_weight=[1, 1, 5, 1]) for i in range(3)]
+    xt = torch.from_numpy(x)
+    t0 = time.perf_counter()
+    outs, _ = OM.yolov3_forward(w, xt, anchors, training=True)
+    total = sum(f(torch.from_numpy(y), o) for f, y, o in zip(lossf, ys, outs))
+    total.backward()
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"1 training step (fwd+loss+autograd bwd, no optimizer) of the torch-CPU/oneDNN fp32 restatement "
+                      f"of the reference YOLOv3 graph, batch {n} at 416x416 C=80, {dt:.1f} s wall; NOT tf.keras "
+                      f"(TensorFlow is not installable in this pipeline)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
+                         f"(WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import yolov3
+    from tf2_yolo_amd import labels, ops, optimizers
+
+    yolo = yolov3.Yolo((HW, HW, 3), [f"c{i}" for i in range(CLASSES)])
+    yolo.create_model(pretrained_body=None, seed=1234)            # same weights on every rank
+    model = yolo.model
+    model.compile(optimizer=optimizers.Adam(learning_rate=1e-4), loss=yolo.loss())   # README.md:241
+    if world > 1:
+        model.enable_data_parallel()
+
+    rng = np.random.default_rng(1234 + rank)                     # seed = 1234 + rank
+    x_h, ys_h = labels.synthetic_batch(rng, args.batch, (HW, HW), CLASSES)
+    x = torch.from_numpy(x_h).cuda()
+    ys = [torch.from_numpy(y).cuda() for y in ys_h]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_step_device(x, ys)
+    barrier()
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    ops.TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bufs, _ = model.train_step_device(x, ys)
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    loss_val = float(sum(b[0].item() for b in bufs))
+
+    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        roof = None
+        if timer is not None:
+            agg = timer.summary()
+            name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
+                    "flops_per_launch": a["flops"] / a["launches"],
+                    "all_conv_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
+                                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                         for k, v in sorted(agg.items())}}
+        out = {"metric": "images/sec training YOLOv3 416x416 bs=32/GPU", "value": round(world * args.batch * args.steps / dt, 2),
+               "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "YOLOv3 Darknet-53 416x416, 9 anchors / 3 FPN scales, C=80: training step = "
+                                      "forward (batch-stat BN) + 3 fused loss/grad kernels + backward + "
+                                      "gradient all-reduce + Adam",
+                          "global_batch": world * args.batch, "per_gpu_batch": args.batch,
+                          "parallelism": f"dp{world}", "loss": round(loss_val, 4)},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

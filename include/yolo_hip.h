@@ -84,6 +84,9 @@ int yolo_conv2d_dgrad(const yolo_conv_desc* d, const float* dy, const float* wT,
 int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const float* dy,
                       float* dw, float* dbias, void* stream);
 
+/* dbias[co] += sum over the P = N*Ho*Wo pixels of dy[p][co] (the bias half of yolo_conv2d_wgrad) */
+int yolo_conv2d_wgrad_bias(const float* dy, long long P, int Cout, float* dbias, void* stream);
+
 /* wT[ci][r][s][co] = w[co][r][s][ci] */
 int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "yolo_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "yolo_conv2d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P]),
     "yolo_conv2d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),
+    "yolo_conv2d_wgrad_bias": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_filter_transpose": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "yolo_bn_stats": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_bn_finalize": (c_int, [_P, _LL, c_int, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),

@@ -685,18 +685,21 @@ extern "C" int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const 
   else if (bflat) rc = dispatch_wgrad<false, true>(a, st);
   else rc = dispatch_wgrad<false, false>(a, st);
   if (rc) return rc;
-  if (dbias != nullptr) {
-    int cw = 32;
-    while (cw < d->Cout && cw < 256) cw <<= 1;
-    dim3 block(cw, 256 / cw);
-    const int gy = (d->Cout + cw - 1) / cw;
-    long long gx = (a.M + block.y * 64 - 1) / (block.y * 64);
-    if (gx > 1024) gx = 1024;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx, gy), block, 0, st, dy, a.M, d->Cout, dbias);
-    return check_launch("colsum_kernel");
-  }
+  if (dbias != nullptr) return yolo_conv2d_wgrad_bias(dy, a.M, d->Cout, dbias, stream);
   return YOLO_OK;
+}
+
+extern "C" int yolo_conv2d_wgrad_bias(const float* dy, long long P, int Cout, float* dbias, void* stream) {
+  YOLO_REQUIRE(dy && dbias && P > 0 && Cout > 0, "conv_wgrad_bias: bad args");
+  int cw = 32;
+  while (cw < Cout && cw < 256) cw <<= 1;
+  dim3 block(cw, 256 / cw);
+  const int gy = (Cout + cw - 1) / cw;
+  long long gx = (P + block.y * 64 - 1) / (block.y * 64);
+  if (gx > 1024) gx = 1024;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx, gy), block, 0, as_stream(stream), dy, P, Cout, dbias);
+  return check_launch("colsum_kernel");
 }
 
 extern "C" int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream) {

@@ -16,6 +16,45 @@ BN_EPS = 1e-3       # Keras BatchNormalization default
 BN_MOMENTUM = 0.99
 
 
+class KernelTimer:
+    """Brackets the MFMA conv launches with HIP events on the launch stream (bench.py roofline).
+    Aggregates per kernel variant: launches, device time, algorithmic FLOPs (2*M*N*K, no padding,
+    im2col or recompute credit). Enabled by assigning an instance to `ops.TIMER`."""
+
+    def __init__(self):
+        self.pending = []
+
+    def bracket(self, name, flops, launches, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        self.pending.append((name, flops, launches, s, e))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, launches, s, e in self.pending:
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            a["launches"] += launches
+            a["ms"] += s.elapsed_time(e)
+            a["flops"] += flops
+        self.pending = []
+        return agg
+
+
+TIMER = None
+
+
+def _conv_flops(d):
+    return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.kh * d.kw * d.Cin
+
+
+def _gather_variant(cout, flat):
+    bn = 32 if cout <= 32 else (64 if cout <= 64 else 128)
+    return f"gather_conv_kernel<128,{bn}{',flat' if flat else ''}>"
+
+
 def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -65,8 +104,15 @@ def conv2d_fwd(d, x, w, bias=None, out=None, stats=None):
         raise YoloHipError("conv2d_fwd: tensor sizes do not match the descriptor")
     if out.numel() != d.N * d.Ho * d.Wo * d.Cout:
         raise YoloHipError("conv2d_fwd: output size does not match the descriptor")
-    check(_lib.load().yolo_conv2d_fwd(byref(d), _p(x), _p(w), _p(bias), _p(out), _p(stats), _stream()),
-          "yolo_conv2d_fwd")
+    def run():
+        check(_lib.load().yolo_conv2d_fwd(byref(d), _p(x), _p(w), _p(bias), _p(out), None, _stream()),
+              "yolo_conv2d_fwd")
+    if TIMER is not None:
+        TIMER.bracket(_gather_variant(d.Cout, d.Cin % 32 != 0), _conv_flops(d), 1, run)
+    else:
+        run()
+    if stats is not None:
+        bn_stats(out, d.Cout, stats)
     return out
 
 
@@ -85,8 +131,13 @@ def conv2d_dgrad(d, dy, wT, dx=None, accumulate=False):
         accumulate = False
     if dy.numel() != d.N * d.Ho * d.Wo * d.Cout or dx.numel() != d.N * d.H * d.W * d.Cin:
         raise YoloHipError("conv2d_dgrad: tensor sizes do not match the descriptor")
-    check(_lib.load().yolo_conv2d_dgrad(byref(d), _p(dy), _p(wT), _p(dx), int(bool(accumulate)), _stream()),
-          "yolo_conv2d_dgrad")
+    def run():
+        check(_lib.load().yolo_conv2d_dgrad(byref(d), _p(dy), _p(wT), _p(dx), int(bool(accumulate)), _stream()),
+              "yolo_conv2d_dgrad")
+    if TIMER is not None:
+        TIMER.bracket(_gather_variant(d.Cin, d.Cout % 32 != 0), _conv_flops(d), d.sh * d.sw, run)
+    else:
+        run()
     return dx
 
 
@@ -94,7 +145,15 @@ def conv2d_wgrad(d, x, dy, dw, dbias=None):
     _chk_f32(x, dy, dw, dbias)
     if dw.numel() != d.Cout * d.kh * d.kw * d.Cin:
         raise YoloHipError("conv2d_wgrad: dw size does not match the descriptor")
-    check(_lib.load().yolo_conv2d_wgrad(byref(d), _p(x), _p(dy), _p(dw), _p(dbias), _stream()), "yolo_conv2d_wgrad")
+    def run():
+        check(_lib.load().yolo_conv2d_wgrad(byref(d), _p(x), _p(dy), _p(dw), None, _stream()), "yolo_conv2d_wgrad")
+    if TIMER is not None:
+        TIMER.bracket("wgrad_kernel", _conv_flops(d), 1, run)
+    else:
+        run()
+    if dbias is not None:
+        check(_lib.load().yolo_conv2d_wgrad_bias(_p(dy), d.N * d.Ho * d.Wo, d.Cout, _p(dbias), _stream()),
+              "yolo_conv2d_wgrad_bias")
     return dw
 
 
