@@ -32,13 +32,13 @@ CLASSES = 80
 
 def cpu_baseline(threads):
     """Bounded sample of the SAME workload on the host CPU: one training step (forward, loss,
-    autograd backward) of the torch-CPU restatement of the reference graph at batch 2, fp32."""
+    autograd backward) of the torch-CPU restatement of the reference graph at batch 16, fp32 (~10 s)."""
     from oracle import losses as OL
     from oracle import models as OM
     from tf2_yolo_amd import graphs, labels
     torch.set_num_threads(threads)
     rng = np.random.default_rng(1234)
-    n = 2
+    n = 16
     x, ys = labels.synthetic_batch(rng, n, (HW, HW), CLASSES)
     b = graphs.build_yolov3((HW, HW, 3), CLASSES)
     w = {}
@@ -108,6 +108,12 @@ def main():
     x = torch.from_numpy(x_h).cuda()
     ys = [torch.from_numpy(y).cuda() for y in ys_h]
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    log(f"model built: {model.trainable_count()} trainable params; data ready")
+
     def barrier():
         if world > 1:
             dist.barrier()
@@ -116,6 +122,7 @@ def main():
     for _ in range(args.warmup):
         model.train_step_device(x, ys)
     barrier()
+    log("warmup done")
     timer = None if args.no_kernel_timer else ops.KernelTimer()
     ops.TIMER = timer
     t0 = time.perf_counter()
@@ -124,6 +131,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     ops.TIMER = None
+    log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     loss_val = float(sum(b[0].item() for b in bufs))
 
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -155,7 +163,12 @@ def main():
                           "parallelism": f"dp{world}", "loss": round(loss_val, 4)},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(os.cpu_count() or 1)
+            log("cpu baseline (bounded sample) ...")
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            out["cpu_baseline"] = cpu_baseline(min(cores, 16))   # the GPU box's CPU share is 16 cores
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

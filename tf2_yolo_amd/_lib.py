@@ -92,6 +92,10 @@ def load():
         raise YoloHipError(
             f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
             "there is no CPU fallback for the product path")
+    # torch bundles its own HIP runtime under the same SONAME (libamdhip64.so.7). It must be mapped
+    # BEFORE this library so that both resolve to ONE runtime (one device context, shared streams);
+    # loading libyolo_hip.so first would pull in /opt/rocm's copy and give torch a second runtime.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
