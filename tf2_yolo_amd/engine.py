@@ -242,6 +242,29 @@ class GraphBuilder:
         return out
 
 
+def count_params(builder):
+    """(trainable, non_trainable) parameter counts of a built graph (no device needed)."""
+    train = state = 0
+    for u in builder.units:
+        if u.kind == "conv":
+            train += u.cout * u.k * u.k * u.src.c + (u.cout if u.bias else 0) + (2 * u.cout if u.bn else 0)
+            state += 2 * u.cout if u.bn else 0
+        elif u.kind == "head":
+            train += u.out.c * u.src.c + u.out.c
+    return train, state
+
+
+def conv_flops_per_image(builder):
+    """2*Ho*Wo*Cout*Cin*kh*kw summed over every conv (head convs included): SURVEY.md section 8d."""
+    total = 0
+    for u in builder.units:
+        if u.kind == "conv":
+            total += 2 * u.out.h * u.out.w * u.cout * u.src.c * u.k * u.k
+        elif u.kind == "head":
+            total += 2 * u.out.h * u.out.w * u.out.c * u.src.c
+    return total
+
+
 # --------------------------------------------------------------------------------------------
 # runtime
 # --------------------------------------------------------------------------------------------
