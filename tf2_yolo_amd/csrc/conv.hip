@@ -92,8 +92,17 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
   const int lrow = tid >> 3;
   const int kcol = (tid & 7) * 4;
 
+  // Buffer resources: an out-of-range offset makes the hardware return 0, which IS the zero padding
+  // (and the M / Cout tails) -- no select on the loaded value, so nothing forces the loads to be
+  // waited for before the MFMAs of the current slice have been issued.
+  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.src), 0, (unsigned)((long long)a.N * a.Hs * a.Ws * a.Cs * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wgt), 0, (unsigned)((long long)a.Cout * a.ldw * 4), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond any buffer (tensors are < 2^31 elements... < 4 GB)
+
   // Per-thread descriptors of the A rows it stages (fixed for the whole K loop).
-  int rowbase[AR];  // n*Hs
+  int rowel[AR];  // element offset of (n, y*sy, x*sx, 0) in src
   int ys0[AR], xs0[AR];
   const int HgWg = a.Hg * a.Wg;
 #pragma unroll
@@ -104,14 +113,20 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
       const int rem = (int)(m - (long long)n * HgWg);
       const int y = rem / a.Wg;
       const int x = rem - y * a.Wg;
-      rowbase[i] = n * a.Hs;
       ys0[i] = y * a.sy;
       xs0[i] = x * a.sx;
+      rowel[i] = ((n * a.Hs + ys0[i]) * a.Ws + xs0[i]) * a.Cs;
     } else {
-      rowbase[i] = 0;
+      rowel[i] = 0;
       ys0[i] = -(1 << 28);  // fails every bounds test
       xs0[i] = 0;
     }
+  }
+  int browel[BR];  // element offset of weight row co (or -1)
+#pragma unroll
+  for (int j = 0; j < BR; ++j) {
+    const int co = n0 + lrow + 32 * j;
+    browel[j] = (co < a.Cout) ? co * a.ldw : -1;
   }
 
   const int Ktot = a.ntaps * a.Cs;
@@ -125,22 +140,19 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
       const int tap = kt / cpt;
       const int c0 = (kt - tap * cpt) * BK;
       const int oy = a.taps[tap].oy, ox = a.taps[tap].ox, woff = a.taps[tap].woff;
+      const int tapel = (oy * a.Ws + ox) * a.Cs + c0 + kcol;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
         const int ys = ys0[i] + oy, xs = xs0[i] + ox;
         const bool ok = ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
-        const long long off = ((long long)(rowbase[i] + ys) * a.Ws + xs) * a.Cs + c0 + kcol;
-        const float* p = ok ? (a.src + off) : a.src;
-        f32x4 v = *reinterpret_cast<const f32x4*>(p);
-        ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned off = ok ? (unsigned)(rowel[i] + tapel) * 4u : OOB;
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
       }
+      const int wel = woff + c0 + kcol;
 #pragma unroll
       for (int j = 0; j < BR; ++j) {
-        const int co = n0 + lrow + 32 * j;
-        const bool ok = co < a.Cout;
-        const float* p = ok ? (a.wgt + (long long)co * a.ldw + woff + c0 + kcol) : a.wgt;
-        f32x4 v = *reinterpret_cast<const f32x4*>(p);
-        rb[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned off = (browel[j] >= 0) ? (unsigned)(browel[j] + wel) * 4u : OOB;
+        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0));
       }
     } else {
       const int kbase = kt * BK + kcol;
@@ -153,22 +165,18 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
         const int r = tap / a.kw;
         const int s = tap - r * a.kw;
         const int oy = r - a.pad_t, ox = s - a.pad_l;
+        const int tapel = (oy * a.Ws + ox) * a.Cs + c;
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
           const int ys = ys0[i] + oy, xs = xs0[i] + ox;
           const bool ok = kok && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
-          const long long off = ((long long)(rowbase[i] + ys) * a.Ws + xs) * a.Cs + c;
-          const float* p = ok ? (a.src + off) : a.src;
-          const float v = *p;
-          ra[i][e] = ok ? v : 0.f;
+          const unsigned off = ok ? (unsigned)(rowel[i] + tapel) * 4u : OOB;
+          ra[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcA, off, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
-          const int co = n0 + lrow + 32 * j;
-          const bool ok = kok && (co < a.Cout);
-          const float* p = ok ? (a.wgt + (long long)co * a.ldw + k) : a.wgt;
-          const float v = *p;
-          rb[j][e] = ok ? v : 0.f;
+          const unsigned off = (kok && browel[j] >= 0) ? (unsigned)(browel[j] + k) * 4u : OOB;
+          rb[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcB, off, 0, 0));
         }
       }
     }
@@ -306,8 +314,10 @@ static int validate_desc(const yolo_conv_desc* d) {
   // every output pixel's window must start inside the (virtually) padded input
   YOLO_REQUIRE((long long)(d->Ho - 1) * d->sh - d->pad_t < d->H && (long long)(d->Wo - 1) * d->sw - d->pad_l < d->W,
                "conv: output %dx%d too large for input %dx%d", d->Ho, d->Wo, d->H, d->W);
-  YOLO_REQUIRE((long long)d->N * d->H * d->W * d->Cin < (1LL << 31) &&
-               (long long)d->N * d->Ho * d->Wo * d->Cout < (1LL << 31), "conv: tensor too large");
+  // 32-bit byte offsets in the buffer loads: every tensor must stay below 4 GB
+  YOLO_REQUIRE((long long)d->N * d->H * d->W * d->Cin < (1LL << 30) &&
+               (long long)d->N * d->Ho * d->Wo * d->Cout < (1LL << 30) &&
+               (long long)d->Cout * d->kh * d->kw * d->Cin < (1LL << 30), "conv: tensor too large (>= 4 GB)");
   return YOLO_OK;
 }
 
@@ -379,6 +389,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int HgWg = a.Hg * a.Wg;
   const int Ktot = a.ntaps * a.Cs;
 
+  // buffer resources: out-of-range offsets read as 0 (pixel tail, channel tails, zero padding)
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)(a.M * a.Cout * 4), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(a.src), 0, (unsigned)((long long)a.N * a.Hs * a.Ws * a.Cs * 4), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
   f32x4 ra[AP], rb[BP];
 
   auto load_slice = [&](int kt) {
@@ -389,16 +406,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       const bool pok = p < p_end;
       if constexpr (!ASCALAR) {
         const bool ok = pok && (co0 + a_col < a.Cout);
-        const float* ptr = ok ? (a.dy + p * a.Cout + co0 + a_col) : a.dy;
-        f32x4 v = *reinterpret_cast<const f32x4*>(ptr);
-        ra[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned off = ok ? (unsigned)(p * a.Cout + co0 + a_col) * 4u : OOB;
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool ok = pok && (co0 + a_col + e < a.Cout);
-          const float* ptr = ok ? (a.dy + p * a.Cout + co0 + a_col + e) : a.dy;
-          const float v = *ptr;
-          ra[i][e] = ok ? v : 0.f;
+          const unsigned off = ok ? (unsigned)(p * a.Cout + co0 + a_col + e) * 4u : OOB;
+          ra[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcA, off, 0, 0));
         }
       }
     }
@@ -415,10 +430,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int ys = y * a.sy + oy, xs = x * a.sx + ox;
         const bool ok = pok && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws) &&
                         (ci0 + b_col < a.Cs);
-        const long long off = ((long long)(n * a.Hs + ys) * a.Ws + xs) * a.Cs + ci0 + b_col;
-        const float* ptr = ok ? (a.src + off) : a.src;
-        f32x4 v = *reinterpret_cast<const f32x4*>(ptr);
-        rb[i] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        const unsigned off = ok ? (unsigned)(((n * a.Hs + ys) * a.Ws + xs) * a.Cs + ci0 + b_col) * 4u : OOB;
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0));
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -430,10 +443,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
           const int s = t - r * a.kw;
           const int ys = y * a.sy + r - a.pad_t, xs = x * a.sx + s - a.pad_l;
           const bool ok = pok && jok && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
-          const long long off = ((long long)(n * a.Hs + ys) * a.Ws + xs) * a.Cs + c;
-          const float* ptr = ok ? (a.src + off) : a.src;
-          const float v = *ptr;
-          rb[i][e] = ok ? v : 0.f;
+          const unsigned off = ok ? (unsigned)(((n * a.Hs + ys) * a.Ws + xs) * a.Cs + c) * 4u : OOB;
+          rb[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcB, off, 0, 0));
         }
       }
     }
