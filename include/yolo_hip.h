@@ -67,8 +67,12 @@ typedef struct yolo_conv_desc {
   int pad_t, pad_l;      /* implicit zero padding top / left        */
 } yolo_conv_desc;
 
-/* y = conv(x, w) (+ bias if bias != NULL). If stats != NULL (double[2*Cout], zeroed by the
- * caller) the epilogue also accumulates per-channel sum / sum-of-squares of y for
+/* BatchNorm statistics buffers hold YOLO_BN_STAT_SLOTS replicas of [2*C] doubles (sum, sum of
+ * squares); producers spread their atomics over the replicas, yolo_bn_finalize adds them up. */
+#define YOLO_BN_STAT_SLOTS 64
+
+/* y = conv(x, w) (+ bias if bias != NULL). If stats != NULL (double[YOLO_BN_STAT_SLOTS][2*Cout],
+ * zeroed by the caller) the epilogue also accumulates per-channel sum / sum-of-squares of y for
  * training-mode BatchNormalization (yolov3/models/backbone.py:54). */
 int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const float* w,
                     const float* bias, float* y, double* stats, void* stream);
@@ -97,15 +101,16 @@ int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin
  * eps = 1e-3, momentum = 0.99 are the Keras defaults used by the reference.
  * ------------------------------------------------------------------------------------ */
 
-/* per-channel sum / sum-of-squares of x[P,C] into stats (double[2*C], caller-zeroed).
- * Only needed when the producing conv did not fuse the statistics. */
+/* per-channel sum / sum-of-squares of x[P,C] into replica 0 of stats
+ * (double[YOLO_BN_STAT_SLOTS][2*C], caller-zeroed). Only needed when the producing conv did not
+ * fuse the statistics. */
 int yolo_bn_stats(const float* x, long long P, int C, double* stats, void* stream);
 
 /* From stats: mean, biased var; writes scale = gamma/sqrt(var+eps), shift = beta - mean*scale,
  * saves mean / invstd for backward, updates the moving statistics
  *   moving = momentum*moving + (1-momentum)*batch   (variance fed: biased if
  *   unbiased_moving_var == 0, Bessel-corrected otherwise)
- * and zeroes `stats` for the next step. */
+ * `stats` is read (all replicas summed), not modified. */
 int yolo_bn_finalize(double* stats, long long P, int C, const float* gamma, const float* beta,
                      float eps, float momentum, int unbiased_moving_var,
                      float* moving_mean, float* moving_var,

@@ -102,3 +102,19 @@ def test_conv_rejects_bad_descriptor():
     w = torch.zeros(32, 3, 3, 32, device="cuda")
     with pytest.raises(YoloHipError):
         ops.conv2d_fwd(d, x, w)
+
+
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[4], CASES[5], CASES[8]])
+def test_conv_fused_bn_statistics(case):
+    """epilogue-fused per-channel sum / sum of squares (training-mode BN) vs the oracle's conv output"""
+    from tf2_yolo_amd import ops
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=5)
+    ref = L.conv2d(x, wk, b, stride=s, padding=pad).reshape(-1, cout)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    stats = torch.zeros(ops.BN_STAT_SLOTS * 2 * cout, device="cuda", dtype=torch.float64)
+    ops.conv2d_fwd(d, x.float().cuda(), _krsc(wk).float().cuda(), None if b is None else b.float().cuda(), stats=stats)
+    torch.cuda.synchronize()
+    got = stats.cpu().reshape(ops.BN_STAT_SLOTS, 2, cout).sum(0)
+    assert _relerr(got[0], ref.sum(0)) < 1e-5 * max(1.0, (ref.abs().sum(0).max() / ref.sum(0).abs().max()).item())
+    assert _relerr(got[1], (ref * ref).sum(0)) < 1e-5

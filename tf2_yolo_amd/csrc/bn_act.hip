@@ -72,14 +72,22 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   const bool active = (row_lane < rpp) && (c4 < C4);
   double v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   if (active) {
-    for (long long p = (long long)blockIdx.x * rpp + row_lane; p < P; p += (long long)gridDim.x * rpp) {
-      const f32x4 t = *reinterpret_cast<const f32x4*>(x + p * C + c4 * 4);
+    const long long stride = (long long)gridDim.x * rpp;
+    for (long long p = (long long)blockIdx.x * rpp + row_lane; p < P; p += 4 * stride) {
+      f32x4 t[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const double d = (double)t[e];
-        v[0][e] += d;
-        v[1][e] += d * d;
+      for (int u = 0; u < 4; ++u) {
+        const long long pu = p + u * stride;
+        t[u] = (pu < P) ? *reinterpret_cast<const f32x4*>(x + pu * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const double d = (double)t[u][e];
+          v[0][e] += d;
+          v[1][e] += d * d;
+        }
     }
   }
   block_col_reduce<2>(v, cw, rpp, row_lane, col, active, smem, stats, C, c4);
@@ -92,8 +100,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
                                    float* __restrict__ sinv) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = stats[c] / (double)P;
-  double var = stats[C + c] / (double)P - mean * mean;
+  double s1 = 0.0, s2 = 0.0;
+  for (int r = 0; r < YOLO_BN_STAT_SLOTS; ++r) {
+    s1 += stats[(long long)r * 2 * C + c];
+    s2 += stats[(long long)r * 2 * C + C + c];
+  }
+  const double mean = s1 / (double)P;
+  double var = s2 / (double)P - mean * mean;
   if (var < 0.0) var = 0.0;
   const double inv = 1.0 / sqrt(var + (double)eps);
   const float sc = (float)((double)gamma[c] * inv);
@@ -159,17 +172,26 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
     const f32x4 mu = reinterpret_cast<const f32x4*>(smean)[c4];
     const f32x4 iv = reinterpret_cast<const f32x4*>(sinv)[c4];
-    for (long long p = (long long)blockIdx.x * rpp + row_lane; p < P; p += (long long)gridDim.x * rpp) {
-      const f32x4 xv = *reinterpret_cast<const f32x4*>(x + p * C + c4 * 4);
-      const f32x4 dv = *reinterpret_cast<const f32x4*>(dout + p * C + c4 * 4);
+    const long long stride = (long long)gridDim.x * rpp;
+    for (long long p = (long long)blockIdx.x * rpp + row_lane; p < P; p += 4 * stride) {
+      f32x4 xv[4], dv[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float z = fmaf(sc[e], xv[e], sh[e]);
-        const float dz = dv[e] * act_grad(z, act);
-        const float xh = (xv[e] - mu[e]) * iv[e];
-        v[0][e] += (double)dz;
-        v[1][e] += (double)dz * (double)xh;
+      for (int u = 0; u < 4; ++u) {
+        const long long pu = p + u * stride;
+        const bool ok = pu < P;
+        xv[u] = ok ? *reinterpret_cast<const f32x4*>(x + pu * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[u] = ok ? *reinterpret_cast<const f32x4*>(dout + pu * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float z = fmaf(sc[e], xv[u][e], sh[e]);
+          const float dz = dv[u][e] * act_grad(z, act);   // dv = 0 for out-of-range rows
+          const float xh = (xv[u][e] - mu[e]) * iv[e];
+          v[0][e] += (double)dz;
+          v[1][e] += (double)dz * (double)xh;
+        }
     }
   }
   block_col_reduce<2>(v, cw, rpp, row_lane, col, active, smem, red, C, c4);
@@ -224,8 +246,8 @@ __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restr
 }
 
 static int reduce_grid_x(long long P, int rpp) {
-  long long g = (P + (long long)rpp * 64 - 1) / ((long long)rpp * 64);  // >= 64 rows per thread
-  if (g > 512) g = 512;
+  long long g = (P + (long long)rpp * 32 - 1) / ((long long)rpp * 32);  // >= 32 rows per thread
+  if (g > 1024) g = 1024;
   if (g < 1) g = 1;
   return (int)g;
 }

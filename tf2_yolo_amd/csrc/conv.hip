@@ -40,6 +40,7 @@ struct GatherConvArgs {
   const float* wgt;
   const float* bias;
   float* dst;
+  double* stats;  // optional [YOLO_BN_STAT_SLOTS][2*Cout]: per-channel sum / sum of squares of dst
   long long M;  // N*Hg*Wg
   int N, Hs, Ws, Cs;
   int Hg, Wg;
@@ -250,11 +251,17 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
   }
   __syncthreads();
 
+  // BatchNorm statistics fused into the epilogue: per-column partial sums over this block's rows
+  // (fp32 over <= 128 rows), combined across the waves that share the columns through LDS, then ONE
+  // fp64 atomic per column per block into one of YOLO_BN_STAT_SLOTS replicas (spreads contention).
+  float* sred = smem + 2 * BM;  // after the row-offset table (BM long longs)
+  float csum[TN], csq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
     const bool cok = col < a.Cout;
     const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -265,7 +272,38 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
           float v = acc[i][j][r] + bv;
           if (a.accumulate) v += a.dst[off + col];
           a.dst[off + col] = v;
+          s1 += v;
+          s2 += v * v;
         }
+      }
+    }
+    csum[j] = s1;
+    csq[j] = s2;
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
+      const float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (lane < 32) {
+        const int c = (wn * TN + j) * 32 + lane;  // column within the block tile
+        sred[(wm * BN + c) * 2 + 0] = s1;
+        sred[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += 256) {
+      const int col = n0 + c;
+      if (col < a.Cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) {
+          s1 += sred[(w * BN + c) * 2 + 0];
+          s2 += sred[(w * BN + c) * 2 + 1];
+        }
+        double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
+        atomicAdd(&slot[col], (double)s1);
+        atomicAdd(&slot[a.Cout + col], (double)s2);
       }
     }
   }
@@ -322,12 +360,16 @@ static int validate_desc(const yolo_conv_desc* d) {
 }
 
 // ---------------------------------------------------------------------------------------
-// wgrad: dW[co][t][ci] += sum_p dy[p][co] * src[p -> tap t][ci].
-// GEMM view: rows = co (A operand, from dy), cols = ci within one tap (B operand, gathered
-// from src), contraction over pixels p, split over blocks (grid.y) and combined with fp32
-// atomics (one 128-B segment per lane-half per store, the full-rate shape).
-// Both operands arrive pixel-major, so the LDS images are [32 pixels][BM|BN] and the
-// fragments are ds_read_b32 with consecutive lanes on consecutive banks.
+// wgrad: dW[co][j] += sum_p dy[p][co] * src[p -> tap(j)][c(j)],   j = tap*Cin + c  (KRSC row of a filter)
+// GEMM view: rows = co (A operand, from dy), cols = j over the FLATTENED (tap, ci) axis (B operand,
+// gathered from src), contraction over pixels p, split over blocks (grid.y) and combined with fp32
+// atomics (each lane-half writes one 128-B segment: the full-rate shape).
+// Flattening the columns means a block with BN = 128 covers 4 taps of a Cin = 32 layer: dy is read once
+// per column tile instead of once per tap, which is what the big-M / narrow-channel early layers need.
+// A thread's column (hence its tap offset) is fixed for the whole pixel loop.
+// Both operands arrive pixel-major, so the LDS images are [32 pixels][BM|BN] and the fragments are
+// ds_read_b32 with consecutive lanes on consecutive banks; fragments of k-step s+1 are fetched before
+// the MFMAs of step s are issued.
 // ---------------------------------------------------------------------------------------
 struct WgradArgs {
   const float* src;
@@ -339,25 +381,25 @@ struct WgradArgs {
   int sy, sx;
   int Cout, ldw;
   int ntaps;
-  int kw, pad_t, pad_l;  // BFLAT column decode
-  int tiles_co, tiles_ci;  // tiles_ci = column tiles per tap (or total in BFLAT)
-  long long chunk;         // pixels per split (multiple of 32)
-  Tap taps[MAX_TAPS];
+  int kw, pad_t, pad_l;
+  int tiles_co, tiles_j;
+  long long chunk;  // pixels per split (multiple of 32)
 };
 
-template <int BM, int BN, int WGM, int WGN, bool ASCALAR, bool BFLAT>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+template <int BM, int BN, int WGM, int WGN, bool ASCALAR, bool BSCALAR>
+__global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a) {
+  constexpr int NT = 64 * WGM * WGN;
   constexpr int BK = 32;
   constexpr int TM = BM / WGM / 32;
   constexpr int TN = BN / WGN / 32;
-  constexpr int AF4 = BM / 4;            // float4 per pixel row of A
-  constexpr int ARP = 256 / AF4;         // pixel rows per pass
-  constexpr int AP = (BK + ARP - 1) / ARP;
+  constexpr int AF4 = BM / 4;  // float4 per pixel row of A
+  constexpr int ARP = (NT / AF4) < BK ? (NT / AF4) : BK;  // pixel rows per pass
+  constexpr int AP = BK / ARP;
   constexpr int BF4 = BN / 4;
-  constexpr int BRP = 256 / BF4;
-  constexpr int BP = (BK + BRP - 1) / BRP;
-  static_assert(WGM * WGN == 4, "4 waves");
-  static_assert(ARP <= BK && BRP <= BK, "tile too narrow");
+  constexpr int BRP = (NT / BF4) < BK ? (NT / BF4) : BK;
+  constexpr int BP = BK / BRP;
+  static_assert(TM >= 1 && TN >= 1, "wave tile");
+  static_assert(AF4 <= NT && BF4 <= NT, "tile too wide for the block");
 
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int BUF = BK * (BM + BN);
@@ -366,17 +408,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int wm = wave / WGN, wn = wave % WGN;
 
   const int tile_co = blockIdx.x % a.tiles_co;
-  const int rest = blockIdx.x / a.tiles_co;
-  int tap = 0, ci0 = 0, oy = 0, ox = 0, woff = 0;
-  if constexpr (!BFLAT) {
-    tap = rest / a.tiles_ci;
-    ci0 = (rest - tap * a.tiles_ci) * BN;
-    oy = a.taps[tap].oy;
-    ox = a.taps[tap].ox;
-    woff = a.taps[tap].woff;
-  } else {
-    ci0 = rest * BN;  // flat column index j0 over ntaps*Cs
-  }
+  const int j0 = (blockIdx.x / a.tiles_co) * BN;
   const int co0 = tile_co * BM;
   const long long p_begin = (long long)blockIdx.y * a.chunk;
   long long p_end = p_begin + a.chunk;
@@ -386,15 +418,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 
   const int a_row = tid / AF4, a_col = (tid % AF4) * 4;
   const int b_row = tid / BF4, b_col = (tid % BF4) * 4;
+  const bool a_act = a_row < ARP;  // threads beyond the tile width idle in the staging passes
+  const bool b_act = b_row < BRP;
   const int HgWg = a.Hg * a.Wg;
   const int Ktot = a.ntaps * a.Cs;
 
-  // buffer resources: out-of-range offsets read as 0 (pixel tail, channel tails, zero padding)
   const __amdgpu_buffer_rsrc_t rsrcA =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)(a.M * a.Cout * 4), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(a.src), 0, (unsigned)((long long)a.N * a.Hs * a.Ws * a.Cs * 4), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  // this thread's B column(s): flattened j -> (tap, c); fixed for the whole pixel loop
+  int boy[BSCALAR ? 4 : 1], box[BSCALAR ? 4 : 1], bc[BSCALAR ? 4 : 1];
+  bool bok[BSCALAR ? 4 : 1];
+#pragma unroll
+  for (int e = 0; e < (BSCALAR ? 4 : 1); ++e) {
+    const int j = j0 + b_col + e;
+    bok[e] = j < Ktot;
+    const int t = bok[e] ? j / a.Cs : 0;
+    const int r = t / a.kw;
+    boy[e] = r - a.pad_t;
+    box[e] = (t - r * a.kw) - a.pad_l;
+    bc[e] = j - t * a.Cs;
+  }
+  const bool aok_col = co0 + a_col < a.Cout;
 
   f32x4 ra[AP], rb[BP];
 
@@ -403,10 +451,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const long long p = pbase + a_row + i * ARP;
-      const bool pok = p < p_end;
+      const bool pok = a_act && (p < p_end);
       if constexpr (!ASCALAR) {
-        const bool ok = pok && (co0 + a_col < a.Cout);
-        const unsigned off = ok ? (unsigned)(p * a.Cout + co0 + a_col) * 4u : OOB;
+        const unsigned off = (pok && aok_col) ? (unsigned)(p * a.Cout + co0 + a_col) * 4u : OOB;
         ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
       } else {
 #pragma unroll
@@ -420,30 +467,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       const long long p = pbase + b_row + i * BRP;
-      const bool pok = p < p_end;
+      const bool pok = b_act && (p < p_end);
       const long long pp = pok ? p : 0;
       const int n = (int)(pp / HgWg);
       const int rem = (int)(pp - (long long)n * HgWg);
       const int y = rem / a.Wg;
       const int x = rem - y * a.Wg;
-      if constexpr (!BFLAT) {
-        const int ys = y * a.sy + oy, xs = x * a.sx + ox;
-        const bool ok = pok && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws) &&
-                        (ci0 + b_col < a.Cs);
-        const unsigned off = ok ? (unsigned)(((n * a.Hs + ys) * a.Ws + xs) * a.Cs + ci0 + b_col) * 4u : OOB;
+      const int ybase = y * a.sy, xbase = x * a.sx;
+      if constexpr (!BSCALAR) {
+        const int ys = ybase + boy[0], xs = xbase + box[0];
+        const bool ok = pok && bok[0] && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
+        const unsigned off = ok ? (unsigned)(((n * a.Hs + ys) * a.Ws + xs) * a.Cs + bc[0]) * 4u : OOB;
         rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0));
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int j = ci0 + b_col + e;
-          const bool jok = j < Ktot;
-          const int t = jok ? j / a.Cs : 0;
-          const int c = j - t * a.Cs;
-          const int r = t / a.kw;
-          const int s = t - r * a.kw;
-          const int ys = y * a.sy + r - a.pad_t, xs = x * a.sx + s - a.pad_l;
-          const bool ok = pok && jok && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
-          const unsigned off = ok ? (unsigned)(((n * a.Hs + ys) * a.Ws + xs) * a.Cs + c) * 4u : OOB;
+          const int ys = ybase + boy[e], xs = xbase + box[e];
+          const bool ok = pok && bok[e] && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
+          const unsigned off = ok ? (unsigned)(((n * a.Hs + ys) * a.Ws + xs) * a.Cs + bc[e]) * 4u : OOB;
           rb[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcB, off, 0, 0));
         }
       }
@@ -453,15 +494,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   auto store_slice = [&](int buf) {
     float* sA = smem + buf * BUF;
     float* sB = sA + BK * BM;
+    if (a_act) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int r = a_row + i * ARP;
-      if (r < BK) *reinterpret_cast<f32x4*>(&sA[r * BM + a_col]) = ra[i];
+      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&sA[(a_row + i * ARP) * BM + a_col]) = ra[i];
     }
+    if (b_act) {
 #pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      const int r = b_row + i * BRP;
-      if (r < BK) *reinterpret_cast<f32x4*>(&sB[r * BN + b_col]) = rb[i];
+      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&sB[(b_row + i * BRP) * BN + b_col]) = rb[i];
     }
   };
 
@@ -484,18 +523,25 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     if (kt + 1 < nk) load_slice(kt + 1);
     const float* sA = smem + buf * BUF + fh * BM + wm * TM * 32 + fr;
     const float* sB = smem + buf * BUF + BK * BM + fh * BN + wn * TN * 32 + fr;
+    float af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = sA[i * 32];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = sB[j * 32];
 #pragma unroll
     for (int s = 0; s < BK / 2; ++s) {
-      float af[TM], bf[TN];
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < BK / 2) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = sA[2 * s * BM + i * 32];
+        for (int i = 0; i < TM; ++i) af[nxt][i] = sA[2 * (s + 1) * BM + i * 32];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = sB[2 * s * BN + j * 32];
+        for (int j = 0; j < TN; ++j) bf[nxt][j] = sB[2 * (s + 1) * BN + j * 32];
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
     }
     if (kt + 1 < nk) store_slice(buf ^ 1);
     __syncthreads();
@@ -503,30 +549,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int cj = ci0 + (wn * TN + j) * 32 + (lane & 31);
-    const bool cok = BFLAT ? (cj < Ktot) : (cj < a.Cs);
-    const int wcol = BFLAT ? cj : (woff + cj);
+    const int cj = j0 + (wn * TN + j) * 32 + (lane & 31);
+    const bool cok = cj < Ktot;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (cok && co < a.Cout) atomicAdd(&a.dw[(long long)co * a.ldw + wcol], acc[i][j][r]);
+        if (cok && co < a.Cout) atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[i][j][r]);
       }
     }
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, bool ASCALAR, bool BFLAT>
+template <int BM, int BN, int WGM, int WGN, bool ASCALAR, bool BSCALAR>
 static int launch_wgrad(WgradArgs& a, hipStream_t st) {
   a.tiles_co = (a.Cout + BM - 1) / BM;
-  const int cols = BFLAT ? a.ntaps * a.Cs : a.Cs;
-  a.tiles_ci = (cols + BN - 1) / BN;
-  const long long tiles = (long long)a.tiles_co * a.tiles_ci * (BFLAT ? 1 : a.ntaps);
-  // split the pixel contraction so that the grid has ~4 blocks per CU
-  long long splits = (1024 + tiles - 1) / tiles;
+  const int cols = a.ntaps * a.Cs;
+  a.tiles_j = (cols + BN - 1) / BN;
+  const long long tiles = (long long)a.tiles_co * a.tiles_j;
+  // split the pixel contraction so that the grid has ~4 workgroups of 256 threads per CU
+  constexpr int NT = 64 * WGM * WGN;
+  long long splits = (1024LL * (256 / NT) + tiles - 1) / tiles;
   const long long max_splits = (a.M + 255) / 256;  // at least 8 K-slices per block
   if (splits > max_splits) splits = max_splits;
+  if (splits > 65535) splits = 65535;
   if (splits < 1) splits = 1;
   long long chunk = (a.M + splits - 1) / splits;
   chunk = (chunk + 31) / 32 * 32;
@@ -537,20 +584,21 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st) {
     return YOLO_ERR_INVALID_ARG;
   }
   constexpr size_t lds = 2 * 32 * (BM + BN) * sizeof(float);
-  hipLaunchKernelGGL((wgrad_kernel<BM, BN, WGM, WGN, ASCALAR, BFLAT>), dim3((unsigned)tiles, (unsigned)splits),
-                     dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wgrad_kernel<BM, BN, WGM, WGN, ASCALAR, BSCALAR>), dim3((unsigned)tiles, (unsigned)splits),
+                     dim3(NT), lds, st, a);
   return check_launch("wgrad_kernel");
 }
 
-template <bool ASCALAR, bool BFLAT>
+template <bool ASCALAR, bool BSCALAR>
 static int dispatch_wgrad(WgradArgs& a, hipStream_t st) {
-  const int cols = BFLAT ? a.ntaps * a.Cs : a.Cs;
-  if (a.Cout <= 32) return launch_wgrad<32, 128, 1, 4, ASCALAR, BFLAT>(a, st);
-  if (cols <= 32) return launch_wgrad<128, 32, 4, 1, ASCALAR, BFLAT>(a, st);
-  if (a.Cout <= 64 && cols <= 64) return launch_wgrad<64, 64, 2, 2, ASCALAR, BFLAT>(a, st);
-  if (a.Cout <= 64) return launch_wgrad<64, 128, 2, 2, ASCALAR, BFLAT>(a, st);
-  if (cols <= 64) return launch_wgrad<128, 64, 2, 2, ASCALAR, BFLAT>(a, st);
-  return launch_wgrad<128, 128, 2, 2, ASCALAR, BFLAT>(a, st);
+  const int cols = a.ntaps * a.Cs;
+  if (a.Cout <= 32 && cols <= 32) return launch_wgrad<32, 32, 1, 1, ASCALAR, BSCALAR>(a, st);   // Cin = 3 stem
+  if (a.Cout <= 32) return launch_wgrad<32, 128, 1, 4, ASCALAR, BSCALAR>(a, st);
+  if (cols <= 32) return launch_wgrad<128, 32, 4, 1, ASCALAR, BSCALAR>(a, st);
+  if (a.Cout <= 64 && cols <= 64) return launch_wgrad<64, 64, 2, 2, ASCALAR, BSCALAR>(a, st);
+  if (a.Cout <= 64) return launch_wgrad<64, 128, 2, 2, ASCALAR, BSCALAR>(a, st);
+  if (cols <= 64) return launch_wgrad<128, 64, 2, 2, ASCALAR, BSCALAR>(a, st);
+  return launch_wgrad<128, 128, 2, 2, ASCALAR, BSCALAR>(a, st);
 }
 
 // wT[ci][t][co] = w[co][t][ci]
@@ -608,10 +656,9 @@ extern "C" int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const fl
   a.M = (long long)d->N * d->Ho * d->Wo;
   for (int r = 0; r < d->kh; ++r)
     for (int s = 0; s < d->kw; ++s) a.taps[r * d->kw + s] = Tap{r - d->pad_t, s - d->pad_l, (r * d->kw + s) * d->Cin};
+  a.stats = stats;
   const bool flat = (d->Cin % 32) != 0;
-  if (int rc = dispatch_gather(a, flat, as_stream(stream))) return rc;
-  if (stats != nullptr) return yolo_bn_stats(y, a.M, d->Cout, stats, stream);
-  return YOLO_OK;
+  return dispatch_gather(a, flat, as_stream(stream));
 }
 
 extern "C" int yolo_conv2d_dgrad(const yolo_conv_desc* d, const float* dy, const float* wT, float* dx, int accumulate,
@@ -685,8 +732,6 @@ extern "C" int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const 
   a.ntaps = d->kh * d->kw;
   a.kw = d->kw; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.M = (long long)d->N * d->Ho * d->Wo;
-  for (int r = 0; r < d->kh; ++r)
-    for (int s = 0; s < d->kw; ++s) a.taps[r * d->kw + s] = Tap{r - d->pad_t, s - d->pad_l, (r * d->kw + s) * d->Cin};
   const bool ascalar = (d->Cout % 4) != 0;
   const bool bflat = (d->Cin % 4) != 0;
   int rc;

@@ -14,6 +14,7 @@ from ._lib import ConvDesc, LossCfg, YoloHipError, check
 
 BN_EPS = 1e-3       # Keras BatchNormalization default
 BN_MOMENTUM = 0.99
+BN_STAT_SLOTS = 64  # YOLO_BN_STAT_SLOTS in include/yolo_hip.h
 
 
 class KernelTimer:
@@ -104,15 +105,15 @@ def conv2d_fwd(d, x, w, bias=None, out=None, stats=None):
         raise YoloHipError("conv2d_fwd: tensor sizes do not match the descriptor")
     if out.numel() != d.N * d.Ho * d.Wo * d.Cout:
         raise YoloHipError("conv2d_fwd: output size does not match the descriptor")
+    if stats is not None and stats.numel() != BN_STAT_SLOTS * 2 * d.Cout:
+        raise YoloHipError("conv2d_fwd: stats must hold BN_STAT_SLOTS x 2 x Cout doubles")
     def run():
-        check(_lib.load().yolo_conv2d_fwd(byref(d), _p(x), _p(w), _p(bias), _p(out), None, _stream()),
+        check(_lib.load().yolo_conv2d_fwd(byref(d), _p(x), _p(w), _p(bias), _p(out), _p(stats), _stream()),
               "yolo_conv2d_fwd")
     if TIMER is not None:
         TIMER.bracket(_gather_variant(d.Cout, d.Cin % 32 != 0), _conv_flops(d), 1, run)
     else:
         run()
-    if stats is not None:
-        bn_stats(out, d.Cout, stats)
     return out
 
 
