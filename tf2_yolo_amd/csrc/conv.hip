@@ -26,6 +26,7 @@
 // Double-buffered LDS, one barrier per slice, next slice's global loads in flight during
 // the 64 MFMAs (4096 cycles) of the current one.
 #include "common.hpp"
+#include <type_traits>
 
 namespace yolo {
 
@@ -96,10 +97,6 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
   // Buffer resources: an out-of-range offset makes the hardware return 0, which IS the zero padding
   // (and the M / Cout tails) -- no select on the loaded value, so nothing forces the loads to be
   // waited for before the MFMAs of the current slice have been issued.
-  const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.src), 0, (unsigned)((long long)a.N * a.Hs * a.Ws * a.Cs * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcB =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.wgt), 0, (unsigned)((long long)a.Cout * a.ldw * 4), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;  // byte offset beyond any buffer (tensors are < 2^31 elements... < 4 GB)
 
   // Per-thread descriptors of the A rows it stages (fixed for the whole K loop).
@@ -134,9 +131,18 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
   const int cpt = FLAT ? 1 : a.Cs / BK;                  // K slices per tap
   const int nk = FLAT ? (Ktot + BK - 1) / BK : a.ntaps * cpt;
 
-  f32x4 ra[AR], rb[BR];
+  // two staging register sets: while set S is being written to LDS (slice kt+1), the other one
+  // receives the global loads of slice kt+2 -- two slices of HBM/L2 latency cover, no extra LDS
+  f32x4 ra[2][AR], rb[2][BR];
 
-  auto load_slice = [&](int kt) {
+  auto load_slice = [&](int kt, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    // descriptors rebuilt from kernel arguments here so that they stay in SGPRs (a descriptor the
+    // compiler cannot prove wave-uniform is wrapped in a waterfall loop per load)
+    const __amdgpu_buffer_rsrc_t rsrcA = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.src), 0, (unsigned)((long long)a.N * a.Hs * a.Ws * a.Cs * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.wgt), 0, (unsigned)((long long)a.Cout * a.ldw * 4), 0x00020000);
     if constexpr (!FLAT) {
       const int tap = kt / cpt;
       const int c0 = (kt - tap * cpt) * BK;
@@ -147,13 +153,13 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
         const int ys = ys0[i] + oy, xs = xs0[i] + ox;
         const bool ok = ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
         const unsigned off = ok ? (unsigned)(rowel[i] + tapel) * 4u : OOB;
-        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
+        ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
       }
       const int wel = woff + c0 + kcol;
 #pragma unroll
       for (int j = 0; j < BR; ++j) {
         const unsigned off = (browel[j] >= 0) ? (unsigned)(browel[j] + wel) * 4u : OOB;
-        rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0));
+        rb[S][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0));
       }
     } else {
       const int kbase = kt * BK + kcol;
@@ -172,26 +178,30 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
           const int ys = ys0[i] + oy, xs = xs0[i] + ox;
           const bool ok = kok && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
           const unsigned off = ok ? (unsigned)(rowel[i] + tapel) * 4u : OOB;
-          ra[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcA, off, 0, 0));
+          ra[S][i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcA, off, 0, 0));
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
           const unsigned off = (kok && browel[j] >= 0) ? (unsigned)(browel[j] + k) * 4u : OOB;
-          rb[j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcB, off, 0, 0));
+          rb[S][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcB, off, 0, 0));
         }
       }
     }
   };
 
-  auto store_slice = [&](int buf) {
+  auto store_a = [&](int buf, auto SET) {
+    constexpr int S = decltype(SET)::value;
     float* sA = smem + buf * BUF;
-    float* sB = sA + BM * LD;
 #pragma unroll
     for (int i = 0; i < AR; ++i)
-      *reinterpret_cast<f32x4*>(&sA[(lrow + 32 * i) * LD + kcol]) = ra[i];
+      *reinterpret_cast<f32x4*>(&sA[(lrow + 32 * i) * LD + kcol]) = ra[S][i];
+  };
+  auto store_b = [&](int buf, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    float* sB = smem + buf * BUF + BM * LD;
 #pragma unroll
     for (int j = 0; j < BR; ++j)
-      *reinterpret_cast<f32x4*>(&sB[(lrow + 32 * j) * LD + kcol]) = rb[j];
+      *reinterpret_cast<f32x4*>(&sB[(lrow + 32 * j) * LD + kcol]) = rb[S][j];
   };
 
   f32x16 acc[TM][TN];
@@ -205,14 +215,15 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
   const int frag_row = lane & 31;
   const int frag_k = (lane >> 5) * 4;
 
-  load_slice(0);
-  store_slice(0);
-  __syncthreads();
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // one K slice: MFMAs on LDS buffer `buf`; interleaved with them, slice kt+2 starts loading into
+  // register set SL and slice kt+1 (register set SS, loaded one iteration ago) is written to the other
+  // LDS buffer, which every wave finished reading before the previous barrier.
+  auto slice = [&](int kt, auto SL, auto SS) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_slice(kt + 1);
-
+    if (kt + 2 < nk) load_slice(kt + 2, SL);
     const float* sA = smem + buf * BUF + (wm * TM * 32 + frag_row) * LD + frag_k;
     const float* sB = smem + buf * BUF + BM * LD + (wn * TN * 32 + frag_row) * LD + frag_k;
 #pragma unroll
@@ -229,10 +240,59 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      if (kt + 1 < nk) {
+        if (q == 1) store_a(buf ^ 1, SS);
+        if (q == 2) store_b(buf ^ 1, SS);
+      }
     }
-
-    if (kt + 1 < nk) store_slice(buf ^ 1);
     __syncthreads();
+  };
+
+  if constexpr (FLAT) {
+    // scalar-gather variant (Cin = 3 stem, 255-wide head gradient): short K, register-hungry loads ->
+    // classic one-set schedule (load slice kt+1 at the top, write it to LDS after the MFMAs)
+    load_slice(0, S0{});
+    store_a(0, S0{});
+    store_b(0, S0{});
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load_slice(kt + 1, S0{});
+      const float* sA = smem + buf * BUF + (wm * TM * 32 + frag_row) * LD + frag_k;
+      const float* sB = smem + buf * BUF + BM * LD + (wn * TN * 32 + frag_row) * LD + frag_k;
+#pragma unroll
+      for (int q = 0; q < BK / 8; ++q) {
+        f32x4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(sA + i * 32 * LD + q * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(sB + j * 32 * LD + q * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      }
+      if (kt + 1 < nk) {
+        store_a(buf ^ 1, S0{});
+        store_b(buf ^ 1, S0{});
+      }
+      __syncthreads();
+    }
+  } else {
+    load_slice(0, S0{});
+    store_a(0, S0{});
+    store_b(0, S0{});
+    if (nk > 1) load_slice(1, S1{});
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      slice(kt, S0{}, S1{});      // loads kt+2 -> set 0, stores set 1 (slice kt+1)
+      slice(kt + 1, S1{}, S0{});  // loads kt+3 -> set 1, stores set 0 (slice kt+2)
+    }
+    if (kt < nk) slice(kt, S0{}, S1{});
   }
 
   // Epilogue. Row -> destination offset table through LDS (the K loop is done with it).
