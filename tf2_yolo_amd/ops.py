@@ -51,9 +51,13 @@ def _conv_flops(d):
     return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.kh * d.kw * d.Cin
 
 
-def _gather_variant(cout, flat):
+def _gather_variant(cout, flat, m=None):
+    """mirrors dispatch_gather() in csrc/conv.hip (names used by bench.py's roofline report)"""
     bn = 32 if cout <= 32 else (64 if cout <= 64 else 128)
-    return f"gather_conv_kernel<128,{bn}{',flat' if flat else ''}>"
+    bm = 128
+    if bn == 128 and not flat and m is not None and ((m + 127) // 128) * ((cout + 127) // 128) <= 512:
+        bm = 64
+    return f"gather_conv_kernel<{bm},{bn}{',flat' if flat else ''}>"
 
 
 def _stream():
@@ -111,7 +115,7 @@ def conv2d_fwd(d, x, w, bias=None, out=None, stats=None):
         check(_lib.load().yolo_conv2d_fwd(byref(d), _p(x), _p(w), _p(bias), _p(out), _p(stats), _stream()),
               "yolo_conv2d_fwd")
     if TIMER is not None:
-        TIMER.bracket(_gather_variant(d.Cout, d.Cin % 32 != 0), _conv_flops(d), 1, run)
+        TIMER.bracket(_gather_variant(d.Cout, d.Cin % 32 != 0, d.N * d.Ho * d.Wo), _conv_flops(d), 1, run)
     else:
         run()
     return out
@@ -136,7 +140,7 @@ def conv2d_dgrad(d, dy, wT, dx=None, accumulate=False):
         check(_lib.load().yolo_conv2d_dgrad(byref(d), _p(dy), _p(wT), _p(dx), int(bool(accumulate)), _stream()),
               "yolo_conv2d_dgrad")
     if TIMER is not None:
-        TIMER.bracket(_gather_variant(d.Cin, d.Cout % 32 != 0), _conv_flops(d), d.sh * d.sw, run)
+        TIMER.bracket(_gather_variant(d.Cin, d.Cout % 32 != 0, d.N * (-(-d.H // d.sh)) * (-(-d.W // d.sw))), _conv_flops(d), d.sh * d.sw, run)
     else:
         run()
     return dx
