@@ -493,10 +493,6 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a
   const int HgWg = a.Hg * a.Wg;
   const int Ktot = a.ntaps * a.Cs;
 
-  const __amdgpu_buffer_rsrc_t rsrcA =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)(a.M * a.Cout * 4), 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(a.src), 0, (unsigned)((long long)a.N * a.Hs * a.Ws * a.Cs * 4), 0x00020000);
   constexpr unsigned OOB = 0xFFFFFFF0u;
 
   // this thread's B column(s): flattened j -> (tap, c); fixed for the whole pixel loop
@@ -514,9 +510,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a
   }
   const bool aok_col = co0 + a_col < a.Cout;
 
-  f32x4 ra[AP], rb[BP];
+  // pixel coordinates of this thread's B rows, advanced by BK per staged slice (slices are staged in
+  // order), so the per-slice integer divisions disappear from the loop
+  int pn[BP], py[BP], px[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const long long p = p_begin + b_row + i * BRP;
+    const long long pp = p < a.M ? p : 0;
+    pn[i] = (int)(pp / HgWg);
+    const int rem = (int)(pp - (long long)pn[i] * HgWg);
+    py[i] = rem / a.Wg;
+    px[i] = rem - py[i] * a.Wg;
+  }
 
-  auto load_slice = [&](int kt) {
+  f32x4 ra[2][AP], rb[2][BP];
+
+  auto load_slice = [&](int kt, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    const __amdgpu_buffer_rsrc_t rsrcA =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (unsigned)(a.M * a.Cout * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcB = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.src), 0, (unsigned)((long long)a.N * a.Hs * a.Ws * a.Cs * 4), 0x00020000);
     const long long pbase = p_begin + (long long)kt * BK;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
@@ -524,13 +538,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a
       const bool pok = a_act && (p < p_end);
       if constexpr (!ASCALAR) {
         const unsigned off = (pok && aok_col) ? (unsigned)(p * a.Cout + co0 + a_col) * 4u : OOB;
-        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
+        ra[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcA, off, 0, 0));
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool ok = pok && (co0 + a_col + e < a.Cout);
           const unsigned off = ok ? (unsigned)(p * a.Cout + co0 + a_col + e) * 4u : OOB;
-          ra[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcA, off, 0, 0));
+          ra[S][i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcA, off, 0, 0));
         }
       }
     }
@@ -538,39 +552,52 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a
     for (int i = 0; i < BP; ++i) {
       const long long p = pbase + b_row + i * BRP;
       const bool pok = b_act && (p < p_end);
-      const long long pp = pok ? p : 0;
-      const int n = (int)(pp / HgWg);
-      const int rem = (int)(pp - (long long)n * HgWg);
-      const int y = rem / a.Wg;
-      const int x = rem - y * a.Wg;
+      const int n = pn[i], y = py[i], x = px[i];
       const int ybase = y * a.sy, xbase = x * a.sx;
       if constexpr (!BSCALAR) {
         const int ys = ybase + boy[0], xs = xbase + box[0];
         const bool ok = pok && bok[0] && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
         const unsigned off = ok ? (unsigned)(((n * a.Hs + ys) * a.Ws + xs) * a.Cs + bc[0]) * 4u : OOB;
-        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0));
+        rb[S][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrcB, off, 0, 0));
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int ys = ybase + boy[e], xs = xbase + box[e];
           const bool ok = pok && bok[e] && ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
           const unsigned off = ok ? (unsigned)(((n * a.Hs + ys) * a.Ws + xs) * a.Cs + bc[e]) * 4u : OOB;
-          rb[i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcB, off, 0, 0));
+          rb[S][i][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrcB, off, 0, 0));
         }
       }
+      // advance this row's pixel by BK for the next staged slice
+      int nx = x + BK, ny = y, nn = n;
+      while (nx >= a.Wg) {
+        nx -= a.Wg;
+        ++ny;
+      }
+      while (ny >= a.Hg) {
+        ny -= a.Hg;
+        ++nn;
+      }
+      px[i] = nx;
+      py[i] = ny;
+      pn[i] = nn;
     }
   };
 
-  auto store_slice = [&](int buf) {
+  auto store_a = [&](int buf, auto SET) {
+    constexpr int S = decltype(SET)::value;
     float* sA = smem + buf * BUF;
-    float* sB = sA + BK * BM;
     if (a_act) {
 #pragma unroll
-      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&sA[(a_row + i * ARP) * BM + a_col]) = ra[i];
+      for (int i = 0; i < AP; ++i) *reinterpret_cast<f32x4*>(&sA[(a_row + i * ARP) * BM + a_col]) = ra[S][i];
     }
+  };
+  auto store_b = [&](int buf, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    float* sB = smem + buf * BUF + BK * BM;
     if (b_act) {
 #pragma unroll
-      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&sB[(b_row + i * BRP) * BN + b_col]) = rb[i];
+      for (int i = 0; i < BP; ++i) *reinterpret_cast<f32x4*>(&sB[(b_row + i * BRP) * BN + b_col]) = rb[S][i];
     }
   };
 
@@ -584,13 +611,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a
 
   const int fr = lane & 31, fh = lane >> 5;
 
-  load_slice(0);
-  store_slice(0);
-  __syncthreads();
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
-  for (int kt = 0; kt < nk; ++kt) {
+  // same two-set schedule as gather_conv_kernel: slice kt+2 is loading into set SL while slice kt+1
+  // (set SS) is written to the other LDS buffer in the middle of slice kt's MFMAs
+  // the scalar-gather variants (Cin = 3 stem, 255-wide heads) are register-hungry and short: they keep
+  // the classic one-set schedule (load slice kt+1 at the top, write it after the MFMAs)
+  constexpr bool DEEP = !(ASCALAR || BSCALAR);
+  auto slice = [&](int kt, auto SL, auto SS) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) load_slice(kt + 1);
+    if constexpr (DEEP) {
+      if (kt + 2 < nk) load_slice(kt + 2, SL);
+    } else {
+      if (kt + 1 < nk) load_slice(kt + 1, SS);
+    }
     const float* sA = smem + buf * BUF + fh * BM + wm * TM * 32 + fr;
     const float* sB = smem + buf * BUF + BK * BM + fh * BN + wn * TN * 32 + fr;
     float af[2][TM], bf[2][TN];
@@ -612,9 +647,30 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i], bf[cur][j], acc[i][j], 0, 0, 0);
+      if (kt + 1 < nk) {
+        if (s == (DEEP ? 5 : BK / 2 - 1)) store_a(buf ^ 1, SS);
+        if (s == (DEEP ? 10 : BK / 2 - 1)) store_b(buf ^ 1, SS);
+      }
     }
-    if (kt + 1 < nk) store_slice(buf ^ 1);
     __syncthreads();
+  };
+
+  load_slice(0, S0{});
+  store_a(0, S0{});
+  store_b(0, S0{});
+  if constexpr (DEEP) {
+    if (nk > 1) load_slice(1, S1{});
+  }
+  __syncthreads();
+  if constexpr (DEEP) {
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      slice(kt, S0{}, S1{});
+      slice(kt + 1, S1{}, S0{});
+    }
+    if (kt < nk) slice(kt, S0{}, S1{});
+  } else {
+    for (int kt = 0; kt < nk; ++kt) slice(kt, S0{}, S0{});
   }
 
 #pragma unroll
