@@ -30,6 +30,26 @@ HW = 416
 CLASSES = 80
 
 
+def hbm_traffic_from_profile(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (bench.py cannot collect
+    PMC itself; FETCH_SIZE and WRITE_SIZE need separate passes). None if no profile is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    prof = json.load(open(path))["kernels"]
+    base, _, rest = kernel.partition("<")
+    dims = rest.rstrip(">").split(",")
+    flat = "true" if "flat" in dims else "false"
+    for name, v in prof.items():
+        if name.startswith(f"{base}<{dims[0]},{dims[1]},") and (base != "gather_conv_kernel" or name.endswith(f",{flat}>")):
+            return v["hbm_bytes_per_launch"]
+    if base == "wgrad_kernel":   # bench aggregates every wgrad tile shape; the profile has one entry per shape
+        tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in prof.items() if n.startswith("wgrad_kernel"))
+        cnt = sum(v["launches"] for n, v in prof.items() if n.startswith("wgrad_kernel"))
+        return int(tot / cnt) if cnt else None
+    return None
+
+
 def cpu_baseline(threads):
     """Bounded sample of the SAME workload on the host CPU: one training step (forward, loss,
     autograd backward) of the torch-CPU restatement of the reference graph at batch 16, fp32 (~10 s)."""
@@ -146,7 +166,10 @@ def main():
             name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
             achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
             roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic": hbm_traffic_from_profile(name),
+                    "traffic_source": "profiles/r01_c_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                      "passes, gfx950 x2 FETCH correction), bytes per launch",
                     "launches": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
                     "flops_per_launch": a["flops"] / a["launches"],
                     "all_conv_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
