@@ -40,9 +40,10 @@ def hbm_traffic_from_profile(kernel):
     base, _, rest = kernel.partition("<")
     dims = rest.rstrip(">").split(",")
     flat = "true" if "flat" in dims else "false"
-    for name, v in prof.items():
-        if name.startswith(f"{base}<{dims[0]},{dims[1]},") and (base != "gather_conv_kernel" or name.endswith(f",{flat}>")):
-            return v["hbm_bytes_per_launch"]
+    if base == "gather_conv_kernel" and len(dims) >= 2:
+        for name, v in prof.items():
+            if name.startswith(f"{base}<{dims[0]},{dims[1]},") and name.endswith(f",{flat}>"):
+                return v["hbm_bytes_per_launch"]
     if base == "wgrad_kernel":   # bench aggregates every wgrad tile shape; the profile has one entry per shape
         tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in prof.items() if n.startswith("wgrad_kernel"))
         cnt = sum(v["launches"] for n, v in prof.items() if n.startswith("wgrad_kernel"))
