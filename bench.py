@@ -108,11 +108,19 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
                          f"(WORLD_SIZE={world})")
-    torch.cuda.set_device(local_rank)
+    # YOLO_BENCH_SINGLE_DEVICE=1 + YOLO_DIST_BACKEND=gloo: rehearse the N > 1 code path (buckets, side
+    # stream, events, 1/world) with several ranks on ONE GPU; the real runs use RCCL, one rank per GPU
+    single_dev = os.environ.get("YOLO_BENCH_SINGLE_DEVICE") == "1"
+    backend = os.environ.get("YOLO_DIST_BACKEND", "nccl")
+    dev_index = 0 if single_dev else local_rank
+    torch.cuda.set_device(dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import yolov3
     from tf2_yolo_amd import labels, ops, optimizers
@@ -136,6 +144,7 @@ def main():
     log(f"model built: {model.trainable_count()} trainable params; data ready")
 
     def barrier():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -159,6 +168,16 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+
+    dp_in_sync = None
+    if world > 1:   # outside the timed region: every replica must hold bit-identical weights after K steps
+        chk = model.net.params.data.double().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        if backend != "nccl":
+            lo, hi = lo.cpu(), hi.cpu()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dp_in_sync = bool(lo.item() == hi.item())
 
     if rank == 0:
         roof = None
@@ -184,7 +203,7 @@ def main():
                                       "forward (batch-stat BN) + 3 fused loss/grad kernels + backward + "
                                       "gradient all-reduce + Adam",
                           "global_batch": world * args.batch, "per_gpu_batch": args.batch,
-                          "parallelism": f"dp{world}", "loss": round(loss_val, 4)},
+                          "parallelism": f"dp{world}", "loss": round(loss_val, 4), "replicas_in_sync": dp_in_sync},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (bounded sample) ...")

@@ -1,0 +1,98 @@
+"""The README's 6-step flow on the Keras-like shell (README.md:207-336 of the reference): compile with
+loss + metrics, fit on arrays and on a Sequence-like, evaluate, predict, decode + nms."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+A9 = [[0.89663461, 0.78365384], [0.375, 0.47596153], [0.27884615, 0.21634615], [0.14182692, 0.28605769],
+      [0.14903846, 0.10817307], [0.07211538, 0.14663461], [0.07932692, 0.05528846], [0.03846153, 0.07211538],
+      [0.02403846, 0.03125]]
+
+
+class _Seq:
+    def __init__(self, x, ys, bs):
+        self.x, self.ys, self.bs = x, ys, bs
+
+    def __len__(self):
+        return len(self.x) // self.bs
+
+    def __getitem__(self, i):
+        sl = slice(i * self.bs, (i + 1) * self.bs)
+        return self.x[sl], [y[sl] for y in self.ys]
+
+
+def test_readme_flow_v3():
+    import yolov3
+    from utils import tools
+    from tf2_yolo_amd import labels
+    from tf2_yolo_amd.optimizers import Adam
+    yolo = yolov3.Yolo((64, 64, 3), ["a", "b"])
+    yolo.create_model(anchors=A9, pretrained_body=None)
+    rng = np.random.default_rng(0)
+    x, ys = labels.synthetic_batch(rng, 8, (64, 64), 2)
+    bw = [labels.get_class_weight(y[..., 4:5], "binary")[0] for y in ys]
+    yolo.model.compile(optimizer=Adam(lr=1e-3), loss=yolo.loss(bw), metrics=yolo.metrics("obj+iou+recall0.5"))
+    h = yolo.model.fit(x, ys, batch_size=4, epochs=3, verbose=0)
+    losses = h.history["loss"]
+    assert len(losses) == 3 and np.isfinite(losses).all() and losses[-1] < losses[0]
+    yolo.model.fit(_Seq(x, ys, 4), epochs=1, verbose=0)
+    ev = yolo.model.evaluate(x, ys, batch_size=4, verbose=0)
+    # total, 3 level losses, 3x3 metrics. (After a dozen steps the moving statistics are still ~90 % their
+    # initial 0/1 (momentum 0.99), so inference-mode losses of this random net may overflow, in Keras too;
+    # the metrics are ratios of counts and must be proper fractions.)
+    assert len(ev) == 1 + 3 + 9
+    pred = yolo.model.predict(x, batch_size=4)
+    assert [p.shape for p in pred] == [(8, 2, 2, 21), (8, 4, 4, 21), (8, 8, 8, 21)]
+    boxes = tools.decode(pred[2][0], pred[1][0], pred[0][0], class_num=2, threshold=0.3, version=3)
+    if boxes.size:
+        kept = tools.nms(boxes, class_num=2, nms_threshold=0.5)
+        assert kept.shape[1] == 7 and len(kept) <= len(boxes)
+    # metric closures are callable like tf.keras metrics and agree with the evaluate() aggregation order
+    m = yolo.metrics("obj+iou+class+recall0.6")
+    assert [f.kind for f in m[0]] == ["obj_acc", "mean_iou", "class_acc", "recall"] and m[0][3].iou_threshold == 0.6
+    out = yolo.model(x[:4], training=True)           # batch-statistics forward: well-scaled predictions
+    v = float(m[2][0](ys[2][:4], out[2]))
+    assert 0.0 <= v <= 1.0
+    # loss closure call == fused kernel loss
+    lf = yolo.loss()[0]
+    a = float(lf(ys[0][:4], out[0]))
+    b = float(lf.fwd_bwd(ys[0][:4], out[0])[0][0])
+    assert abs(a - b) <= 1e-5 * max(1.0, abs(b))
+
+
+@pytest.mark.parametrize("ver", [2, 1, 4])
+def test_train_steps_reduce_loss(ver):
+    from tf2_yolo_amd import labels
+    from tf2_yolo_amd.optimizers import Adam
+    rng = np.random.default_rng(ver)
+    if ver == 2:
+        import yolov2
+        y = yolov2.Yolo((64, 64, 3), ["a", "b", "c"])
+        y.create_model()
+        x, ys = labels.synthetic_batch(rng, 4, (64, 64), 3, levels=1, finest_stride=32)
+        loss, lab = y.loss(), ys[0]
+    elif ver == 1:
+        import yolov1_5
+        y = yolov1_5.Yolo((128, 128, 3), ["a"])
+        y.create_model()
+        x, ys = labels.synthetic_batch(rng, 4, (128, 128), 1, levels=1, finest_stride=64)
+        loss, lab = y.loss(binary_weight=0.5), ys[0]
+    else:
+        import yolov4
+        y = yolov4.Yolo((64, 64, 3), ["a", "b"])
+        y.create_model(anchors=A9, pretrained_body=None)
+        x, ys = labels.synthetic_batch(rng, 4, (64, 64), 2)
+        loss, lab = y.loss(), ys
+        assert np.allclose(np.array(y.anchors), np.array(A9), atol=1e-7)
+        y.reshape_anchors((128, 128))
+        assert np.allclose(np.array(y.anchors), 2 * np.array(A9), atol=1e-6)
+        y.anchors = A9
+    y.model.compile(optimizer=Adam(learning_rate=1e-3), loss=loss)
+    first = y.model.train_on_batch(x, lab)
+    for _ in range(6):
+        last = y.model.train_on_batch(x, lab)
+    first = first[0] if isinstance(first, list) else first
+    last = last[0] if isinstance(last, list) else last
+    assert np.isfinite(last) and last < first
