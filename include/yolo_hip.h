@@ -101,7 +101,7 @@ int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin
  * eps = 1e-3, momentum = 0.99 are the Keras defaults used by the reference.
  * ------------------------------------------------------------------------------------ */
 
-/* per-channel sum / sum-of-squares of x[P,C] into replica 0 of stats
+/* per-channel sum / sum-of-squares of x[P,C] spread over the replicas of stats
  * (double[YOLO_BN_STAT_SLOTS][2*C], caller-zeroed). Only needed when the producing conv did not
  * fuse the statistics. */
 int yolo_bn_stats(const float* x, long long P, int C, double* stats, void* stream);
@@ -128,7 +128,8 @@ int yolo_bn_act_fwd(const float* x, long long P, int C, const float* scale, cons
 
 /* Backward of out = act(BN_train(x)) given dout = dL/dout (the residual branch, if any,
  * receives dout unchanged and is handled by the caller).
- *   pass 1 (reduce): dgamma/dbeta partial sums -> red (double[2*C], caller-zeroed)
+ *   pass 1 (reduce): dgamma/dbeta partial sums -> red (double[(YOLO_BN_STAT_SLOTS+1)*2*C], caller-zeroed:
+ *                    SLOTS atomic replicas followed by their sum)
  *   pass 2 (apply) : dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma, dbeta
  *                    are ACCUMULATED (+=) into the flat gradient buffer.
  * dx may alias dout. */

@@ -34,7 +34,7 @@ def test_bn_act_train_fwd_bwd(C, act, use_res):
     xd = x.detach().float().to(dev)
     P = N * H * W
     stats = torch.zeros(64 * 2 * C, device=dev, dtype=torch.float64)
-    red = torch.zeros(2 * C, device=dev, dtype=torch.float64)
+    red = torch.zeros(65 * 2 * C, device=dev, dtype=torch.float64)
     f = lambda: torch.empty(C, device=dev)
     scale, shift, smean, sinv = f(), f(), f(), f()
     mm = torch.zeros(C, device=dev)

@@ -28,6 +28,9 @@ __device__ __forceinline__ float act_grad(float z, int act) {
   return 1.f;
 }
 
+// All per-channel reductions spread their fp64 atomics over YOLO_BN_STAT_SLOTS replicas of the [NQ][C]
+// result (replica = blockIdx.x mod SLOTS): 1024 blocks hammering the same 2C addresses ran at the
+// contended-atomic rate (MI355X_MICROARCH.md: 14x slower) and cost more than the streaming pass itself.
 // Column layout shared by the per-channel reductions: a block covers `cw` float4 columns
 // (cw = min(C/4, 256)) x (256/cw) pixel rows per pass; grid.y walks column chunks.
 struct ColGeom {
@@ -57,7 +60,7 @@ __device__ __forceinline__ void block_col_reduce(double (&v)[NQ][4], int cw, int
       for (int e = 0; e < 4; ++e) {
         double s = 0.0;
         for (int r = 0; r < rpp; ++r) s += smem[(q * 4 + e) * 256 + r * cw + col];
-        atomicAdd(&out[(long long)q * C + c4 * 4 + e], s);
+        atomicAdd(&out[(long long)(blockIdx.x & (YOLO_BN_STAT_SLOTS - 1)) * NQ * C + (long long)q * C + c4 * 4 + e], s);
       }
   }
 }
@@ -72,13 +75,17 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   const bool active = (row_lane < rpp) && (c4 < C4);
   double v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   if (active) {
-    const long long stride = (long long)gridDim.x * rpp;
-    for (long long p = (long long)blockIdx.x * rpp + row_lane; p < P; p += 4 * stride) {
+    // each block sweeps ONE contiguous range of rows front to back (sequential DRAM pages)
+    const long long per_block = (P + gridDim.x - 1) / gridDim.x;
+    const long long p_lo = (long long)blockIdx.x * per_block;
+    const long long p_hi = (p_lo + per_block < P) ? p_lo + per_block : P;
+    const long long stride = rpp;
+    for (long long p = p_lo + row_lane; p < p_hi; p += 4 * stride) {
       f32x4 t[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long pu = p + u * stride;
-        t[u] = (pu < P) ? *reinterpret_cast<const f32x4*>(x + pu * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        t[u] = (pu < p_hi) ? *reinterpret_cast<const f32x4*>(x + pu * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -172,13 +179,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const f32x4 sh = reinterpret_cast<const f32x4*>(shift)[c4];
     const f32x4 mu = reinterpret_cast<const f32x4*>(smean)[c4];
     const f32x4 iv = reinterpret_cast<const f32x4*>(sinv)[c4];
-    const long long stride = (long long)gridDim.x * rpp;
-    for (long long p = (long long)blockIdx.x * rpp + row_lane; p < P; p += 4 * stride) {
+    const long long per_block = (P + gridDim.x - 1) / gridDim.x;
+    const long long p_lo = (long long)blockIdx.x * per_block;
+    const long long p_hi = (p_lo + per_block < P) ? p_lo + per_block : P;
+    const long long stride = rpp;
+    for (long long p = p_lo + row_lane; p < p_hi; p += 4 * stride) {
       f32x4 xv[4], dv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long pu = p + u * stride;
-        const bool ok = pu < P;
+        const bool ok = pu < p_hi;
         xv[u] = ok ? *reinterpret_cast<const f32x4*>(x + pu * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
         dv[u] = ok ? *reinterpret_cast<const f32x4*>(dout + pu * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -227,12 +237,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
-__global__ void bn_bwd_params_kernel(int C, const double* __restrict__ red, float* __restrict__ dgamma,
+// red layout: [SLOTS replicas][2][C] followed by the final [2][C] sums
+__global__ void bn_bwd_sum_kernel(int C, double* __restrict__ red) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 2C
+  if (i >= 2 * C) return;
+  double s = 0.0;
+  for (int r = 0; r < YOLO_BN_STAT_SLOTS; ++r) s += red[(long long)r * 2 * C + i];
+  red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + i] = s;
+}
+
+__global__ void bn_bwd_params_kernel(int C, const double* __restrict__ redsum, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  if (dbeta) dbeta[c] += (float)red[c];
-  if (dgamma) dgamma[c] += (float)red[C + c];
+  if (dbeta) dbeta[c] += (float)redsum[c];
+  if (dgamma) dgamma[c] += (float)redsum[C + c];
 }
 
 __global__ void act_fwd_kernel(const float* __restrict__ x, long long n, int act, float* __restrict__ out) {
@@ -306,6 +325,7 @@ extern "C" int yolo_bn_act_bwd_reduce(const float* x, const float* dout, long lo
   dim3 grid(reduce_grid_x(P, g.rpp), (C / 4 + g.cw - 1) / g.cw);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, dout, P, C, g.cw, g.rpp, scale,
                      shift, save_mean, save_invstd, act, red);
+  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, as_stream(stream), C, red);
   return check_launch("bn_bwd_reduce_kernel");
 }
 
@@ -319,11 +339,12 @@ extern "C" int yolo_bn_act_bwd_apply(const float* x, const float* dout, long lon
   YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_apply: C=%d must be a multiple of 4", C);
   const long long n4 = P * (C / 4);
   hipStream_t st = as_stream(stream);
+  const double* redsum = red + (long long)YOLO_BN_STAT_SLOTS * 2 * C;
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, st, x, dout, n4, C / 4,
-                     1.0 / (double)P, scale, shift, save_mean, save_invstd, act, red, dx);
+                     1.0 / (double)P, scale, shift, save_mean, save_invstd, act, redsum, dx);
   if (int rc = check_launch("bn_bwd_apply_kernel")) return rc;
   if (dgamma || dbeta) {
-    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, red, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, redsum, dgamma, dbeta);
     return check_launch("bn_bwd_params_kernel");
   }
   return YOLO_OK;
