@@ -3,7 +3,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := tf2_yolo_amd/csrc
-SRCS  := $(CSRC)/runtime.hip $(CSRC)/conv.hip $(CSRC)/bn_act.hip $(CSRC)/elementwise.hip \
+SRCS  := $(CSRC)/runtime.hip $(CSRC)/conv.hip $(CSRC)/conv_split.hip $(CSRC)/bn_act.hip $(CSRC)/elementwise.hip \
          $(CSRC)/loss.hip $(CSRC)/decode_nms.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := tf2_yolo_amd/libyolo_hip.so
@@ -11,7 +11,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -munsafe-fp-atomics -Wal
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp include/yolo_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/conv_args.hpp include/yolo_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

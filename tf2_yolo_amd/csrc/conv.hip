@@ -25,47 +25,11 @@
 // and B (lane half h reads k = 8q+4h..8q+4h+3), which the contraction does not care about.
 // Double-buffered LDS, one barrier per slice, next slice's global loads in flight during
 // the 64 MFMAs (4096 cycles) of the current one.
-#include "common.hpp"
+#include "conv_args.hpp"
 #include <cstdlib>
 #include <type_traits>
 
 namespace yolo {
-
-constexpr int MAX_TAPS = 49;
-
-struct Tap {
-  int oy, ox, woff;
-};
-
-struct GatherConvArgs {
-  const float* src;
-  const float* wgt;
-  const float* bias;
-  float* dst;
-  double* stats;  // optional [YOLO_BN_STAT_SLOTS][2*Cout]: per-channel sum / sum of squares of dst
-  long long M;  // N*Hg*Wg
-  int N, Hs, Ws, Cs;
-  int Hg, Wg;
-  int sy, sx;
-  int Hd, Wd, Cd;
-  int osy, osx, ooy, oox;
-  int Cout, ldw;
-  int ntaps, accumulate;
-  int kw, pad_t, pad_l;  // FLAT mode: tap t = (r*kw+s), oy = r-pad_t, ox = s-pad_l
-  int tiles_n;
-  int nblocks;
-  Tap taps[MAX_TAPS];
-};
-
-// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
-// logical tiles so tiles that share A rows / B columns hit the same L2. Bijective for any
-// grid size (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-  const int xcd = bid & 7, idx = bid >> 3;
-  const int q = nblocks >> 3, r = nblocks & 7;
-  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  return start + idx;
-}
 
 template <int BM, int BN, int WGM, int WGN, bool FLAT>
 __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a) {
@@ -391,7 +355,16 @@ static int launch_gather(GatherConvArgs& a, hipStream_t st) {
   return check_launch("gather_conv_kernel");
 }
 
+// 0 = exact-fp32 MFMA kernels (this file), 1 = fp32 emulated with 6 bf16 MFMA passes (conv_split.hip)
+static int g_conv_mode = [] {
+  const char* e = getenv("YOLO_CONV_MODE");
+  if (e && (e[0] == 'f' || e[0] == '0')) return 0;   // "fp32"
+  if (e && (e[0] == 's' || e[0] == 'b' || e[0] == '1')) return 1;   // "split" / "bf16x6"
+  return 0;
+}();
+
 static int dispatch_gather(GatherConvArgs& a, bool flat, hipStream_t st) {
+  if (!flat && g_conv_mode == 1 && gather_split_supported(a)) return launch_gather_split(a, st);
   // every configuration keeps LDS <= 80 KB so that two workgroups share a CU
   if (flat) {
     if (a.Cout <= 32) return launch_gather<128, 32, 4, 1, true>(a, st);

@@ -1,0 +1,49 @@
+// Shared argument block of the implicit-GEMM "gather" convolution kernels (conv.hip: exact-fp32 MFMA;
+// conv_split.hip: fp32 emulated by bf16 x 6 MFMA passes). See conv.hip for the formulation.
+#pragma once
+#include "common.hpp"
+
+namespace yolo {
+
+constexpr int MAX_TAPS = 49;
+
+struct Tap {
+  int oy, ox, woff;
+};
+
+struct GatherConvArgs {
+  const float* src;
+  const float* wgt;
+  const float* bias;
+  float* dst;
+  double* stats;  // optional [YOLO_BN_STAT_SLOTS][2*Cout]: per-channel sum / sum of squares of dst
+  long long M;  // N*Hg*Wg
+  int N, Hs, Ws, Cs;
+  int Hg, Wg;
+  int sy, sx;
+  int Hd, Wd, Cd;
+  int osy, osx, ooy, oox;
+  int Cout, ldw;
+  int ntaps, accumulate;
+  int kw, pad_t, pad_l;  // FLAT mode: tap t = (r*kw+s), oy = r-pad_t, ox = s-pad_l
+  int tiles_n;
+  int nblocks;
+  Tap taps[MAX_TAPS];
+};
+
+// Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
+// logical tiles so tiles that share A rows / B columns hit the same L2. Bijective for any
+// grid size (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int q = nblocks >> 3, r = nblocks & 7;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + idx;
+}
+
+
+// conv_split.hip
+int launch_gather_split(GatherConvArgs& a, hipStream_t st);
+bool gather_split_supported(const GatherConvArgs& a);
+
+}  // namespace yolo
