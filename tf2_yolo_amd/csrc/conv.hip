@@ -358,9 +358,8 @@ static int launch_gather(GatherConvArgs& a, hipStream_t st) {
 // 0 = exact-fp32 MFMA kernels (this file), 1 = fp32 emulated with 6 bf16 MFMA passes (conv_split.hip)
 static int g_conv_mode = [] {
   const char* e = getenv("YOLO_CONV_MODE");
-  if (e && (e[0] == 'f' || e[0] == '0')) return 0;   // "fp32"
-  if (e && (e[0] == 's' || e[0] == 'b' || e[0] == '1')) return 1;   // "split" / "bf16x6"
-  return 0;
+  if (e && (e[0] == 'f' || e[0] == '0')) return 0;   // "fp32": exact-fp32 MFMA everywhere
+  return 1;                                          // default: "split" (bf16 x 6, fp32-accurate)
 }();
 
 static int dispatch_gather(GatherConvArgs& a, bool flat, hipStream_t st) {

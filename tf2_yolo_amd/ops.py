@@ -51,12 +51,18 @@ def _conv_flops(d):
     return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.kh * d.kw * d.Cin
 
 
+import os as _os
+CONV_MODE = "fp32" if _os.environ.get("YOLO_CONV_MODE", "split")[:1] in ("f", "0") else "split"
+
+
 def _gather_variant(cout, flat, m=None):
     """mirrors dispatch_gather() in csrc/conv.hip (names used by bench.py's roofline report)"""
     bn = 32 if cout <= 32 else (64 if cout <= 64 else 128)
     bm = 128
     if bn == 128 and not flat and m is not None and ((m + 127) // 128) * ((cout + 127) // 128) <= 512:
         bm = 64
+    if CONV_MODE == "split" and not flat and cout > 32:
+        return f"gather_conv_split_kernel<{bm},{bn}>"
     return f"gather_conv_kernel<{bm},{bn}{',flat' if flat else ''}>"
 
 
