@@ -413,21 +413,6 @@ static int validate_desc(const yolo_conv_desc* d) {
 // ds_read_b32 with consecutive lanes on consecutive banks; fragments of k-step s+1 are fetched before
 // the MFMAs of step s are issued.
 // ---------------------------------------------------------------------------------------
-struct WgradArgs {
-  const float* src;
-  const float* dy;
-  float* dw;
-  long long M;  // N*Hg*Wg pixels
-  int N, Hs, Ws, Cs;
-  int Hg, Wg;
-  int sy, sx;
-  int Cout, ldw;
-  int ntaps;
-  int kw, pad_t, pad_l;
-  int tiles_co, tiles_j;
-  long long chunk;  // pixels per split (multiple of 32)
-};
-
 template <int BM, int BN, int WGM, int WGN, bool ASCALAR, bool BSCALAR>
 __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a) {
   constexpr int NT = 64 * WGM * WGN;
@@ -834,7 +819,8 @@ extern "C" int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const 
   const bool bflat = (d->Cin % 4) != 0;
   int rc;
   hipStream_t st = as_stream(stream);
-  if (ascalar && bflat) rc = dispatch_wgrad<true, true>(a, st);
+  if (g_conv_mode == 1 && wgrad_split_supported(a)) rc = launch_wgrad_split(a, st);
+  else if (ascalar && bflat) rc = dispatch_wgrad<true, true>(a, st);
   else if (ascalar) rc = dispatch_wgrad<true, false>(a, st);
   else if (bflat) rc = dispatch_wgrad<false, true>(a, st);
   else rc = dispatch_wgrad<false, false>(a, st);

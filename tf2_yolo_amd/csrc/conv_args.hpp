@@ -42,8 +42,26 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
 }
 
 
+struct WgradArgs {
+  const float* src;
+  const float* dy;
+  float* dw;
+  long long M;  // N*Hg*Wg pixels
+  int N, Hs, Ws, Cs;
+  int Hg, Wg;
+  int sy, sx;
+  int Cout, ldw;
+  int ntaps;
+  int kw, pad_t, pad_l;
+  int tiles_co, tiles_j;
+  long long chunk;  // pixels per split (multiple of 32)
+};
+
 // conv_split.hip
 int launch_gather_split(GatherConvArgs& a, hipStream_t st);
 bool gather_split_supported(const GatherConvArgs& a);
+// conv_wgrad_split.hip
+int launch_wgrad_split(WgradArgs& a, hipStream_t st);
+bool wgrad_split_supported(const WgradArgs& a);
 
 }  // namespace yolo

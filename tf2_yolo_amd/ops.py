@@ -159,7 +159,9 @@ def conv2d_wgrad(d, x, dy, dw, dbias=None):
     def run():
         check(_lib.load().yolo_conv2d_wgrad(byref(d), _p(x), _p(dy), _p(dw), None, _stream()), "yolo_conv2d_wgrad")
     if TIMER is not None:
-        TIMER.bracket("wgrad_kernel", _conv_flops(d), 1, run)
+        split = (CONV_MODE == "split" and d.Cout % 4 == 0 and d.Cin % 4 == 0 and d.Cout >= 64
+                 and d.kh * d.kw * d.Cin >= 64)
+        TIMER.bracket("wgrad_split_kernel" if split else "wgrad_kernel", _conv_flops(d), 1, run)
     else:
         run()
     if dbias is not None:
