@@ -16,6 +16,7 @@
 //     (the ds_read_b128 fragment reads of 16 distinct rows hit 16 distinct 4-bank groups);
 //   * fragments: lane (r = lane&31, h = lane>>5) reads 8 consecutive k of row r at k = 8h (one b128).
 #include "conv_args.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 namespace yolo {
@@ -49,14 +50,16 @@ __device__ __forceinline__ Planes split4(const f32x4 v) {
 }
 
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void gather_conv_split_kernel(const GatherConvArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN) void gather_conv_split_kernel(const GatherConvArgs a) {
+  constexpr int NT = 64 * WGM * WGN;
   constexpr int BK = SPLIT_BK;
   constexpr int ROW = SPLIT_ROW;
   constexpr int TM = BM / WGM / 32;
   constexpr int TN = BN / WGN / 32;
-  constexpr int AR = BM / 64;  // A rows staged per thread (4 float4 per 16-wide row -> 64 rows per pass)
-  constexpr int BR = BN / 64;
-  static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1 && AR >= 1 && BR >= 1, "tile config");
+  constexpr int RPP = NT / 4;   // rows staged per pass (4 float4 per 16-wide row)
+  constexpr int AR = (BM + RPP - 1) / RPP;
+  constexpr int BR = (BN + RPP - 1) / RPP;
+  static_assert(TM >= 1 && TN >= 1 && AR >= 1 && BR >= 1, "tile config");
 
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   constexpr int PLANE_A = BM * ROW;              // bf16 elements
@@ -82,8 +85,8 @@ __global__ __launch_bounds__(256) void gather_conv_split_kernel(const GatherConv
   const int HgWg = a.Hg * a.Wg;
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    const long long m = m0 + lrow + 64 * i;
-    if (m < a.M) {
+    const long long m = m0 + lrow + RPP * i;
+    if (m < a.M && lrow + RPP * i < BM) {
       const int n = (int)(m / HgWg);
       const int rem = (int)(m - (long long)n * HgWg);
       const int y = rem / a.Wg;
@@ -100,8 +103,8 @@ __global__ __launch_bounds__(256) void gather_conv_split_kernel(const GatherConv
   int browel[BR];
 #pragma unroll
   for (int j = 0; j < BR; ++j) {
-    const int co = n0 + lrow + 64 * j;
-    browel[j] = (co < a.Cout) ? co * a.ldw : -1;
+    const int co = n0 + lrow + RPP * j;
+    browel[j] = (co < a.Cout && lrow + RPP * j < BN) ? co * a.ldw : -1;
   }
 
   const int cpt = a.Cs / BK;  // stages per tap
@@ -140,11 +143,13 @@ __global__ __launch_bounds__(256) void gather_conv_split_kernel(const GatherConv
     unsigned short* base = smem16 + buf * BUF;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const Planes p = split4(ra[S][i]);
-      const int o = (lrow + 64 * i) * ROW + kcol;
-      *reinterpret_cast<u32x2*>(base + o) = p.h;
-      *reinterpret_cast<u32x2*>(base + PLANE_A + o) = p.m;
-      *reinterpret_cast<u32x2*>(base + 2 * PLANE_A + o) = p.l;
+      if (lrow + RPP * i < BM) {
+        const Planes p = split4(ra[S][i]);
+        const int o = (lrow + RPP * i) * ROW + kcol;
+        *reinterpret_cast<u32x2*>(base + o) = p.h;
+        *reinterpret_cast<u32x2*>(base + PLANE_A + o) = p.m;
+        *reinterpret_cast<u32x2*>(base + 2 * PLANE_A + o) = p.l;
+      }
     }
   };
   auto store_b = [&](int buf, auto SET) {
@@ -152,11 +157,13 @@ __global__ __launch_bounds__(256) void gather_conv_split_kernel(const GatherConv
     unsigned short* base = smem16 + buf * BUF + 3 * PLANE_A;
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-      const Planes p = split4(rb[S][j]);
-      const int o = (lrow + 64 * j) * ROW + kcol;
-      *reinterpret_cast<u32x2*>(base + o) = p.h;
-      *reinterpret_cast<u32x2*>(base + PLANE_B + o) = p.m;
-      *reinterpret_cast<u32x2*>(base + 2 * PLANE_B + o) = p.l;
+      if (lrow + RPP * j < BN) {
+        const Planes p = split4(rb[S][j]);
+        const int o = (lrow + RPP * j) * ROW + kcol;
+        *reinterpret_cast<u32x2*>(base + o) = p.h;
+        *reinterpret_cast<u32x2*>(base + PLANE_B + o) = p.m;
+        *reinterpret_cast<u32x2*>(base + 2 * PLANE_B + o) = p.l;
+      }
     }
   };
 
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) void gather_conv_split_kernel(const GatherConv
   // ---- epilogue: identical to gather_conv_kernel (C/D layout is dtype-independent) ----
   float* smem = reinterpret_cast<float*>(smem16);
   long long* rowoff = reinterpret_cast<long long*>(smem);
-  for (int r = tid; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += NT) {
     const long long m = m0 + r;
     long long off = -1;
     if (m < a.M) {
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(256) void gather_conv_split_kernel(const GatherConv
       }
     }
     __syncthreads();
-    for (int c = tid; c < BN; c += 256) {
+    for (int c = tid; c < BN; c += NT) {
       const int col = n0 + c;
       if (col < a.Cout) {
         float s1 = 0.f, s2 = 0.f;
@@ -312,16 +319,20 @@ static int launch_split(GatherConvArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gather_conv_split_kernel<BM, BN, WGM, WGN>), dim3((unsigned)nb), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gather_conv_split_kernel<BM, BN, WGM, WGN>), dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
   return check_launch("gather_conv_split_kernel");
 }
 
 bool gather_split_supported(const GatherConvArgs& a) { return (a.Cs % SPLIT_BK) == 0 && a.Cout > 32; }
 
 int launch_gather_split(GatherConvArgs& a, hipStream_t st) {
+  // 8-wave workgroups (4 waves per SIMD with two workgroups per CU) cover the per-stage barrier and the
+  // split VALU better than 4-wave ones: +7 % on the 128x128 tile (YOLO_SPLIT_WAVES=4 restores 4 waves)
+  static const int waves = [] { const char* e = getenv("YOLO_SPLIT_WAVES"); return e ? atoi(e) : 8; }();
   if (a.Cout <= 64) return launch_split<128, 64, 2, 2>(a, st);
   const long long blocks128 = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-  if (blocks128 <= 512) return launch_split<64, 128, 1, 4>(a, st);
+  if (blocks128 <= 512) return launch_split<64, 128, 1, 4>(a, st);   // (8 waves measured slower here)
+  if (waves == 8) return launch_split<128, 128, 4, 2>(a, st);
   return launch_split<128, 128, 2, 2>(a, st);
 }
 
