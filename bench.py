@@ -39,12 +39,15 @@ CLASSES = 80
 
 
 def hbm_traffic_from_profile(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (bench.py cannot collect
-    PMC itself; FETCH_SIZE and WRITE_SIZE need separate passes). None if no profile is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_c_hbm_traffic.json")
-    if not os.path.exists(path):
+    """HBM bytes per launch of `kernel` from the newest committed rocprofv3 PMC passes (bench.py cannot
+    collect PMC itself; FETCH_SIZE and WRITE_SIZE need separate passes). None if no profile is committed."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))
+    if not paths:
         return None
-    prof = json.load(open(path))["kernels"]
+    prof = json.load(open(paths[-1]))["kernels"]
+    if kernel in prof:           # split kernels: the timer name is the rocprof name without "void yolo::" and spaces
+        return prof[kernel]["hbm_bytes_per_launch"]
     base, _, rest = kernel.partition("<")
     dims = rest.rstrip(">").split(",")
     flat = "true" if "flat" in dims else "false"
@@ -52,7 +55,7 @@ def hbm_traffic_from_profile(kernel):
         for name, v in prof.items():
             if name.startswith(f"{base}<{dims[0]},{dims[1]},") and name.endswith(f",{flat}>"):
                 return v["hbm_bytes_per_launch"]
-    if base == "wgrad_kernel":   # bench aggregates every wgrad tile shape; the profile has one entry per shape
+    if base == "wgrad_kernel":   # the timer aggregates the fp32 wgrad tile shapes; the profile has one entry per shape
         tot = sum(v["hbm_bytes_per_launch"] * v["launches"] for n, v in prof.items() if n.startswith("wgrad_kernel"))
         cnt = sum(v["launches"] for n, v in prof.items() if n.startswith("wgrad_kernel"))
         return int(tot / cnt) if cnt else None
@@ -199,7 +202,8 @@ def main():
                                    if "split" in name else "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": hbm_traffic_from_profile(name),
-                    "traffic_source": "profiles/r01_c_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                    "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "traffic_source": "newest profiles/r*_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                       "passes, gfx950 x2 FETCH correction), bytes per launch",
                     "launches": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
                     "flops_per_launch": a["flops"] / a["launches"],
@@ -211,7 +215,7 @@ def main():
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "arithmetic": "fp32 storage and accumulation everywhere; conv fwd/dgrad products = exact 3-way bf16 split x 6 MFMA passes (fp32-accurate, parity 1e-4 vs the float64 oracle), wgrad = fp32-input MFMA",
+               "arithmetic": "fp32 storage and accumulation everywhere; conv fwd/dgrad/wgrad products = exact 3-way bf16 split x 6 MFMA passes (fp32-accurate, parity 1e-4 vs the float64 oracle); first conv (Cin=3) and Cout<=32 layers use the fp32-input MFMA kernels; YOLO_CONV_MODE=fp32 selects those everywhere",
                "config": {"workload": "YOLOv3 Darknet-53 416x416, 9 anchors / 3 FPN scales, C=80: training step = "
                                       "forward (batch-stat BN) + 3 fused loss/grad kernels + backward + "
                                       "gradient all-reduce + Adam",

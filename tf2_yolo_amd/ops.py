@@ -62,7 +62,8 @@ def _gather_variant(cout, flat, m=None):
     if bn == 128 and not flat and m is not None and ((m + 127) // 128) * ((cout + 127) // 128) <= 512:
         bm = 64
     if CONV_MODE == "split" and not flat and cout > 32:
-        return f"gather_conv_split_kernel<{bm},{bn}>"
+        waves = {(128, 64): "2,2", (64, 128): "1,4", (128, 128): "4,2"}[(bm, bn)]
+        return f"gather_conv_split_kernel<{bm},{bn},{waves}>"
     return f"gather_conv_kernel<{bm},{bn}{',flat' if flat else ''}>"
 
 
@@ -161,7 +162,12 @@ def conv2d_wgrad(d, x, dy, dw, dbias=None):
     if TIMER is not None:
         split = (CONV_MODE == "split" and d.Cout % 4 == 0 and d.Cin % 4 == 0 and d.Cout >= 64
                  and d.kh * d.kw * d.Cin >= 64)
-        TIMER.bracket("wgrad_split_kernel" if split else "wgrad_kernel", _conv_flops(d), 1, run)
+        if split:  # mirrors launch_wgrad_split() in csrc/conv_wgrad_split.hip
+            cols = d.kh * d.kw * d.Cin
+            name = "wgrad_split_kernel<%d,%d,2,2>" % (64 if d.Cout <= 64 else 128, 64 if cols <= 64 else 128)
+        else:
+            name = "wgrad_kernel"
+        TIMER.bracket(name, _conv_flops(d), 1, run)
     else:
         run()
     if dbias is not None:
