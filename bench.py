@@ -32,7 +32,7 @@ SPLIT_PASSES = 6                # conv_split.hip: one fp32 product = 6 bf16 MFMA
 def kernel_peak(name):
     """Peak of ALGORITHMIC (fp32-equivalent) TFLOP/s for a kernel: the fp32-MFMA peak for the exact-fp32
     kernels, the bf16-MFMA peak / 6 for the bf16x6 split kernels (each algorithmic FLOP costs 6 bf16 FLOPs)."""
-    return BF16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if "split" in name else FP32_MFMA_PEAK_TFLOPS
+    return BF16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if ("split" in name or "planes" in name) else FP32_MFMA_PEAK_TFLOPS
 BATCH = 32
 HW = 416
 CLASSES = 80
@@ -199,7 +199,7 @@ def main():
             peak = kernel_peak(name)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
                     "peak_basis": ("bf16 MFMA dense peak 2500 TFLOP/s / 6 passes per fp32 product (exact 3-way split)"
-                                   if "split" in name else "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                                   if ("split" in name or "planes" in name) else "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": hbm_traffic_from_profile(name),
                     "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),

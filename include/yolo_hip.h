@@ -94,6 +94,24 @@ int yolo_conv2d_wgrad_bias(const float* dy, long long P, int Cout, float* dbias,
 /* wT[ci][r][s][co] = w[co][r][s][ci] */
 int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
 
+/* "Planes" operands: a row-major fp32 matrix X[rows][C] (the pixels of an NHWC tensor, or the output
+ * channels of a [Cout][kh*kw*Cin] filter), C % 16 == 0, split EXACTLY into three bf16 planes
+ * (x = h + m + l) and blocked 16 rows x 16 channels so that the conv kernels can bring MFMA operand
+ * fragments into LDS by DMA (layout: tf2_yolo_amd/csrc/conv_planes.hip). yolo_planes_bytes gives the
+ * buffer size (0 for unsupported shapes); yolo_split_planes fills it from fp32. A tensor that feeds
+ * several convolutions (forward, filter gradient) is split once. */
+size_t yolo_planes_bytes(long long rows, int C);
+int yolo_split_planes(const float* x, long long rows, int C, void* planes, void* stream);
+
+/* yolo_conv2d_fwd / yolo_conv2d_dgrad on pre-split operands (same conv, same fused epilogue, same
+ * fp32-accurate result): x_planes = planes of x viewed as [N*H*W][Cin], w_planes = planes of w viewed as
+ * [Cout][kh*kw*Cin]; dy_planes = planes of dy [N*Ho*Wo][Cout], wT_planes = planes of wT [Cin][kh*kw*Cout].
+ * Requires Cin % 16 == 0 and Cout > 32 (dgrad: Cout % 16 == 0 and Cin > 32). */
+int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,
+                           const float* bias, float* y, double* stats, void* stream);
+int yolo_conv2d_dgrad_planes(const yolo_conv_desc* d, const void* dy_planes, const void* wT_planes,
+                             float* dx, int accumulate, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * BatchNormalization (training and inference) + activation (+ residual add)
  * (replaces BatchNormalization + LeakyReLU / Mish + Add at

@@ -18,7 +18,14 @@ dy = torch.randn(N, d.Ho, d.Wo, cout, device="cuda")
 dw = torch.zeros_like(w)
 wT = ops.filter_transpose(w, cout, k * k, cin)
 dx = torch.empty_like(x)
-fn = {"fwd": lambda: ops.conv2d_fwd(d, x, w, None, out=y), "dgrad": lambda: ops.conv2d_dgrad(d, dy, wT, dx=dx),
+if mode.endswith("p"):   # planes kernels (pre-split operands, LDS-DMA)
+    xp = ops.split_planes(x, N * h * h, cin); wp = ops.split_planes(w, cout, k * k * cin)
+    dyp = ops.split_planes(dy, N * d.Ho * d.Wo, cout); wTp = ops.split_planes(wT, cin, k * k * cout)
+else:
+    xp = wp = dyp = wTp = None
+fn = {"fwdp": lambda: ops.conv2d_fwd_planes(d, xp, wp, None, out=y),
+      "dgradp": lambda: ops.conv2d_dgrad_planes(d, dyp, wTp, dx=dx),
+      "fwd": lambda: ops.conv2d_fwd(d, x, w, None, out=y), "dgrad": lambda: ops.conv2d_dgrad(d, dy, wT, dx=dx),
       "wgrad": lambda: ops.conv2d_wgrad(d, x, dy, dw)}[mode]
 fn(); torch.cuda.synchronize()
 s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

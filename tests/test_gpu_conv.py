@@ -118,3 +118,99 @@ def test_conv_fused_bn_statistics(case):
     got = stats.cpu().reshape(ops.BN_STAT_SLOTS, 2, cout).sum(0)
     assert _relerr(got[0], ref.sum(0)) < 1e-5 * max(1.0, (ref.abs().sum(0).max() / ref.sum(0).abs().max()).item())
     assert _relerr(got[1], (ref * ref).sum(0)) < 1e-5
+
+
+# ---- pre-split ("planes") operands + LDS-DMA kernels (include/yolo_hip.h: yolo_split_planes,
+# ---- yolo_conv2d_fwd_planes, yolo_conv2d_dgrad_planes) ------------------------------------------------
+# (N, H, W, Cin, Cout, k, stride, padding, bias): Cin % 16 == 0 and Cout > 32
+PLANES_CASES = [
+    (2, 16, 16, 32, 64, 3, 1, "same", False),        # 128x64 tile, spare loader waves
+    (2, 17, 13, 32, 64, 3, 2, "darknet_s2", False),   # stride 2, odd sizes
+    (2, 16, 16, 48, 128, 3, 2, "darknet_s2", True),   # Cin % 32 != 0
+    (2, 13, 13, 128, 255, 1, 1, "same", True),       # head: Cout = 255 (zero block past the last filter row)
+    (2, 7, 7, 96, 160, 3, 1, "same", False),         # M tail (98 pixels), N tail (160 = 128 + 32)
+    (3, 9, 11, 256, 128, 1, 1, "valid", False),
+    (1, 2, 2, 1024, 512, 3, 1, "same", False),       # 4 pixels: every tap but the centre hits padding
+    (2, 14, 14, 64, 64, 3, 2, "same", True),         # 'same' stride 2 (asymmetric pad)
+    (1, 13, 13, 64, 125, 1, 1, "same", True),
+]
+
+
+def test_split_planes_is_exact():
+    """h + m + l reproduces every fp32 value of magnitude >= 2^-110 bit for bit (the three 8-bit pieces
+    need exponents down to e-23 >= -133, the smallest bf16 subnormal); smaller values lose bits below
+    2^-133 only; rows past the end and the extra block are zero"""
+    from tf2_yolo_amd import ops
+    g = torch.Generator().manual_seed(11)
+    rows, c = 37, 48
+    x = (torch.randn(rows, c, generator=g) * torch.logspace(-30, 30, rows * c).reshape(rows, c)).float()
+    x[0, :4] = torch.tensor([0.0, 3.0e-33, 1e-40, float(2 ** -126)])   # zero, ~2^-108, a subnormal, the smallest normal
+    pl = ops.split_planes(x.cuda(), rows, c).cpu()
+    nblk = (rows + 15) // 16
+    assert pl.numel() == (nblk + 1) * (c // 16) * 1536
+    u = pl.view(torch.int16).reshape(nblk + 1, c // 16, 3, 2, 16, 8)          # [blk][kb][plane][half][row][8]
+    f = (u.to(torch.int32) << 16).view(torch.float32)                          # bf16 -> fp32 (exact)
+    f = f.permute(2, 0, 4, 1, 3, 5).reshape(3, (nblk + 1) * 16, c)             # [plane][row][channel]
+    rec = (f[2].double() + f[1].double() + f[0].double())
+    big = x.abs() >= 2.0 ** -110
+    assert torch.equal(rec[:rows][big].float(), x[big])
+    assert ((rec[:rows] - x.double()).abs()[~big] <= 2.0 ** -133).all()
+    assert (f[:, rows:] == 0).all()
+
+
+@pytest.mark.parametrize("case", PLANES_CASES)
+def test_conv_fwd_planes(case):
+    from tf2_yolo_amd import ops
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=7)
+    ref = L.conv2d(x, wk, b, stride=s, padding=pad)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    xd, wd = x.float().cuda(), _krsc(wk).float().cuda()
+    bd = None if b is None else b.float().cuda()
+    xp = ops.split_planes(xd, n * h * w, cin)
+    wp = ops.split_planes(wd, cout, k * k * cin)
+    stats = torch.zeros(ops.BN_STAT_SLOTS * 2 * cout, device="cuda", dtype=torch.float64)
+    y = ops.conv2d_fwd_planes(d, xp, wp, bd, stats=stats)
+    torch.cuda.synchronize()
+    assert _relerr(y.double().cpu(), ref) < TOL
+    # same products in the same order as the register-staged split kernel: bit-identical results
+    if cin % 32 == 0 and ops.CONV_MODE == "split":
+        assert torch.equal(y, ops.conv2d_fwd(d, xd, wd, bd))
+    got = stats.cpu().reshape(ops.BN_STAT_SLOTS, 2, cout).sum(0)
+    r2 = ref.reshape(-1, cout)
+    assert _relerr(got[1], (r2 * r2).sum(0)) < 1e-5
+
+
+@pytest.mark.parametrize("case", [c for c in PLANES_CASES if c[4] % 16 == 0 and c[3] > 32])
+def test_conv_dgrad_planes(case):
+    from tf2_yolo_amd import ops
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=8)
+    x.requires_grad_(True)
+    ref = L.conv2d(x, wk, None, stride=s, padding=pad)
+    g = torch.Generator().manual_seed(9)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    wT = ops.filter_transpose(_krsc(wk.detach()).float().cuda(), cout, k * k, cin)
+    dyp = ops.split_planes(dy.float().cuda(), n * d.Ho * d.Wo, cout)
+    wTp = ops.split_planes(wT, cin, k * k * cout)
+    dx = ops.conv2d_dgrad_planes(d, dyp, wTp)
+    torch.cuda.synchronize()
+    assert _relerr(dx.double().cpu(), x.grad) < TOL
+    dx2 = dx.clone()
+    ops.conv2d_dgrad_planes(d, dyp, wTp, dx=dx2, accumulate=True)
+    torch.cuda.synchronize()
+    assert _relerr(dx2.double().cpu(), 2 * x.grad) < TOL
+
+
+def test_conv_planes_rejects_unsupported_shapes():
+    from tf2_yolo_amd import ops
+    from tf2_yolo_amd._lib import YoloHipError
+    with pytest.raises(YoloHipError):
+        ops.planes_bytes(10, 24)          # C % 16 != 0
+    d = ops.conv_desc((1, 8, 8, 32), 32, 3, 3, 1, "same")   # Cout = 32: not covered by the planes kernels
+    xp = ops.split_planes(torch.zeros(64, 32, device="cuda"), 64, 32)
+    wp = ops.split_planes(torch.zeros(32, 288, device="cuda"), 32, 288)
+    with pytest.raises(YoloHipError):
+        ops.conv2d_fwd_planes(d, xp, wp)

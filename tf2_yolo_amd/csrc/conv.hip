@@ -717,15 +717,7 @@ __global__ void colsum_kernel(const float* __restrict__ x, long long P, int C, f
 
 using namespace yolo;
 
-extern "C" int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                               double* stats, void* stream) {
-  if (int rc = validate_desc(d)) return rc;
-  YOLO_REQUIRE(x && w && y, "conv_fwd: null pointer");
-  GatherConvArgs a{};
-  a.src = x;
-  a.wgt = w;
-  a.bias = bias;
-  a.dst = y;
+static void fill_fwd_args(const yolo_conv_desc* d, GatherConvArgs& a) {
   a.N = d->N; a.Hs = d->H; a.Ws = d->W; a.Cs = d->Cin;
   a.Hg = d->Ho; a.Wg = d->Wo;
   a.sy = d->sh; a.sx = d->sw;
@@ -739,13 +731,50 @@ extern "C" int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const fl
   a.M = (long long)d->N * d->Ho * d->Wo;
   for (int r = 0; r < d->kh; ++r)
     for (int s = 0; s < d->kw; ++s) a.taps[r * d->kw + s] = Tap{r - d->pad_t, s - d->pad_l, (r * d->kw + s) * d->Cin};
+}
+
+extern "C" int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                               double* stats, void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x && w && y, "conv_fwd: null pointer");
+  GatherConvArgs a{};
+  a.src = x;
+  a.wgt = w;
+  a.bias = bias;
+  a.dst = y;
+  fill_fwd_args(d, a);
   a.stats = stats;
   const bool flat = (d->Cin % 32) != 0;
   return dispatch_gather(a, flat, as_stream(stream));
 }
 
-extern "C" int yolo_conv2d_dgrad(const yolo_conv_desc* d, const float* dy, const float* wT, float* dx, int accumulate,
-                                 void* stream) {
+extern "C" int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,
+                                      const float* bias, float* y, double* stats, void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x_planes && w_planes && y, "conv_fwd_planes: null pointer");
+  GatherConvArgs a{};
+  a.src = reinterpret_cast<const float*>(x_planes);
+  a.wgt = reinterpret_cast<const float*>(w_planes);
+  a.bias = bias;
+  a.dst = y;
+  fill_fwd_args(d, a);
+  a.stats = stats;
+  YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_planes: needs Cin %% 16 == 0 and Cout > 32");
+  return launch_gather_planes(a, as_stream(stream));
+}
+
+extern "C" size_t yolo_planes_bytes(long long rows, int C) {
+  if (rows <= 0 || C <= 0 || (C % 16) != 0) return 0;
+  return (size_t)planes_bytes(rows, C);
+}
+
+extern "C" int yolo_split_planes(const float* x, long long rows, int C, void* planes, void* stream) {
+  YOLO_REQUIRE(x && planes, "split_planes: null pointer");
+  return launch_split_planes(x, rows, C, planes, as_stream(stream));
+}
+
+static int dgrad_impl(const yolo_conv_desc* d, const float* dy, const float* wT, float* dx, int accumulate,
+                      void* stream, bool planes) {
   if (int rc = validate_desc(d)) return rc;
   YOLO_REQUIRE(dy && wT && dx, "conv_dgrad: null pointer");
   // hi = ho*sh + r - pad_t  =>  for input-row parity class py (hi = y*sh + py) the taps with
@@ -793,10 +822,26 @@ extern "C" int yolo_conv2d_dgrad(const yolo_conv_desc* d, const float* dy, const
           continue;
         }
       }
-      if (int rc = dispatch_gather(a, flat, as_stream(stream))) return rc;
+      if (planes) {
+        YOLO_REQUIRE(gather_planes_supported(a), "conv_dgrad_planes: needs Cout %% 16 == 0 and Cin > 32");
+        if (int rc = launch_gather_planes(a, as_stream(stream))) return rc;
+      } else if (int rc = dispatch_gather(a, flat, as_stream(stream))) {
+        return rc;
+      }
     }
   }
   return YOLO_OK;
+}
+
+extern "C" int yolo_conv2d_dgrad(const yolo_conv_desc* d, const float* dy, const float* wT, float* dx, int accumulate,
+                                 void* stream) {
+  return dgrad_impl(d, dy, wT, dx, accumulate, stream, false);
+}
+
+extern "C" int yolo_conv2d_dgrad_planes(const yolo_conv_desc* d, const void* dy_planes, const void* wT_planes, float* dx,
+                                        int accumulate, void* stream) {
+  return dgrad_impl(d, reinterpret_cast<const float*>(dy_planes), reinterpret_cast<const float*>(wT_planes), dx,
+                    accumulate, stream, true);
 }
 
 extern "C" int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,

@@ -28,6 +28,9 @@ struct GatherConvArgs {
   int kw, pad_t, pad_l;  // FLAT mode: tap t = (r*kw+s), oy = r-pad_t, ox = s-pad_l
   int tiles_n;
   int nblocks;
+  // planes kernels (conv_planes.hip): src / wgt point to bf16 planes; byte sizes and all-zero block indices
+  unsigned src_bytes, wgt_bytes;
+  int zero_blk_src, zero_blk_wgt;
   Tap taps[MAX_TAPS];
 };
 
@@ -60,6 +63,11 @@ struct WgradArgs {
 // conv_split.hip
 int launch_gather_split(GatherConvArgs& a, hipStream_t st);
 bool gather_split_supported(const GatherConvArgs& a);
+// conv_planes.hip
+long long planes_bytes(long long rows, int C);
+int launch_split_planes(const float* x, long long rows, int C, void* planes, hipStream_t st);
+int launch_gather_planes(GatherConvArgs& a, hipStream_t st);
+bool gather_planes_supported(const GatherConvArgs& a);
 // conv_wgrad_split.hip
 int launch_wgrad_split(WgradArgs& a, hipStream_t st);
 bool wgrad_split_supported(const WgradArgs& a);

@@ -1,0 +1,424 @@
+// Convolution forward / dgrad on operands that were split into bf16 planes BEFORE the kernel runs
+// ("planes" format, yolo_split_planes) and that reach LDS by LDS-DMA (buffer_load ... lds): the main
+// loop has no VALU split arithmetic, no ds_write and no VGPR staging -- only DMA issue, fragment
+// reads and the 6 MFMA passes per 32x32 fragment pair of the exact bf16 x 6 product (conv_split.hip).
+//
+// Planes format of a row-major fp32 matrix X[rows][C] (rows = pixels of an NHWC tensor or the output
+// channels of a KRSC filter; C % 16 == 0): 16-row blocks, inside a block one 1536-byte record per
+// 16-channel block kb, inside a record six 256-byte sub-blocks (plane p in {h,m,l}) x (half hf in {0,1}),
+// each sub-block = 16 rows x 8 bf16 (one 16-byte unit per row):
+//     byte(row, c) = ((row>>4) * C/16 + c/16) * 1536 + (2*p + (c%16)/8) * 256 + (row&15) * 16 + (c%8)*2
+// followed by ONE all-zero block (the target of padding taps and of rows/columns past the matrix edge).
+// Why this shape: an MFMA 32x32x16 operand fragment is "lane (r, hf) holds 8 consecutive k of row r";
+// a DMA wave-instruction writes 64 lanes x 16 B lane-linearly into LDS. With lane (r, hf) fetching unit
+// (row r, half hf) the LDS image of a 32-row block IS the fragment: reads are linear ds_read_b128
+// (conflict-free), while adjacent lanes = adjacent rows fetch adjacent 16-byte units of one 256-byte
+// sub-block, i.e. whole cache lines (a row-major planes layout cannot have both).
+#include "conv_args.hpp"
+#include <cstdlib>
+#include <type_traits>
+
+namespace yolo {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PL_RECORD = 1536;  // bytes per (16-row block, 16-channel block)
+
+struct Planes8 {
+  u32x4 h, m, l;  // 8 bf16 each
+};
+
+// exact 3-way truncation split (see conv_split.hip: split4) of 8 floats
+__device__ __forceinline__ Planes8 split8(const f32x4 v0, const f32x4 v1) {
+  const u32x4 mask = {0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u};
+  Planes8 p;
+  {
+    const u32x4 hb = __builtin_bit_cast(u32x4, v0) & mask;
+    const f32x4 r1 = v0 - __builtin_bit_cast(f32x4, hb);
+    const u32x4 mb = __builtin_bit_cast(u32x4, r1) & mask;
+    const f32x4 r2 = r1 - __builtin_bit_cast(f32x4, mb);
+    const u32x4 lb = __builtin_bit_cast(u32x4, r2) & mask;
+    p.h[0] = (hb[0] >> 16) | hb[1]; p.h[1] = (hb[2] >> 16) | hb[3];
+    p.m[0] = (mb[0] >> 16) | mb[1]; p.m[1] = (mb[2] >> 16) | mb[3];
+    p.l[0] = (lb[0] >> 16) | lb[1]; p.l[1] = (lb[2] >> 16) | lb[3];
+  }
+  {
+    const u32x4 hb = __builtin_bit_cast(u32x4, v1) & mask;
+    const f32x4 r1 = v1 - __builtin_bit_cast(f32x4, hb);
+    const u32x4 mb = __builtin_bit_cast(u32x4, r1) & mask;
+    const f32x4 r2 = r1 - __builtin_bit_cast(f32x4, mb);
+    const u32x4 lb = __builtin_bit_cast(u32x4, r2) & mask;
+    p.h[2] = (hb[0] >> 16) | hb[1]; p.h[3] = (hb[2] >> 16) | hb[3];
+    p.m[2] = (mb[0] >> 16) | mb[1]; p.m[3] = (mb[2] >> 16) | mb[3];
+    p.l[2] = (lb[0] >> 16) | lb[1]; p.l[3] = (lb[2] >> 16) | lb[3];
+  }
+  return p;
+}
+
+// one thread = (row, 8-channel group); adjacent lanes read adjacent 32-byte pieces of a row
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long rows, int C,
+                                                          unsigned char* __restrict__ out, long long rows_padded) {
+  const int G = C >> 3;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows_padded * G) return;
+  const long long row = t / G;
+  const int g = (int)(t - row * G);
+  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+  if (row < rows) {
+    const float* p = x + row * C + g * 8;
+    v0 = *reinterpret_cast<const f32x4*>(p);
+    v1 = *reinterpret_cast<const f32x4*>(p + 4);
+  }
+  const Planes8 s = split8(v0, v1);
+  unsigned char* o = out + ((row >> 4) * (C >> 4) + (g >> 1)) * PL_RECORD + (g & 1) * 256 + (row & 15) * 16;
+  *reinterpret_cast<u32x4*>(o) = s.h;
+  *reinterpret_cast<u32x4*>(o + 512) = s.m;
+  *reinterpret_cast<u32x4*>(o + 1024) = s.l;
+}
+
+// LDS-DMA: 64 lanes x 16 bytes from buffer offset (voff + soff) to LDS bytes [lds, lds + 1024).
+// Invisible to hipcc's s_waitcnt bookkeeping: completion is counted by hand (vmcnt) in the kernel.
+__device__ __forceinline__ void dma16(const i32x4 rsrc, const unsigned voff, const unsigned soff, const unsigned lds) {
+  // M0 = LDS destination; nothing else in these kernels uses M0, so it is not saved
+  asm volatile(
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "buffer_load_dwordx4 %0, %1, %2 offen lds"
+      :
+      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds)
+      : "memory");
+}
+
+// Workgroup tile BM x BN, NW = WGM*WGN waves; every wave is also the loader of ONE 32-row block of
+// A (waves 0 .. BM/32-1) or B (the rest): three DMA instructions (planes h, m, l) per 16-k stage.
+// Ring of 3 stage buffers in LDS + 2 fragment register sets, one barrier per stage. Iteration kt:
+//   wait vmcnt(3)  -> my DMAs of stage kt+1 have landed (those of kt+2 may still fly)
+//   barrier        -> everybody's have; everybody finished reading stage kt's buffer (last iteration)
+//   read fragments of stage kt+1 into the other register set
+//   6 MFMA passes per fragment pair on stage kt's registers, with the 3 DMAs of stage kt+3 (into stage
+//   kt's buffer) issued between them
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(const GatherConvArgs a) {
+  constexpr int NW = WGM * WGN;
+  constexpr int NT = 64 * NW;
+  constexpr int TM = BM / WGM / 32;
+  constexpr int TN = BN / WGN / 32;
+  constexpr int RBA = BM / 32, RBB = BN / 32;
+  static_assert(RBA + RBB <= NW, "at least one loader wave per 32-row block");
+  constexpr int STAGE_BYTES = (RBA + RBB) * 3 * 1024;
+  constexpr int NBUF = 3;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds_base = (unsigned)(size_t)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int tile = xcd_remap(blockIdx.x, a.nblocks);
+  const int tile_n = tile % a.tiles_n;
+  const int tile_m = tile / a.tiles_n;
+  const long long m0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
+  const int HgWg = a.Hg * a.Wg;
+
+  // ---- loader role ----
+  const bool loadA = wave < RBA;
+  // (spare waves load a B block a second time -- identical bytes to the same LDS address -- so that every
+  // wave has the same number of DMAs on its counter)
+  const int rb = loadA ? wave : (wave - RBA) % RBB;
+  const int r = lane & 31, hf = lane >> 5;
+  int nimg = 0, ys0 = -(1 << 28), xs0 = 0;
+  unsigned rowbaseB = 0;
+  if (loadA) {
+    const long long m = m0 + rb * 32 + r;
+    if (m < a.M) {
+      nimg = (int)(m / HgWg);
+      const int rem = (int)(m - (long long)nimg * HgWg);
+      const int y = rem / a.Wg;
+      ys0 = y * a.sy;
+      xs0 = (rem - y * a.Wg) * a.sx;
+    }
+  } else {
+    const int co = n0 + rb * 32 + r;
+    const unsigned blk = co < a.Cout ? (unsigned)(co >> 4) : (unsigned)a.zero_blk_wgt;
+    rowbaseB = blk * (unsigned)((a.ldw >> 4) * PL_RECORD) + (co < a.Cout ? (co & 15) * 16 : 0) + hf * 256;
+  }
+  const unsigned blkstrideA = (unsigned)((a.Cs >> 4) * PL_RECORD);
+  const void* pbase = loadA ? (const void*)a.src : (const void*)a.wgt;
+  const unsigned pbytes = loadA ? a.src_bytes : a.wgt_bytes;
+  // raw buffer descriptor: base, stride 0, num_records = bytes, DATA_FORMAT = 32 (raw, bounds-checked)
+  const unsigned long long pb = (unsigned long long)(size_t)pbase;
+  const i32x4 rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)pb),
+                      __builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32) & 0xFFFF),
+                      __builtin_amdgcn_readfirstlane((int)pbytes), 0x00020000};
+  const unsigned lds_mine = lds_base + ((loadA ? 0 : RBA) + rb) * 3 * 1024;
+
+  const int cpt = a.Cs >> 4;  // stages per tap
+  const int nk = a.ntaps * cpt;
+
+  // ---- loader state: the next stage to issue (tap, 16-channel block) and its DMA offsets ----
+  int ld_tap = 0, ld_kb = 0;
+  unsigned ld_voff = 0, ld_soff = 0;
+  auto loader_tap = [&]() {  // per-tap part of the source address (A: the shifted pixel, B: the filter tap)
+    if (ld_tap >= a.ntaps) {  // stages past the end (issued to keep the DMA count per stage uniform): zero block
+      ld_voff = (loadA ? (unsigned)a.zero_blk_src * blkstrideA : (unsigned)a.zero_blk_wgt * (unsigned)((a.ldw >> 4) * PL_RECORD));
+      ld_soff = 0;
+      return;
+    }
+    if (loadA) {
+      const int ys = ys0 + a.taps[ld_tap].oy, xs = xs0 + a.taps[ld_tap].ox;
+      const bool ok = ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
+      const int pix = (nimg * a.Hs + ys) * a.Ws + xs;
+      ld_voff = (ok ? ((unsigned)pix >> 4) : (unsigned)a.zero_blk_src) * blkstrideA + (ok ? (pix & 15) * 16 : 0) + hf * 256;
+      ld_soff = 0;
+    } else {
+      ld_voff = rowbaseB;
+      ld_soff = (unsigned)(a.taps[ld_tap].woff >> 4) * PL_RECORD;
+    }
+  };
+  auto loader_next = [&]() {
+    ld_soff += PL_RECORD;
+    if (++ld_kb == cpt) {
+      ld_kb = 0;
+      ++ld_tap;
+      loader_tap();
+    }
+  };
+  auto issue_plane = [&](int p, int buf) {
+    const unsigned so = __builtin_amdgcn_readfirstlane(ld_soff + p * 512);
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_mine + buf * STAGE_BYTES + p * 1024);
+    dma16(rsrc, ld_voff, so, l);
+  };
+  auto issue_stage = [&](int buf) {
+    issue_plane(0, buf);
+    issue_plane(1, buf);
+    issue_plane(2, buf);
+    loader_next();
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // two fragment register sets: the MFMAs of stage kt run on one while stage kt+1 is read into the other
+  bf16x8 fa[2][3][TM], fb[2][3][TN];
+  auto read_frags = [&](int buf, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    const unsigned char* sb = smem + buf * STAGE_BYTES + lane * 16;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[S][p][i] = *reinterpret_cast<const bf16x8*>(sb + ((wm * TM + i) * 3 + p) * 1024);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[S][p][j] = *reinterpret_cast<const bf16x8*>(sb + ((RBA + wn * TN + j) * 3 + p) * 1024);
+    }
+  };
+  // six partial products, smallest first: l*h, h*l, m*m, m*h, h*m, h*h (planes: 0 = h, 1 = m, 2 = l).
+  // The three DMA instructions of the stage being issued sit between MFMA groups: their issue slots are
+  // covered by the matrix pipe working on the MFMAs already queued.
+  auto mfma_stage = [&](auto SET, int wbuf) {
+    constexpr int S = decltype(SET)::value;
+    constexpr int NM = TM * TN * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      // q: (A plane, B plane) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+      const int pa = (q == 0) ? 2 : (q == 2 || q == 3) ? 1 : 0;
+      const int pb = (q == 1) ? 2 : (q == 2 || q == 4) ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
+          const int idx = (q * TM + i) * TN + j;
+          if (idx == NM / 4 - 1 || idx == NM / 2 - 1 || idx == (3 * NM) / 4 - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_plane(idx == NM / 4 - 1 ? 0 : idx == NM / 2 - 1 ? 1 : 2, wbuf);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    }
+    loader_next();
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  // prologue: stages 0..2 in flight (stages >= nk are dummies that read the zero block, so that every
+  // wave always has exactly 3 DMAs per stage on its counter), stage 0's fragments in set 0
+  loader_tap();
+  issue_stage(0);
+  issue_stage(1);
+  issue_stage(2);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, S0{});
+
+  // iteration kt: MFMAs of stage kt (registers) | fragment reads of stage kt+1 | DMA issue of stage kt+3
+  // (into stage kt's buffer: everybody finished reading it before this iteration's barrier)
+  auto step = [&](int rbuf, int wbuf, auto CUR, auto NXT) {
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // my pieces of stage kt+1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage kt's buffer are done
+    __builtin_amdgcn_s_barrier();
+    read_frags(rbuf, NXT);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_stage(CUR, wbuf);
+  };
+  {
+    int rbuf = 1, wbuf = 0;
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      step(rbuf, wbuf, S0{}, S1{});
+      rbuf = (rbuf + 1 == NBUF) ? 0 : rbuf + 1;
+      wbuf = (wbuf + 1 == NBUF) ? 0 : wbuf + 1;
+      step(rbuf, wbuf, S1{}, S0{});
+      rbuf = (rbuf + 1 == NBUF) ? 0 : rbuf + 1;
+      wbuf = (wbuf + 1 == NBUF) ? 0 : wbuf + 1;
+    }
+    if (kt < nk) step(rbuf, wbuf, S0{}, S1{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy tail DMAs too
+  __syncthreads();  // every wave is done with the stage buffers: the epilogue reuses them
+
+  // ---- epilogue: identical to gather_conv_kernel (C/D layout is dtype-independent) ----
+  float* smf = reinterpret_cast<float*>(smem);
+  long long* rowoff = reinterpret_cast<long long*>(smf);
+  for (int rr = tid; rr < BM; rr += NT) {
+    const long long m = m0 + rr;
+    long long off = -1;
+    if (m < a.M) {
+      const int n = (int)(m / HgWg);
+      const int rem = (int)(m - (long long)n * HgWg);
+      const int y = rem / a.Wg;
+      const int x = rem - y * a.Wg;
+      off = (((long long)n * a.Hd + (y * a.osy + a.ooy)) * a.Wd + (x * a.osx + a.oox)) * a.Cd;
+    }
+    rowoff[rr] = off;
+  }
+  __syncthreads();
+
+  float* sred = smf + 2 * BM;
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+    const bool cok = col < a.Cout;
+    const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+        const long long off = rowoff[row];
+        if (cok && off >= 0) {
+          float v = acc[i][j][q] + bv;
+          if (a.accumulate) v += a.dst[off + col];
+          a.dst[off + col] = v;
+          s1 += v;
+          s2 += v * v;
+        }
+      }
+    }
+    csum[j] = s1;
+    csq[j] = s2;
+  }
+  if (a.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
+      const float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (lane < 32) {
+        const int c = (wn * TN + j) * 32 + lane;
+        sred[(wm * BN + c) * 2 + 0] = s1;
+        sred[(wm * BN + c) * 2 + 1] = s2;
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < BN; c += NT) {
+      const int col = n0 + c;
+      if (col < a.Cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) {
+          s1 += sred[(w * BN + c) * 2 + 0];
+          s2 += sred[(w * BN + c) * 2 + 1];
+        }
+        double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
+        atomicAdd(&slot[col], (double)s1);
+        atomicAdd(&slot[a.Cout + col], (double)s2);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_planes(GatherConvArgs& a, hipStream_t st) {
+  const long long tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.Cout + BN - 1) / BN;
+  const long long nb = tiles_m * a.tiles_n;
+  if (nb <= 0 || nb > 0x7fffffffLL) {
+    set_error("conv(planes): bad grid %lld", nb);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  a.nblocks = (int)nb;
+  constexpr size_t lds = 3 * (BM / 32 + BN / 32) * 3 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN>), dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
+  return check_launch("gather_conv_planes_kernel");
+}
+
+long long planes_bytes(long long rows, int C) {
+  return ((rows + 15) / 16 + 1) * (long long)(C / 16) * PL_RECORD;
+}
+
+bool gather_planes_supported(const GatherConvArgs& a) { return (a.Cs % 16) == 0 && a.Cout > 32; }
+
+int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
+  const long long rowsA = (long long)a.N * a.Hs * a.Ws;
+  const long long bytesA = planes_bytes(rowsA, a.Cs), bytesB = planes_bytes(a.Cout, a.ldw);
+  if (bytesA >= (1LL << 32) || bytesB >= (1LL << 32)) {
+    set_error("conv(planes): operand planes exceed 4 GiB (%lld, %lld bytes)", bytesA, bytesB);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  a.src_bytes = (unsigned)bytesA;
+  a.wgt_bytes = (unsigned)bytesB;
+  a.zero_blk_src = (int)((rowsA + 15) / 16);
+  a.zero_blk_wgt = (a.Cout + 15) / 16;
+  if (a.Cout <= 64) return launch_planes<128, 64, 4, 2>(a, st);
+  return launch_planes<128, 128, 4, 2>(a, st);
+}
+
+int launch_split_planes(const float* x, long long rows, int C, void* planes, hipStream_t st) {
+  if (C % 16 != 0 || rows <= 0) {
+    set_error("split_planes: C %% 16 != 0 or rows <= 0");
+    return YOLO_ERR_INVALID_ARG;
+  }
+  const long long rows_padded = ((rows + 15) / 16 + 1) * 16;
+  const long long threads = rows_padded * (C / 8);
+  const long long blocks = (threads + 255) / 256;
+  if (blocks > 0x7fffffffLL) {
+    set_error("split_planes: tensor too large");
+    return YOLO_ERR_INVALID_ARG;
+  }
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, rows, C,
+                     reinterpret_cast<unsigned char*>(planes), rows_padded);
+  return check_launch("split_planes_kernel");
+}
+
+}  // namespace yolo

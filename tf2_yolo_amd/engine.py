@@ -301,6 +301,26 @@ class Network:
         self._infer_scale_valid = False
         # consumers per tensor decide whether a tensor needs a gradient at all
         self._needs_grad = self._compute_needs_grad()
+        # pre-split ("planes") copies of the filters for the LDS-DMA conv kernels: [Cout][taps*Cin] for
+        # forward, [Cin][taps*Cout] for dgrad; refreshed when the parameters change
+        wp = 0
+        for u in self.units:
+            if u.kind not in ("conv", "head"):
+                continue
+            cout = u.cout if u.kind == "conv" else u.out.c
+            k = u.k if u.kind == "conv" else 1
+            u.planes_fwd = ops.planes_fwd_ok(u.src.c, cout)
+            u.planes_dgrad = ops.planes_dgrad_ok(u.src.c, cout) and self._needs_grad[u.src.tid]
+            u.wp_off = u.wTp_off = -1
+            if u.planes_fwd:
+                u.wp_off, u.wp_bytes = wp, ops.planes_bytes(cout, k * k * u.src.c)
+                wp += (u.wp_bytes + 255) // 256 * 256
+            if u.planes_dgrad:
+                u.wTp_off, u.wTp_bytes = wp, ops.planes_bytes(u.src.c, k * k * cout)
+                wp += (u.wTp_bytes + 255) // 256 * 256
+        self._wplanes = torch.empty(wp, device=self.device, dtype=torch.uint8) if wp else None
+        self._wp_valid = False
+        self._wTp_valid = False
 
     # ---- construction -------------------------------------------------------------------
     def _declare_params(self):
@@ -381,6 +401,57 @@ class Network:
             else:
                 u.buf = torch.empty((N, oh, ow, oc), device=dev, dtype=torch.float32)
                 self.act[u.out.tid] = u.buf
+        # planes of the activations that feed planes-capable convs (kept from forward for the filter
+        # gradient), one scratch for the planes of the current layer's dy in backward
+        self._xplanes = {}
+        dyp = 0
+        for u in self.units:
+            if u.kind not in ("conv", "head"):
+                continue
+            if u.planes_fwd and u.src.tid not in self._xplanes:
+                self._xplanes[u.src.tid] = torch.empty(ops.planes_bytes(N * u.src.h * u.src.w, u.src.c), device=dev,
+                                                       dtype=torch.uint8)
+            if u.planes_dgrad:
+                dyp = max(dyp, ops.planes_bytes(N * u.out.h * u.out.w, u.cout if u.kind == "conv" else u.out.c))
+        self._dyplanes = torch.empty(dyp, device=dev, dtype=torch.uint8) if dyp else None
+        self._xp_valid = set()
+
+    def _xp(self, t):
+        """planes of activation tensor t for this forward pass (split once, shared by all consumers)"""
+        buf = self._xplanes[t.tid]
+        if t.tid not in self._xp_valid:
+            ops.split_planes(self.act[t.tid], self.batch * t.h * t.w, t.c, out=buf)
+            self._xp_valid.add(t.tid)
+        return buf
+
+    def _refresh_wplanes(self):
+        if self._wp_valid or self._wplanes is None:
+            return
+        for u in self.units:
+            if u.kind in ("conv", "head") and u.planes_fwd:
+                cout = u.cout if u.kind == "conv" else u.out.c
+                k = u.k if u.kind == "conv" else 1
+                ops.split_planes(self.params.view(u.p_kernel.name), cout, k * k * u.src.c,
+                                 out=self._wplanes[u.wp_off:u.wp_off + u.wp_bytes])
+        self._wp_valid = True
+
+    def _refresh_wTplanes(self):
+        if self._wTp_valid or self._wplanes is None:
+            return
+        for u in self.units:
+            if u.kind in ("conv", "head") and u.planes_dgrad:
+                cout = u.cout if u.kind == "conv" else u.out.c
+                k = u.k if u.kind == "conv" else 1
+                n = cout * k * k * u.src.c
+                ops.split_planes(self._wT[u.wT_off:u.wT_off + n], u.src.c, k * k * cout,
+                                 out=self._wplanes[u.wTp_off:u.wTp_off + u.wTp_bytes])
+        self._wTp_valid = True
+
+    def _conv_fwd(self, u, xin, w, bias, out, stats=None):
+        if u.planes_fwd:
+            return ops.conv2d_fwd_planes(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias,
+                                         out=out, stats=stats)
+        return ops.conv2d_fwd(u.desc, xin, w, bias, out=out, stats=stats)
 
     def _bn_bufs(self, u):
         c = u.cout
@@ -392,6 +463,8 @@ class Network:
 
     def mark_params_changed(self):
         self._wT_valid = False
+        self._wp_valid = False
+        self._wTp_valid = False
         self._infer_scale_valid = False
 
     # ---- forward ------------------------------------------------------------------------
@@ -407,6 +480,8 @@ class Network:
         self.allocate(N)
         self.training = training
         self.act[self.input.tid] = x
+        self._xp_valid = set()
+        self._refresh_wplanes()
         if training:
             self._bn_f64.zero_()
             self._infer_scale_valid = False  # moving statistics (and the shared scale/shift) change
@@ -420,26 +495,26 @@ class Network:
                     scale, shift, smean, sinv, stats, _ = self._bn_bufs(u)
                     gamma, beta = P.view(u.p_gamma.name), P.view(u.p_beta.name)
                     if training:
-                        ops.conv2d_fwd(u.desc, xin, w, bias, out=u.y, stats=stats)
+                        self._conv_fwd(u, xin, w, bias, u.y, stats)
                         ops.bn_finalize(stats, u.y.numel() // u.cout, u.cout, gamma, beta,
                                         self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
                                         scale, shift, smean, sinv, unbiased=self.unbiased_moving_var)
                     else:
-                        ops.conv2d_fwd(u.desc, xin, w, bias, out=u.y)
+                        self._conv_fwd(u, xin, w, bias, u.y)
                         if not self._infer_scale_valid:
                             ops.bn_fold_inference(u.cout, gamma, beta, self.state.view(u.s_mean.name),
                                                   self.state.view(u.s_var.name), scale, shift)
                     res = self.act[u.residual.tid] if u.residual is not None else None
                     ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a)
                 else:
-                    ops.conv2d_fwd(u.desc, xin, w, bias, out=u.y)
+                    self._conv_fwd(u, xin, w, bias, u.y)
                     if u.act != ACT_LINEAR:
                         ops.act_fwd(u.y, u.act, out=u.a)
                     if u.residual is not None:
                         raise YoloHipError("residual without BN is not used by any reference graph")
             elif u.kind == "head":
                 xin = self.act[u.src.tid]
-                ops.conv2d_fwd(u.desc, xin, P.view(u.p_kernel.name), P.view(u.p_bias.name), out=u.t)
+                self._conv_fwd(u, xin, P.view(u.p_kernel.name), P.view(u.p_bias.name), u.t)
                 ops.head_act_fwd(u.t, u.A, u.C, u.version, self._anchors_dev.get(u.name), out=u.yact)
             elif u.kind == "upsample":
                 ops.upsample2x_fwd(self.act[u.src.tid], u.buf, u.out.c, 0)
@@ -493,6 +568,7 @@ class Network:
         if not self.training:
             raise YoloHipError("backward() requires a preceding forward(training=True)")
         self._refresh_wT()
+        self._refresh_wTplanes()
         grads = {}
         for t, g in zip(self.outputs, douts):
             grads[t.tid] = g
@@ -562,8 +638,17 @@ class Network:
     def _dgrad(self, grads, u, dy, wsize):
         if not self._needs_grad[u.src.tid]:
             return
-        wT = self._wT[u.wT_off:u.wT_off + wsize]
         cur = grads.get(u.src.tid)
+        if u.planes_dgrad:
+            cout = u.cout if u.kind == "conv" else u.out.c
+            dyp = ops.split_planes(dy, self.batch * u.out.h * u.out.w, cout, out=self._dyplanes)
+            wTp = self._wplanes[u.wTp_off:u.wTp_off + u.wTp_bytes]
+            if cur is None:
+                grads[u.src.tid] = ops.conv2d_dgrad_planes(u.desc, dyp, wTp)
+            else:
+                ops.conv2d_dgrad_planes(u.desc, dyp, wTp, dx=cur, accumulate=True)
+            return
+        wT = self._wT[u.wT_off:u.wT_off + wsize]
         if cur is None:
             grads[u.src.tid] = ops.conv2d_dgrad(u.desc, dy, wT)
         else:

@@ -53,6 +53,20 @@ def _conv_flops(d):
 
 import os as _os
 CONV_MODE = "fp32" if _os.environ.get("YOLO_CONV_MODE", "split")[:1] in ("f", "0") else "split"
+# engine-level choice: keep conv operands as pre-split bf16 planes and use the LDS-DMA kernels (conv_planes.hip)
+USE_PLANES = CONV_MODE == "split" and _os.environ.get("YOLO_CONV_PLANES", "1") != "0"
+
+
+def planes_fwd_ok(cin, cout):
+    return USE_PLANES and cin % 16 == 0 and cout > 32
+
+
+def planes_dgrad_ok(cin, cout):
+    return USE_PLANES and cout % 16 == 0 and cin > 32
+
+
+def _planes_variant(cout):
+    return "gather_conv_planes_kernel<128,%d,4,2>" % (64 if cout <= 64 else 128)
 
 
 def _gather_variant(cout, flat, m=None):
@@ -126,6 +140,64 @@ def conv2d_fwd(d, x, w, bias=None, out=None, stats=None):
     else:
         run()
     return out
+
+
+def planes_bytes(rows, c):
+    n = int(_lib.load().yolo_planes_bytes(int(rows), int(c)))
+    if n == 0:
+        raise YoloHipError(f"planes: unsupported shape rows={rows} C={c} (C must be a multiple of 16)")
+    return n
+
+
+def split_planes(x, rows, c, out=None):
+    """fp32 [rows][c] -> exact bf16 x 3 planes (include/yolo_hip.h: yolo_split_planes); returns a uint8 buffer"""
+    _chk_f32(x)
+    if x.numel() != rows * c:
+        raise YoloHipError("split_planes: tensor size does not match rows x C")
+    n = planes_bytes(rows, c)
+    if out is None:
+        out = torch.empty(n, device=x.device, dtype=torch.uint8)
+    elif out.numel() < n or out.dtype != torch.uint8:
+        raise YoloHipError("split_planes: output buffer too small")
+    check(_lib.load().yolo_split_planes(_p(x), int(rows), int(c), _p(out), _stream()), "yolo_split_planes")
+    return out
+
+
+def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None):
+    _chk_f32(bias)
+    if out is None:
+        out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=xp.device, dtype=torch.float32)
+    if xp.numel() < planes_bytes(d.N * d.H * d.W, d.Cin) or wp.numel() < planes_bytes(d.Cout, d.kh * d.kw * d.Cin):
+        raise YoloHipError("conv2d_fwd_planes: planes buffers do not match the descriptor")
+    if out.numel() != d.N * d.Ho * d.Wo * d.Cout:
+        raise YoloHipError("conv2d_fwd_planes: output size does not match the descriptor")
+    if stats is not None and stats.numel() != BN_STAT_SLOTS * 2 * d.Cout:
+        raise YoloHipError("conv2d_fwd_planes: stats must hold BN_STAT_SLOTS x 2 x Cout doubles")
+    def run():
+        check(_lib.load().yolo_conv2d_fwd_planes(byref(d), _p(xp), _p(wp), _p(bias), _p(out), _p(stats), _stream()),
+              "yolo_conv2d_fwd_planes")
+    if TIMER is not None:
+        TIMER.bracket(_planes_variant(d.Cout), _conv_flops(d), 1, run)
+    else:
+        run()
+    return out
+
+
+def conv2d_dgrad_planes(d, dyp, wTp, dx=None, accumulate=False):
+    if dx is None:
+        dx = torch.empty((d.N, d.H, d.W, d.Cin), device=dyp.device, dtype=torch.float32)
+        accumulate = False
+    if (dyp.numel() < planes_bytes(d.N * d.Ho * d.Wo, d.Cout) or wTp.numel() < planes_bytes(d.Cin, d.kh * d.kw * d.Cout)
+            or dx.numel() != d.N * d.H * d.W * d.Cin):
+        raise YoloHipError("conv2d_dgrad_planes: buffers do not match the descriptor")
+    def run():
+        check(_lib.load().yolo_conv2d_dgrad_planes(byref(d), _p(dyp), _p(wTp), _p(dx), int(bool(accumulate)), _stream()),
+              "yolo_conv2d_dgrad_planes")
+    if TIMER is not None:
+        TIMER.bracket(_planes_variant(d.Cin), _conv_flops(d), d.sh * d.sw, run)
+    else:
+        run()
+    return dx
 
 
 def filter_transpose(w, cout, taps, cin, out=None):
