@@ -111,6 +111,10 @@ int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_planes, const 
                            const float* bias, float* y, double* stats, void* stream);
 int yolo_conv2d_dgrad_planes(const yolo_conv_desc* d, const void* dy_planes, const void* wT_planes,
                              float* dx, int accumulate, void* stream);
+/* yolo_conv2d_wgrad on pre-split operands (dw += ..., same contract; the bias gradient stays with
+ * yolo_conv2d_wgrad_bias on the fp32 dy). Requires Cin % 16 == 0, Cout % 16 == 0, Cout >= 64, kh*kw*Cin >= 64. */
+int yolo_conv2d_wgrad_planes(const yolo_conv_desc* d, const void* x_planes, const void* dy_planes,
+                             float* dw, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * BatchNormalization (training and inference) + activation (+ residual add)

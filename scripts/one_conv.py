@@ -25,6 +25,7 @@ else:
     xp = wp = dyp = wTp = None
 fn = {"fwdp": lambda: ops.conv2d_fwd_planes(d, xp, wp, None, out=y),
       "dgradp": lambda: ops.conv2d_dgrad_planes(d, dyp, wTp, dx=dx),
+      "wgradp": lambda: ops.conv2d_wgrad_planes(d, xp, dyp, dw),
       "fwd": lambda: ops.conv2d_fwd(d, x, w, None, out=y), "dgrad": lambda: ops.conv2d_dgrad(d, dy, wT, dx=dx),
       "wgrad": lambda: ops.conv2d_wgrad(d, x, dy, dw)}[mode]
 fn(); torch.cuda.synchronize()

@@ -214,3 +214,45 @@ def test_conv_planes_rejects_unsupported_shapes():
     wp = ops.split_planes(torch.zeros(32, 288, device="cuda"), 32, 288)
     with pytest.raises(YoloHipError):
         ops.conv2d_fwd_planes(d, xp, wp)
+
+
+# Cin % 16 == 0, Cout % 16 == 0, Cout >= 64, k*k*Cin >= 64
+WGRAD_PLANES_CASES = [
+    (2, 16, 16, 32, 64, 3, 1, "same", False),         # 64 x 128 tile
+    (2, 17, 13, 32, 64, 3, 2, "darknet_s2", False),    # stride 2, odd sizes, pixel count not a multiple of 16
+    (2, 16, 16, 48, 128, 3, 2, "darknet_s2", True),    # Cin = 48: column blocks straddle taps; bias
+    (2, 7, 7, 96, 160, 3, 1, "same", False),          # Cout tail (160 = 128 + 32), column tail
+    (3, 9, 11, 256, 128, 1, 1, "valid", False),
+    (1, 2, 2, 1024, 512, 3, 1, "same", False),        # 4 pixels
+    (2, 14, 14, 64, 64, 1, 1, "same", True),          # 64 x 64 tile
+    (2, 13, 13, 64, 128, 1, 1, "same", False),        # 128 x 64 tile
+    (4, 26, 26, 128, 256, 3, 1, "same", False),       # several pixel chunks (split-K) per tile
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_PLANES_CASES)
+def test_conv_wgrad_planes(case):
+    from tf2_yolo_amd import ops
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=12)
+    wk.requires_grad_(True)
+    if b is not None:
+        b.requires_grad_(True)
+    ref = L.conv2d(x, wk, b, stride=s, padding=pad)
+    g = torch.Generator().manual_seed(13)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    xp = ops.split_planes(x.float().cuda(), n * h * w, cin)
+    dyd = dy.float().cuda()
+    dyp = ops.split_planes(dyd, n * d.Ho * d.Wo, cout)
+    dw = torch.zeros(cout, k, k, cin, device="cuda")
+    db = torch.zeros(cout, device="cuda") if bias else None
+    ops.conv2d_wgrad_planes(d, xp, dyp, dw, dy=dyd, dbias=db)
+    torch.cuda.synchronize()
+    assert _relerr(dw.double().cpu(), _krsc(wk.grad)) < TOL
+    if bias:
+        assert _relerr(db.double().cpu(), b.grad) < TOL
+    ops.conv2d_wgrad_planes(d, xp, dyp, dw)       # accumulates: dw += ...
+    torch.cuda.synchronize()
+    assert _relerr(dw.double().cpu(), 2 * _krsc(wk.grad)) < TOL

@@ -50,6 +50,7 @@ SIGNATURES = {
     "yolo_split_planes": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_conv2d_fwd_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "yolo_conv2d_dgrad_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P]),
+    "yolo_conv2d_wgrad_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P]),
     "yolo_bn_stats": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_bn_finalize": (c_int, [_P, _LL, c_int, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "yolo_bn_fold_inference": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),

@@ -844,14 +844,7 @@ extern "C" int yolo_conv2d_dgrad_planes(const yolo_conv_desc* d, const void* dy_
                     accumulate, stream, true);
 }
 
-extern "C" int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
-                                 void* stream) {
-  if (int rc = validate_desc(d)) return rc;
-  YOLO_REQUIRE(x && dy && dw, "conv_wgrad: null pointer");
-  WgradArgs a{};
-  a.src = x;
-  a.dy = dy;
-  a.dw = dw;
+static void fill_wgrad_args(const yolo_conv_desc* d, WgradArgs& a) {
   a.N = d->N; a.Hs = d->H; a.Ws = d->W; a.Cs = d->Cin;
   a.Hg = d->Ho; a.Wg = d->Wo;
   a.sy = d->sh; a.sx = d->sw;
@@ -860,6 +853,31 @@ extern "C" int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const 
   a.ntaps = d->kh * d->kw;
   a.kw = d->kw; a.pad_t = d->pad_t; a.pad_l = d->pad_l;
   a.M = (long long)d->N * d->Ho * d->Wo;
+}
+
+extern "C" int yolo_conv2d_wgrad_planes(const yolo_conv_desc* d, const void* x_planes, const void* dy_planes, float* dw,
+                                        void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x_planes && dy_planes && dw, "conv_wgrad_planes: null pointer");
+  WgradArgs a{};
+  a.src = reinterpret_cast<const float*>(x_planes);
+  a.dy = reinterpret_cast<const float*>(dy_planes);
+  a.dw = dw;
+  fill_wgrad_args(d, a);
+  YOLO_REQUIRE(wgrad_planes_supported(a),
+               "conv_wgrad_planes: needs Cin %% 16 == 0, Cout %% 16 == 0, Cout >= 64 and kh*kw*Cin >= 64");
+  return launch_wgrad_planes(a, as_stream(stream));
+}
+
+extern "C" int yolo_conv2d_wgrad(const yolo_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                 void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x && dy && dw, "conv_wgrad: null pointer");
+  WgradArgs a{};
+  a.src = x;
+  a.dy = dy;
+  a.dw = dw;
+  fill_wgrad_args(d, a);
   const bool ascalar = (d->Cout % 4) != 0;
   const bool bflat = (d->Cin % 4) != 0;
   int rc;

@@ -58,6 +58,9 @@ struct WgradArgs {
   int kw, pad_t, pad_l;
   int tiles_co, tiles_j;
   long long chunk;  // pixels per split (multiple of 32)
+  // planes kernel (conv_wgrad_planes.hip): src / dy point to bf16 planes
+  unsigned src_bytes, dy_bytes;
+  int zero_blk_src, zero_blk_dy;
 };
 
 // conv_split.hip
@@ -68,6 +71,9 @@ long long planes_bytes(long long rows, int C);
 int launch_split_planes(const float* x, long long rows, int C, void* planes, hipStream_t st);
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st);
 bool gather_planes_supported(const GatherConvArgs& a);
+// conv_wgrad_planes.hip
+int launch_wgrad_planes(WgradArgs& a, hipStream_t st);
+bool wgrad_planes_supported(const WgradArgs& a);
 // conv_wgrad_split.hip
 int launch_wgrad_split(WgradArgs& a, hipStream_t st);
 bool wgrad_split_supported(const WgradArgs& a);

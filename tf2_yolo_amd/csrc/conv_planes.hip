@@ -14,18 +14,11 @@
 // (row r, half hf) the LDS image of a 32-row block IS the fragment: reads are linear ds_read_b128
 // (conflict-free), while adjacent lanes = adjacent rows fetch adjacent 16-byte units of one 256-byte
 // sub-block, i.e. whole cache lines (a row-major planes layout cannot have both).
-#include "conv_args.hpp"
+#include "planes.hpp"
 #include <cstdlib>
 #include <type_traits>
 
 namespace yolo {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int PL_RECORD = 1536;  // bytes per (16-row block, 16-channel block)
 
 struct Planes8 {
   u32x4 h, m, l;  // 8 bf16 each
@@ -77,19 +70,6 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   *reinterpret_cast<u32x4*>(o) = s.h;
   *reinterpret_cast<u32x4*>(o + 512) = s.m;
   *reinterpret_cast<u32x4*>(o + 1024) = s.l;
-}
-
-// LDS-DMA: 64 lanes x 16 bytes from buffer offset (voff + soff) to LDS bytes [lds, lds + 1024).
-// Invisible to hipcc's s_waitcnt bookkeeping: completion is counted by hand (vmcnt) in the kernel.
-__device__ __forceinline__ void dma16(const i32x4 rsrc, const unsigned voff, const unsigned soff, const unsigned lds) {
-  // M0 = LDS destination; nothing else in these kernels uses M0, so it is not saved
-  asm volatile(
-      "s_mov_b32 m0, %3\n\t"
-      "s_nop 0\n\t"
-      "buffer_load_dwordx4 %0, %1, %2 offen lds"
-      :
-      : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds)
-      : "memory");
 }
 
 // Workgroup tile BM x BN, NW = WGM*WGN waves; every wave is also the loader of ONE 32-row block of
@@ -151,11 +131,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   const unsigned blkstrideA = (unsigned)((a.Cs >> 4) * PL_RECORD);
   const void* pbase = loadA ? (const void*)a.src : (const void*)a.wgt;
   const unsigned pbytes = loadA ? a.src_bytes : a.wgt_bytes;
-  // raw buffer descriptor: base, stride 0, num_records = bytes, DATA_FORMAT = 32 (raw, bounds-checked)
-  const unsigned long long pb = (unsigned long long)(size_t)pbase;
-  const i32x4 rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)pb),
-                      __builtin_amdgcn_readfirstlane((int)(unsigned)(pb >> 32) & 0xFFFF),
-                      __builtin_amdgcn_readfirstlane((int)pbytes), 0x00020000};
+  const i32x4 rsrc = planes_rsrc(pbase, pbytes);
   const unsigned lds_mine = lds_base + ((loadA ? 0 : RBA) + rb) * 3 * 1024;
 
   const int cpt = a.Cs >> 4;  // stages per tap

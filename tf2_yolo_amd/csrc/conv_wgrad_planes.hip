@@ -1,0 +1,289 @@
+// Filter gradient on pre-split operands ("planes" format, conv_planes.hip) staged by LDS-DMA:
+//   dW[co][j] += sum_p dy[p][co] * x[p -> tap(j)][c(j)],  j = tap*Cin + c,
+// rows = co, columns = flattened (tap, c), contraction over pixels in 16-pixel stages, split over
+// grid.y and combined with fp32 atomics (as wgrad_split_kernel). Both operands are pixel-major, the
+// MFMA wants 8 consecutive pixels per lane: the fragments come from the transposing LDS read
+// ds_read_b64_tr_b16, which per 16-lane group turns a 4(pixel) x 16(channel) block into "4 pixels of MY
+// channel" -- and a 256-byte sub-block of the planes format IS a 16(pixel) x 8(channel) matrix.
+//
+// One DMA piece (64 lanes x 16 B = 1 KiB) = 16 pixels x 32 channels of one plane = 4 sub-blocks.
+// Lane l fetches the unit (pixel 4*(l>>4) + (l&3), sub-block (l>>2)&3): quads of lanes read 64 contiguous
+// bytes (4 pixels of a sub-block), and the lane-linear LDS image [pixel quad][sub-block][pixel] puts the
+// 16 units a 32-lane transposed read touches (4 sub-blocks x 4 pixels) on 16 distinct 16-byte bank
+// groups: conflict-free. Same wave roles, ring of 3 stage buffers, 2 fragment register sets and barrier /
+// vmcnt discipline as gather_conv_planes_kernel.
+#include "planes.hpp"
+#include <type_traits>
+
+namespace yolo {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const WgradArgs a) {
+  constexpr int NW = WGM * WGN;
+  constexpr int TM = BM / WGM / 32;
+  constexpr int TN = BN / WGN / 32;
+  constexpr int RBA = BM / 32, RBB = BN / 32;
+  static_assert(RBA + RBB <= NW, "at least one loader wave per 32-channel block");
+  constexpr int STAGE_BYTES = (RBA + RBB) * 3 * 1024;
+  constexpr int NBUF = 3;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds_base = (unsigned)(size_t)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+
+  const int tile_co = blockIdx.x % a.tiles_co;
+  const int j0 = (blockIdx.x / a.tiles_co) * BN;
+  const int co0 = tile_co * BM;
+  const long long p_begin = (long long)blockIdx.y * a.chunk;   // multiple of 16
+  long long p_end = p_begin + a.chunk;
+  if (p_end > a.M) p_end = a.M;
+  if (p_begin >= p_end) return;
+  const int nk = (int)((p_end - p_begin + 15) / 16);
+  const int Ktot = a.ntaps * a.Cs;
+
+  // ---- loader role: lane -> (pixel of the stage, sub-block of the 32-channel block) ----
+  const bool loadA = wave < RBA;
+  const int rb = loadA ? wave : (wave - RBA) % RBB;
+  const int lpix = 4 * (lane >> 4) + (lane & 3);
+  const int lsb = (lane >> 2) & 3;
+  const unsigned strideA = (unsigned)((a.Cout >> 4) * PL_RECORD);   // bytes per 16-pixel block of dy planes
+  const unsigned strideB = (unsigned)((a.Cs >> 4) * PL_RECORD);
+  const unsigned zeroA = (unsigned)a.zero_blk_dy * strideA, zeroB = (unsigned)a.zero_blk_src * strideB;
+  const i32x4 rsrc = planes_rsrc(loadA ? (const void*)a.dy : (const void*)a.src, loadA ? a.dy_bytes : a.src_bytes);
+  const unsigned lds_mine = lds_base + ((loadA ? 0 : RBA) + rb) * 3 * 1024;
+
+  // A (dy): unit (pixel block, 16-channel block co16, half, pixel); advances one pixel block per stage
+  bool lane_ok;
+  unsigned ld_voff;
+  // B (x): column block -> (tap, 16-channel block), pixel decoded incrementally
+  int b_oy = 0, b_ox = 0, b_chan = 0;
+  int pn = 0, py = 0, px = 0;
+  long long pcur = p_begin + lpix;
+  if (loadA) {
+    const int co16 = ((co0 + rb * 32) >> 4) + (lsb >> 1);
+    lane_ok = co16 * 16 < a.Cout;
+    ld_voff = lane_ok ? (unsigned)(p_begin >> 4) * strideA + (unsigned)co16 * PL_RECORD + (lsb & 1) * 256 + lpix * 16 : zeroA;
+  } else {
+    const int j16 = ((j0 + rb * 32) >> 4) + (lsb >> 1);
+    lane_ok = j16 * 16 < Ktot;
+    const int cpt = a.Cs >> 4;
+    const int t = lane_ok ? j16 / cpt : 0;
+    const int r = t / a.kw;
+    b_oy = r - a.pad_t;
+    b_ox = (t - r * a.kw) - a.pad_l;
+    b_chan = (j16 - t * cpt) * PL_RECORD + (lsb & 1) * 256;
+    const int HgWg = a.Hg * a.Wg;
+    const long long pp = pcur < a.M ? pcur : 0;
+    pn = (int)(pp / HgWg);
+    const int rem = (int)(pp - (long long)pn * HgWg);
+    py = rem / a.Wg;
+    px = rem - py * a.Wg;
+    ld_voff = zeroB;
+  }
+  int ld_stage = 0;  // stage the loader will issue next
+
+  auto loader_addr = [&]() {   // B only: source unit of this lane's pixel for the stage about to be issued
+    const int ys = py * a.sy + b_oy, xs = px * a.sx + b_ox;
+    const bool ok = lane_ok && (ld_stage < nk) && (pcur < p_end) && ((unsigned)ys < (unsigned)a.Hs) &&
+                    ((unsigned)xs < (unsigned)a.Ws);
+    const int s = (pn * a.Hs + ys) * a.Ws + xs;
+    ld_voff = ok ? ((unsigned)s >> 4) * strideB + (s & 15) * 16 + b_chan : zeroB;
+  };
+  auto loader_next = [&]() {
+    ++ld_stage;
+    if (loadA) {
+      if (ld_stage >= nk) ld_voff = zeroA;
+      else if (lane_ok) ld_voff += strideA;
+    } else {
+      pcur += 16;
+      px += 16;
+      while (px >= a.Wg) {
+        px -= a.Wg;
+        ++py;
+      }
+      while (py >= a.Hg) {
+        py -= a.Hg;
+        ++pn;
+      }
+      loader_addr();
+    }
+  };
+  auto issue_plane = [&](int p, int buf) {
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_mine + buf * STAGE_BYTES + p * 1024);
+    dma16(rsrc, ld_voff, (unsigned)(p * 512), l);
+  };
+  auto issue_stage = [&](int buf) {
+    issue_plane(0, buf);
+    issue_plane(1, buf);
+    issue_plane(2, buf);
+    loader_next();
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  // transposed fragment reads: 16-lane group g -> channel half g&1, pixel half g>>1; lane (qq, pp) of the
+  // group supplies pixel qq, channels 4pp..4pp+3 of the half (sub-block (g&1)*2 + (pp>>1))
+  const int grp = lane >> 4, i16 = lane & 15;
+  const int qq = i16 >> 2, pq = i16 & 3;
+  const int tr_off = ((2 * (grp >> 1)) * 16 + ((grp & 1) * 2 + (pq >> 1)) * 4 + qq) * 16 + (pq & 1) * 8;
+  typedef s16x4 __attribute__((address_space(3))) * lds_p;
+  auto tr_frag = [&](const unsigned char* piece) -> bf16x8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(piece + tr_off));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(piece + tr_off + 256));
+    const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  bf16x8 fa[2][3][TM], fb[2][3][TN];
+  auto read_frags = [&](int buf, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    const unsigned char* sb = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[S][p][i] = tr_frag(sb + ((wm * TM + i) * 3 + p) * 1024);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[S][p][j] = tr_frag(sb + ((RBA + wn * TN + j) * 3 + p) * 1024);
+    }
+  };
+  auto mfma_stage = [&](auto SET, int wbuf) {
+    constexpr int S = decltype(SET)::value;
+    constexpr int NM = TM * TN * 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      // q: (A plane, B plane) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+      const int pa = (q == 0) ? 2 : (q == 2 || q == 3) ? 1 : 0;
+      const int pb = (q == 1) ? 2 : (q == 2 || q == 4) ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
+          const int idx = (q * TM + i) * TN + j;
+          if (idx == NM / 4 - 1 || idx == NM / 2 - 1 || idx == (3 * NM) / 4 - 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_plane(idx == NM / 4 - 1 ? 0 : idx == NM / 2 - 1 ? 1 : 2, wbuf);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+    }
+    loader_next();
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+
+  if (!loadA) loader_addr();
+  issue_stage(0);
+  issue_stage(1);
+  issue_stage(2);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  read_frags(0, S0{});
+
+  auto step = [&](int rbuf, int wbuf, auto CUR, auto NXT) {
+    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // my pieces of the next stage have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of the current stage's buffer are done
+    __builtin_amdgcn_s_barrier();
+    read_frags(rbuf, NXT);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_stage(CUR, wbuf);
+  };
+  {
+    int rbuf = 1, wbuf = 0;
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+      step(rbuf, wbuf, S0{}, S1{});
+      rbuf = (rbuf + 1 == NBUF) ? 0 : rbuf + 1;
+      wbuf = (wbuf + 1 == NBUF) ? 0 : wbuf + 1;
+      step(rbuf, wbuf, S1{}, S0{});
+      rbuf = (rbuf + 1 == NBUF) ? 0 : rbuf + 1;
+      wbuf = (wbuf + 1 == NBUF) ? 0 : wbuf + 1;
+    }
+    if (kt < nk) step(rbuf, wbuf, S0{}, S1{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy tail DMAs too
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cj = j0 + (wn * TN + j) * 32 + (lane & 31);
+    const bool cok = cj < Ktot;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (cok && co < a.Cout) atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[i][j][r]);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+static int launch_wp(WgradArgs& a, hipStream_t st) {
+  a.tiles_co = (a.Cout + BM - 1) / BM;
+  const int cols = a.ntaps * a.Cs;
+  a.tiles_j = (cols + BN - 1) / BN;
+  const long long tiles = (long long)a.tiles_co * a.tiles_j;
+  // split the pixel contraction so that the grid has ~2 rounds of (2 workgroups x 256 CUs)
+  long long splits = (1024 + tiles - 1) / tiles;
+  const long long max_splits = (a.M + 255) / 256;  // at least 16 stages per workgroup
+  if (splits > max_splits) splits = max_splits;
+  if (splits > 65535) splits = 65535;
+  if (splits < 1) splits = 1;
+  long long chunk = (a.M + splits - 1) / splits;
+  chunk = (chunk + 15) / 16 * 16;
+  splits = (a.M + chunk - 1) / chunk;
+  a.chunk = chunk;
+  if (tiles > 0x7fffffffLL || splits > 65535) {
+    set_error("wgrad(planes): bad grid %lld x %lld", tiles, splits);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  constexpr size_t lds = 3 * (BM / 32 + BN / 32) * 3 * 1024;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((wgrad_planes_kernel<BM, BN, WGM, WGN>), dim3((unsigned)tiles, (unsigned)splits),
+                     dim3(64 * WGM * WGN), lds, st, a);
+  return check_launch("wgrad_planes_kernel");
+}
+
+bool wgrad_planes_supported(const WgradArgs& a) {
+  return (a.Cout % 16) == 0 && (a.Cs % 16) == 0 && a.Cout >= 64 && a.ntaps * a.Cs >= 64;
+}
+
+int launch_wgrad_planes(WgradArgs& a, hipStream_t st) {
+  const long long rowsX = (long long)a.N * a.Hs * a.Ws;
+  const long long bytesX = planes_bytes(rowsX, a.Cs), bytesDy = planes_bytes(a.M, a.Cout);
+  if (bytesX >= (1LL << 32) || bytesDy >= (1LL << 32)) {
+    set_error("wgrad(planes): operand planes exceed 4 GiB (%lld, %lld bytes)", bytesX, bytesDy);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  a.src_bytes = (unsigned)bytesX;
+  a.dy_bytes = (unsigned)bytesDy;
+  a.zero_blk_src = (int)((rowsX + 15) / 16);
+  a.zero_blk_dy = (int)((a.M + 15) / 16);
+  const int cols = a.ntaps * a.Cs;
+  if (a.Cout <= 64 && cols <= 64) return launch_wp<64, 64, 2, 2>(a, st);
+  if (a.Cout <= 64) return launch_wp<64, 128, 2, 4>(a, st);
+  if (cols <= 64) return launch_wp<128, 64, 4, 2>(a, st);
+  return launch_wp<128, 128, 4, 2>(a, st);
+}
+
+}  // namespace yolo

@@ -311,6 +311,7 @@ class Network:
             k = u.k if u.kind == "conv" else 1
             u.planes_fwd = ops.planes_fwd_ok(u.src.c, cout)
             u.planes_dgrad = ops.planes_dgrad_ok(u.src.c, cout) and self._needs_grad[u.src.tid]
+            u.planes_wgrad = u.planes_fwd and ops.planes_wgrad_ok(u.src.c, cout, k * k, u.stride if u.kind == "conv" else 1)
             u.wp_off = u.wTp_off = -1
             if u.planes_fwd:
                 u.wp_off, u.wp_bytes = wp, ops.planes_bytes(cout, k * k * u.src.c)
@@ -411,7 +412,7 @@ class Network:
             if u.planes_fwd and u.src.tid not in self._xplanes:
                 self._xplanes[u.src.tid] = torch.empty(ops.planes_bytes(N * u.src.h * u.src.w, u.src.c), device=dev,
                                                        dtype=torch.uint8)
-            if u.planes_dgrad:
+            if u.planes_dgrad or u.planes_wgrad:
                 dyp = max(dyp, ops.planes_bytes(N * u.out.h * u.out.w, u.cout if u.kind == "conv" else u.out.c))
         self._dyplanes = torch.empty(dyp, device=dev, dtype=torch.uint8) if dyp else None
         self._xp_valid = set()
@@ -587,14 +588,24 @@ class Network:
                                         sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta))
                 else:
                     dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
-                ops.conv2d_wgrad(u.desc, xin, dy, self._gview(u.p_kernel),
-                                 self._gview(u.p_bias) if u.p_bias is not None else None)
-                self._dgrad(grads, u, dy, u.cout * u.k * u.k * u.src.c)
+                dyp = self._dyp(u, dy)
+                if u.planes_wgrad:
+                    ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dyp, self._gview(u.p_kernel), dy=dy,
+                                            dbias=self._gview(u.p_bias) if u.p_bias is not None else None)
+                else:
+                    ops.conv2d_wgrad(u.desc, xin, dy, self._gview(u.p_kernel),
+                                     self._gview(u.p_bias) if u.p_bias is not None else None)
+                self._dgrad(grads, u, dy, u.cout * u.k * u.k * u.src.c, dyp)
             elif u.kind == "head":
                 xin = self.act[u.src.tid]
                 dt = ops.head_act_bwd(u.yact, dout, u.A, u.C, u.version, self._anchors_dev.get(u.name))
-                ops.conv2d_wgrad(u.desc, xin, dt, self._gview(u.p_kernel), self._gview(u.p_bias))
-                self._dgrad(grads, u, dt, u.out.c * u.src.c)
+                dtp = self._dyp(u, dt)
+                if u.planes_wgrad:
+                    ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dtp, self._gview(u.p_kernel), dy=dt,
+                                            dbias=self._gview(u.p_bias))
+                else:
+                    ops.conv2d_wgrad(u.desc, xin, dt, self._gview(u.p_kernel), self._gview(u.p_bias))
+                self._dgrad(grads, u, dt, u.out.c * u.src.c, dtp)
             elif u.kind == "upsample":
                 if self._needs_grad[u.src.tid]:
                     cur = grads.get(u.src.tid)
@@ -635,13 +646,18 @@ class Network:
             if self.grad_ready_hook is not None and u.kind in ("conv", "head"):
                 self.grad_ready_hook(u)
 
-    def _dgrad(self, grads, u, dy, wsize):
+    def _dyp(self, u, dy):
+        """planes of this layer's dy (one scratch, consumed by the filter and data gradients right away)"""
+        if not (u.planes_wgrad or u.planes_dgrad):
+            return None
+        cout = u.cout if u.kind == "conv" else u.out.c
+        return ops.split_planes(dy, self.batch * u.out.h * u.out.w, cout, out=self._dyplanes)
+
+    def _dgrad(self, grads, u, dy, wsize, dyp=None):
         if not self._needs_grad[u.src.tid]:
             return
         cur = grads.get(u.src.tid)
         if u.planes_dgrad:
-            cout = u.cout if u.kind == "conv" else u.out.c
-            dyp = ops.split_planes(dy, self.batch * u.out.h * u.out.w, cout, out=self._dyplanes)
             wTp = self._wplanes[u.wTp_off:u.wTp_off + u.wTp_bytes]
             if cur is None:
                 grads[u.src.tid] = ops.conv2d_dgrad_planes(u.desc, dyp, wTp)

@@ -65,6 +65,16 @@ def planes_dgrad_ok(cin, cout):
     return USE_PLANES and cout % 16 == 0 and cin > 32
 
 
+def planes_wgrad_ok(cin, cout, taps, stride=1):
+    # (stride-2 layers gather every second source pixel: the register-staged kernel is faster there)
+    return USE_PLANES and stride == 1 and cin % 16 == 0 and cout % 16 == 0 and cout >= 64 and taps * cin >= 64
+
+
+def _wgrad_planes_variant(cout, cols):
+    return "wgrad_planes_kernel<%d,%d,%s>" % (64 if cout <= 64 else 128, 64 if cols <= 64 else 128,
+                                             "2,2" if (cout <= 64 and cols <= 64) else "2,4" if cout <= 64 else "4,2")
+
+
 def _planes_variant(cout):
     return "gather_conv_planes_kernel<128,%d,4,2>" % (64 if cout <= 64 else 128)
 
@@ -198,6 +208,28 @@ def conv2d_dgrad_planes(d, dyp, wTp, dx=None, accumulate=False):
     else:
         run()
     return dx
+
+
+def conv2d_wgrad_planes(d, xp, dyp, dw, dy=None, dbias=None):
+    """dw += filter gradient from pre-split x / dy planes; dbias (optional) needs the fp32 dy"""
+    _chk_f32(dw, dy, dbias)
+    if dw.numel() != d.Cout * d.kh * d.kw * d.Cin:
+        raise YoloHipError("conv2d_wgrad_planes: dw size does not match the descriptor")
+    if xp.numel() < planes_bytes(d.N * d.H * d.W, d.Cin) or dyp.numel() < planes_bytes(d.N * d.Ho * d.Wo, d.Cout):
+        raise YoloHipError("conv2d_wgrad_planes: planes buffers do not match the descriptor")
+    def run():
+        check(_lib.load().yolo_conv2d_wgrad_planes(byref(d), _p(xp), _p(dyp), _p(dw), _stream()),
+              "yolo_conv2d_wgrad_planes")
+    if TIMER is not None:
+        TIMER.bracket(_wgrad_planes_variant(d.Cout, d.kh * d.kw * d.Cin), _conv_flops(d), 1, run)
+    else:
+        run()
+    if dbias is not None:
+        if dy is None:
+            raise YoloHipError("conv2d_wgrad_planes: dbias needs the fp32 dy")
+        check(_lib.load().yolo_conv2d_wgrad_bias(_p(dy), d.N * d.Ho * d.Wo, d.Cout, _p(dbias), _stream()),
+              "yolo_conv2d_wgrad_bias")
+    return dw
 
 
 def filter_transpose(w, cout, taps, cin, out=None):
