@@ -165,6 +165,17 @@ int yolo_bn_act_bwd_apply(const float* x, const float* dout, long long P, int C,
                           int act, double* red, float* dgamma, float* dbeta,
                           float* dx, void* stream);
 
+/* yolo_bn_act_fwd / yolo_bn_act_bwd_apply that ALSO emit their result in the conv kernels' "planes"
+ * operand format (yolo_planes_bytes(P, C) bytes, C % 16 == 0), so that the consumer convolutions need no
+ * yolo_split_planes pass. planes == NULL: plain forms. yolo_bn_act_bwd_apply_planes: dx may be NULL when
+ * only the planes are wanted. */
+int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scale, const float* shift,
+                           int act, const float* residual, float* out, void* planes, void* stream);
+int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, long long P, int C, const float* gamma,
+                                 const float* scale, const float* shift, const float* save_mean,
+                                 const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,
+                                 float* dx, void* planes, void* stream);
+
 /* plain activation (no BN) forward / backward on [n] elements; used by conv(+bias)+act
  * units without BN, if any */
 int yolo_act_fwd(const float* x, long long n, int act, float* out, void* stream);

@@ -5,7 +5,7 @@
 // Replaces BatchNormalization + LeakyReLU / Mish (+ Add) of
 //   yolov3/models/backbone.py:39-71, yolov4/models/backbone.py:22-37,76-123,
 //   yolov{1_5,2}/models/backbone.py:9-18.
-#include "common.hpp"
+#include "planes.hpp"
 
 namespace yolo {
 
@@ -237,6 +237,138 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
   }
 }
 
+// ---- column-fixed forms (C % 8 == 0): a thread owns one 8-channel group for a run of rows, so the
+// per-channel coefficients live in registers (the generic kernels above re-load them and take a 64-bit
+// modulo per element: 128 B of parameter loads per 16 B of data). Optionally the result is also written
+// in the "planes" operand format of the conv kernels (conv_planes.hip) -- exact 3-way bf16 split, one
+// 16-byte unit per plane per thread -- so the consumer convolutions need no separate split pass. Rows in
+// [P, rows_padded) of the planes (block tail + the all-zero block) are zero-filled here. ----
+// Thread mapping: a wave owns one 32-channel quad (4 groups of 8 channels) and walks 16-row blocks; lane =
+// row-in-block + 16 * group-in-quad. Every fp32 load/store instruction of the wave then touches 16 rows x
+// 128 contiguous bytes, and every planes store writes 4 whole 256-byte sub-blocks (16 rows x 16 B).
+// C % 32 != 0 (C = 16 * odd) leaves the last quad half empty.
+struct RowGeom {
+  int wpr;            // waves side by side along the channels in one workgroup (1, 2 or 4)
+  unsigned gx, gy;
+  long long blocks_per_wg;  // 16-row blocks each wave row-slot walks
+};
+static inline RowGeom row_geom(long long rows, int C) {
+  RowGeom g;
+  const int quads = (C + 31) / 32;
+  g.wpr = quads >= 4 ? 4 : quads >= 2 ? 2 : 1;
+  g.gy = (unsigned)((quads + g.wpr - 1) / g.wpr);
+  const long long rblocks = (rows + 15) / 16;
+  const int slots = 4 / g.wpr;                       // row-block slots per workgroup pass
+  long long per = (rblocks + 2047) / 2048;           // <= ~2048 workgroups along the rows
+  if (per < 2 * slots) per = 2 * slots;
+  per = (per + slots - 1) / slots * slots;
+  g.blocks_per_wg = per;
+  g.gx = (unsigned)((rblocks + per - 1) / per);
+  return g;
+}
+
+__device__ __forceinline__ void store_planes8(unsigned char* planes, long long row, int g8, int C, const f32x4 v0,
+                                              const f32x4 v1) {
+  const Planes8 s = split8(v0, v1);
+  unsigned char* o = planes + planes_unit_offset(row, g8, C);
+  *reinterpret_cast<u32x4*>(o) = s.h;
+  *reinterpret_cast<u32x4*>(o + 512) = s.m;
+  *reinterpret_cast<u32x4*>(o + 1024) = s.l;
+}
+
+template <bool PLANES>
+__global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restrict__ x, long long P, int C, int wpr,
+                                                          long long blocks_per_wg, long long rows_total,
+                                                          const float* __restrict__ scale,
+                                                          const float* __restrict__ shift, int act,
+                                                          const float* __restrict__ res, float* __restrict__ out,
+                                                          unsigned char* __restrict__ planes) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g8 = (blockIdx.y * wpr + wave % wpr) * 4 + (lane >> 4);
+  if (g8 >= (C >> 3)) return;
+  const int slots = 4 / wpr;
+  const f32x4 sc0 = reinterpret_cast<const f32x4*>(scale)[2 * g8], sc1 = reinterpret_cast<const f32x4*>(scale)[2 * g8 + 1];
+  const f32x4 sh0 = reinterpret_cast<const f32x4*>(shift)[2 * g8], sh1 = reinterpret_cast<const f32x4*>(shift)[2 * g8 + 1];
+  const long long rb_lo = (long long)blockIdx.x * blocks_per_wg;
+  long long p_hi = (rb_lo + blocks_per_wg) * 16;
+  if (p_hi > rows_total) p_hi = rows_total;
+#pragma unroll 2
+  for (long long p = (rb_lo + wave / wpr) * 16 + (lane & 15); p < p_hi; p += 16 * slots) {
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    if (p < P) {
+      const long long e = p * C + g8 * 8;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + e), x1 = *reinterpret_cast<const f32x4*>(x + e + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        o0[k] = act_fwd(fmaf(sc0[k], x0[k], sh0[k]), act);
+        o1[k] = act_fwd(fmaf(sc1[k], x1[k], sh1[k]), act);
+      }
+      if (res != nullptr) {
+        o0 += *reinterpret_cast<const f32x4*>(res + e);
+        o1 += *reinterpret_cast<const f32x4*>(res + e + 4);
+      }
+      *reinterpret_cast<f32x4*>(out + e) = o0;
+      *reinterpret_cast<f32x4*>(out + e + 4) = o1;
+    }
+    if (PLANES) store_planes8(planes, p, g8, C, o0, o1);
+  }
+}
+
+// dx = scale * (dz - mean(dz) - xhat * mean(dz * xhat)),  dz = dout * act'(scale*x + shift)
+//    = scale*dz + B*(x - mean) + K  with per-channel B = -scale*invstd*mean(dz*xhat), K = -scale*mean(dz)
+// (x - mean is formed first, as in the generic kernel: no cancellation between B*x and B*mean)
+template <bool PLANES, bool WRITE_DX>
+__global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dout, long long P, int C,
+                                                            int wpr, long long blocks_per_wg, long long rows_total,
+                                                            double invP, const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ smean,
+                                                            const float* __restrict__ sinv, int act,
+                                                            const double* __restrict__ red, float* __restrict__ dx,
+                                                            unsigned char* __restrict__ planes) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g8 = (blockIdx.y * wpr + wave % wpr) * 4 + (lane >> 4);
+  if (g8 >= (C >> 3)) return;
+  const int slots = 4 / wpr;
+  float sc[8], sh[8], mu[8], cb[8], ck[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = g8 * 8 + k;
+    sc[k] = scale[c];
+    sh[k] = shift[c];
+    mu[k] = smean[c];
+    const float mdz = (float)(red[c] * invP);
+    const float mdzx = (float)(red[C + c] * invP);
+    cb[k] = -sc[k] * sinv[c] * mdzx;
+    ck[k] = -sc[k] * mdz;
+  }
+  const long long rb_lo = (long long)blockIdx.x * blocks_per_wg;
+  long long p_hi = (rb_lo + blocks_per_wg) * 16;
+  if (p_hi > rows_total) p_hi = rows_total;
+#pragma unroll 2
+  for (long long p = (rb_lo + wave / wpr) * 16 + (lane & 15); p < p_hi; p += 16 * slots) {
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    if (p < P) {
+      const long long e = p * C + g8 * 8;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + e), x1 = *reinterpret_cast<const f32x4*>(x + e + 4);
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(dout + e), d1 = *reinterpret_cast<const f32x4*>(dout + e + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dz0 = d0[k] * act_grad(fmaf(sc[k], x0[k], sh[k]), act);
+        const float dz1 = d1[k] * act_grad(fmaf(sc[4 + k], x1[k], sh[4 + k]), act);
+        o0[k] = fmaf(sc[k], dz0, fmaf(cb[k], x0[k] - mu[k], ck[k]));
+        o1[k] = fmaf(sc[4 + k], dz1, fmaf(cb[4 + k], x1[k] - mu[4 + k], ck[4 + k]));
+      }
+      if (WRITE_DX) {
+        *reinterpret_cast<f32x4*>(dx + e) = o0;
+        *reinterpret_cast<f32x4*>(dx + e + 4) = o1;
+      }
+    }
+    if (PLANES) store_planes8(planes, p, g8, C, o0, o1);
+  }
+}
+
 // red layout: [SLOTS replicas][2][C] followed by the final [2][C] sums
 __global__ void bn_bwd_sum_kernel(int C, double* __restrict__ red) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 2C
@@ -265,8 +397,8 @@ __global__ void act_bwd_kernel(const float* __restrict__ x, const float* __restr
 }
 
 static int reduce_grid_x(long long P, int rpp) {
-  long long g = (P + (long long)rpp * 32 - 1) / ((long long)rpp * 32);  // >= 32 rows per thread
-  if (g > 1024) g = 1024;
+  long long g = (P + (long long)rpp * 16 - 1) / ((long long)rpp * 16);  // >= 16 rows per thread
+  if (g > 2048) g = 2048;
   if (g < 1) g = 1;
   return (int)g;
 }
@@ -304,15 +436,33 @@ extern "C" int yolo_bn_fold_inference(int C, const float* gamma, const float* be
   return check_launch("bn_fold_kernel");
 }
 
-extern "C" int yolo_bn_act_fwd(const float* x, long long P, int C, const float* scale, const float* shift, int act,
-                               const float* residual, float* out, void* stream) {
+extern "C" int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scale, const float* shift,
+                                      int act, const float* residual, float* out, void* planes, void* stream) {
   YOLO_REQUIRE(x && scale && shift && out && P > 0 && C > 0, "bn_act_fwd: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_fwd: C=%d must be a multiple of 4", C);
   YOLO_REQUIRE(act >= 0 && act <= 2, "bn_act_fwd: bad activation %d", act);
+  YOLO_REQUIRE(planes == nullptr || C % 16 == 0, "bn_act_fwd: planes output needs C %% 16 == 0 (C=%d)", C);
+  if (C % 8 == 0) {
+    const long long rows = planes ? ((P + 15) / 16 + 1) * 16 : P;
+    const RowGeom g = row_geom(rows, C);
+    if (planes)
+      hipLaunchKernelGGL(bn_act_fwd8_kernel<true>, dim3(g.gx, g.gy), dim3(256), 0, as_stream(stream), x, P, C, g.wpr,
+                         g.blocks_per_wg, rows, scale, shift, act, residual, out,
+                         reinterpret_cast<unsigned char*>(planes));
+    else
+      hipLaunchKernelGGL(bn_act_fwd8_kernel<false>, dim3(g.gx, g.gy), dim3(256), 0, as_stream(stream), x, P, C, g.wpr,
+                         g.blocks_per_wg, rows, scale, shift, act, residual, out, (unsigned char*)nullptr);
+    return check_launch("bn_act_fwd8_kernel");
+  }
   const long long n4 = P * (C / 4);
   hipLaunchKernelGGL(bn_act_fwd_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, as_stream(stream), x, n4, C / 4,
                      scale, shift, act, residual, out);
   return check_launch("bn_act_fwd_kernel");
+}
+
+extern "C" int yolo_bn_act_fwd(const float* x, long long P, int C, const float* scale, const float* shift, int act,
+                               const float* residual, float* out, void* stream) {
+  return yolo_bn_act_fwd_planes(x, P, C, scale, shift, act, residual, out, nullptr, stream);
 }
 
 extern "C" int yolo_bn_act_bwd_reduce(const float* x, const float* dout, long long P, int C, const float* scale,
@@ -329,25 +479,48 @@ extern "C" int yolo_bn_act_bwd_reduce(const float* x, const float* dout, long lo
   return check_launch("bn_bwd_reduce_kernel");
 }
 
-extern "C" int yolo_bn_act_bwd_apply(const float* x, const float* dout, long long P, int C, const float* gamma,
-                                     const float* scale, const float* shift, const float* save_mean,
-                                     const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,
-                                     float* dx, void* stream) {
+extern "C" int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, long long P, int C, const float* gamma,
+                                            const float* scale, const float* shift, const float* save_mean,
+                                            const float* save_invstd, int act, double* red, float* dgamma,
+                                            float* dbeta, float* dx, void* planes, void* stream) {
   (void)gamma;
-  YOLO_REQUIRE(x && dout && scale && shift && save_mean && save_invstd && red && dx && P > 0 && C > 0,
+  YOLO_REQUIRE(x && dout && scale && shift && save_mean && save_invstd && red && (dx || planes) && P > 0 && C > 0,
                "bn_act_bwd_apply: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_apply: C=%d must be a multiple of 4", C);
+  YOLO_REQUIRE(planes == nullptr || C % 16 == 0, "bn_act_bwd_apply: planes output needs C %% 16 == 0 (C=%d)", C);
   const long long n4 = P * (C / 4);
   hipStream_t st = as_stream(stream);
   const double* redsum = red + (long long)YOLO_BN_STAT_SLOTS * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, st, x, dout, n4, C / 4,
-                     1.0 / (double)P, scale, shift, save_mean, save_invstd, act, redsum, dx);
+  if (C % 8 == 0) {
+    const long long rows = planes ? ((P + 15) / 16 + 1) * 16 : P;
+    const RowGeom g = row_geom(rows, C);
+    unsigned char* pl = reinterpret_cast<unsigned char*>(planes);
+#define YOLO_BWD8(PL, DX)                                                                                            \
+  hipLaunchKernelGGL((bn_bwd_apply8_kernel<PL, DX>), dim3(g.gx, g.gy), dim3(256), 0, st, x, dout, P, C, g.wpr,       \
+                     g.blocks_per_wg, rows, 1.0 / (double)P, scale, shift, save_mean, save_invstd, act, redsum, dx, pl)
+    if (planes && dx) YOLO_BWD8(true, true);
+    else if (planes) YOLO_BWD8(true, false);
+    else YOLO_BWD8(false, true);
+#undef YOLO_BWD8
+  } else {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, st, x, dout, n4, C / 4,
+                       1.0 / (double)P, scale, shift, save_mean, save_invstd, act, redsum, dx);
+  }
   if (int rc = check_launch("bn_bwd_apply_kernel")) return rc;
   if (dgamma || dbeta) {
     hipLaunchKernelGGL(bn_bwd_params_kernel, dim3((C + 255) / 256), dim3(256), 0, st, C, redsum, dgamma, dbeta);
     return check_launch("bn_bwd_params_kernel");
   }
   return YOLO_OK;
+}
+
+extern "C" int yolo_bn_act_bwd_apply(const float* x, const float* dout, long long P, int C, const float* gamma,
+                                     const float* scale, const float* shift, const float* save_mean,
+                                     const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,
+                                     float* dx, void* stream) {
+  YOLO_REQUIRE(dx != nullptr, "bn_act_bwd_apply: bad args");
+  return yolo_bn_act_bwd_apply_planes(x, dout, P, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma,
+                                      dbeta, dx, nullptr, stream);
 }
 
 extern "C" int yolo_act_fwd(const float* x, long long n, int act, float* out, void* stream) {

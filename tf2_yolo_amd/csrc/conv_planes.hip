@@ -20,37 +20,6 @@
 
 namespace yolo {
 
-struct Planes8 {
-  u32x4 h, m, l;  // 8 bf16 each
-};
-
-// exact 3-way truncation split (see conv_split.hip: split4) of 8 floats
-__device__ __forceinline__ Planes8 split8(const f32x4 v0, const f32x4 v1) {
-  const u32x4 mask = {0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u, 0xFFFF0000u};
-  Planes8 p;
-  {
-    const u32x4 hb = __builtin_bit_cast(u32x4, v0) & mask;
-    const f32x4 r1 = v0 - __builtin_bit_cast(f32x4, hb);
-    const u32x4 mb = __builtin_bit_cast(u32x4, r1) & mask;
-    const f32x4 r2 = r1 - __builtin_bit_cast(f32x4, mb);
-    const u32x4 lb = __builtin_bit_cast(u32x4, r2) & mask;
-    p.h[0] = (hb[0] >> 16) | hb[1]; p.h[1] = (hb[2] >> 16) | hb[3];
-    p.m[0] = (mb[0] >> 16) | mb[1]; p.m[1] = (mb[2] >> 16) | mb[3];
-    p.l[0] = (lb[0] >> 16) | lb[1]; p.l[1] = (lb[2] >> 16) | lb[3];
-  }
-  {
-    const u32x4 hb = __builtin_bit_cast(u32x4, v1) & mask;
-    const f32x4 r1 = v1 - __builtin_bit_cast(f32x4, hb);
-    const u32x4 mb = __builtin_bit_cast(u32x4, r1) & mask;
-    const f32x4 r2 = r1 - __builtin_bit_cast(f32x4, mb);
-    const u32x4 lb = __builtin_bit_cast(u32x4, r2) & mask;
-    p.h[2] = (hb[0] >> 16) | hb[1]; p.h[3] = (hb[2] >> 16) | hb[3];
-    p.m[2] = (mb[0] >> 16) | mb[1]; p.m[3] = (mb[2] >> 16) | mb[3];
-    p.l[2] = (lb[0] >> 16) | lb[1]; p.l[3] = (lb[2] >> 16) | lb[3];
-  }
-  return p;
-}
-
 // one thread = (row, 8-channel group); adjacent lanes read adjacent 32-byte pieces of a row
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long rows, int C,
                                                           unsigned char* __restrict__ out, long long rows_padded) {

@@ -410,7 +410,7 @@ class Network:
             if u.kind not in ("conv", "head"):
                 continue
             if u.planes_fwd and u.src.tid not in self._xplanes:
-                self._xplanes[u.src.tid] = torch.empty(ops.planes_bytes(N * u.src.h * u.src.w, u.src.c), device=dev,
+                self._xplanes[u.src.tid] = torch.zeros(ops.planes_bytes(N * u.src.h * u.src.w, u.src.c), device=dev,
                                                        dtype=torch.uint8)
             if u.planes_dgrad or u.planes_wgrad:
                 dyp = max(dyp, ops.planes_bytes(N * u.out.h * u.out.w, u.cout if u.kind == "conv" else u.out.c))
@@ -506,7 +506,11 @@ class Network:
                             ops.bn_fold_inference(u.cout, gamma, beta, self.state.view(u.s_mean.name),
                                                   self.state.view(u.s_var.name), scale, shift)
                     res = self.act[u.residual.tid] if u.residual is not None else None
-                    ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a)
+                    # consumers that are planes-capable convs get their operand straight from this kernel
+                    pl = self._xplanes.get(u.out.tid) if u.cout % 16 == 0 else None
+                    ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a, planes=pl)
+                    if pl is not None:
+                        self._xp_valid.add(u.out.tid)
                 else:
                     self._conv_fwd(u, xin, w, bias, u.y)
                     if u.act != ACT_LINEAR:
@@ -584,11 +588,18 @@ class Network:
                     scale, shift, smean, sinv, _, red = self._bn_bufs(u)
                     if u.residual is not None:
                         self._add_grad(grads, u.residual, dout)
+                    # the gradient of the conv output goes straight into the planes the filter / data gradient
+                    # kernels read; the fp32 copy is written only if an fp32-path kernel still needs it
+                    need_pl = u.planes_wgrad or u.planes_dgrad
+                    need_f32 = ((not u.planes_wgrad) or u.p_bias is not None
+                                or (self._needs_grad[u.src.tid] and not u.planes_dgrad))
+                    dyp = self._dyplanes if need_pl else None
                     dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
-                                        sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta))
+                                        sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta),
+                                        planes=dyp, want_dx=need_f32)
                 else:
                     dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
-                dyp = self._dyp(u, dy)
+                    dyp = self._dyp(u, dy)
                 if u.planes_wgrad:
                     ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dyp, self._gview(u.p_kernel), dy=dy,
                                             dbias=self._gview(u.p_bias) if u.p_bias is not None else None)

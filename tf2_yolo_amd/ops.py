@@ -297,26 +297,36 @@ def bn_fold_inference(C, gamma, beta, moving_mean, moving_var, scale, shift, eps
                                              _p(scale), _p(shift), _stream()), "yolo_bn_fold_inference")
 
 
-def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None):
+def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None, planes=None):
+    """planes: optional uint8 buffer (planes_bytes(P, C)) that also receives the result in the conv operand format"""
     if out is None:
         out = torch.empty_like(x)
     P = x.numel() // C
-    check(_lib.load().yolo_bn_act_fwd(_p(x), P, C, _p(scale), _p(shift), act, _p(residual), _p(out), _stream()),
-          "yolo_bn_act_fwd")
+    if planes is not None and planes.numel() < planes_bytes(P, C):
+        raise YoloHipError("bn_act_fwd: planes buffer too small")
+    check(_lib.load().yolo_bn_act_fwd_planes(_p(x), P, C, _p(scale), _p(shift), act, _p(residual), _p(out), _p(planes),
+                                             _stream()), "yolo_bn_act_fwd")
     return out
 
 
-def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dx=None):
-    if dx is None:
-        dx = torch.empty_like(x)
+def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dx=None,
+               planes=None, want_dx=True):
+    """returns dx (None when want_dx is False and only the planes of dx are produced)"""
     P = x.numel() // C
+    if planes is not None and planes.numel() < planes_bytes(P, C):
+        raise YoloHipError("bn_act_bwd: planes buffer too small")
+    if not want_dx and planes is None:
+        raise YoloHipError("bn_act_bwd: nothing to produce")
+    if dx is None and want_dx:
+        dx = torch.empty_like(x)
     lib = _lib.load()
     check(lib.yolo_bn_act_bwd_reduce(_p(x), _p(dout), P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
                                      act, _p(red), _stream()), "yolo_bn_act_bwd_reduce")
-    check(lib.yolo_bn_act_bwd_apply(_p(x), _p(dout), P, C, _p(gamma), _p(scale), _p(shift), _p(save_mean),
-                                    _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta), _p(dx), _stream()),
+    check(lib.yolo_bn_act_bwd_apply_planes(_p(x), _p(dout), P, C, _p(gamma), _p(scale), _p(shift), _p(save_mean),
+                                           _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta),
+                                           _p(dx if want_dx else None), _p(planes), _stream()),
           "yolo_bn_act_bwd_apply")
-    return dx
+    return dx if want_dx else None
 
 
 def act_fwd(x, act, out=None):
