@@ -42,12 +42,25 @@ for (h, w, cin, cout, k, s, pad), cnt in shapes.items():
     dy = torch.randn(N, d.Ho, d.Wo, cout, device="cuda")
     dw = torch.zeros_like(wt)
     fl = 2.0 * N * d.Ho * d.Wo * cout * k * k * cin
-    t_f = timeit(lambda: ops.conv2d_fwd(d, x, wt, None, out=y))
-    t_w = timeit(lambda: ops.conv2d_wgrad(d, x, dy, dw))
+    M0 = N * d.Ho * d.Wo
+    if ops.planes_fwd_ok(cin, cout):
+        xp = ops.split_planes(x, N * h * w, cin); wp = ops.split_planes(wt, cout, k * k * cin)
+        t_f = timeit(lambda: ops.conv2d_fwd_planes(d, xp, wp, None, out=y))
+    else:
+        t_f = timeit(lambda: ops.conv2d_fwd(d, x, wt, None, out=y))
+    if ops.planes_fwd_ok(cin, cout) and ops.planes_wgrad_ok(cin, cout, k * k, s):
+        dyp = ops.split_planes(dy, M0, cout)
+        t_w = timeit(lambda: ops.conv2d_wgrad_planes(d, xp, dyp, dw))
+    else:
+        t_w = timeit(lambda: ops.conv2d_wgrad(d, x, dy, dw))
     if cin % 32 == 0:
         wT = ops.filter_transpose(wt, cout, k * k, cin)
         dx = torch.empty_like(x)
-        t_d = timeit(lambda: ops.conv2d_dgrad(d, dy, wT, dx=dx))
+        if ops.planes_dgrad_ok(cin, cout):
+            dyp = ops.split_planes(dy, M0, cout); wTp = ops.split_planes(wT, cin, k * k * cout)
+            t_d = timeit(lambda: ops.conv2d_dgrad_planes(d, dyp, wTp, dx=dx))
+        else:
+            t_d = timeit(lambda: ops.conv2d_dgrad(d, dy, wT, dx=dx))
     else:
         t_d = 0.0
     tot["fwd"] += t_f * cnt; tot["dgrad"] += t_d * cnt; tot["wgrad"] += t_w * cnt; totf += fl * cnt

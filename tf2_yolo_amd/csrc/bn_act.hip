@@ -184,14 +184,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const long long p_hi = (p_lo + per_block < P) ? p_lo + per_block : P;
     const long long stride = rpp;
     for (long long p = p_lo + row_lane; p < p_hi; p += 4 * stride) {
+      // all 8 loads are issued unconditionally (rows past the end re-read row p and are zeroed afterwards):
+      // a per-load "in range ? load : 0" makes hipcc branch around every load and wait for each in turn
       f32x4 xv[4], dv[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const long long pu = p + u * stride;
-        const bool ok = pu < p_hi;
-        xv[u] = ok ? *reinterpret_cast<const f32x4*>(x + pu * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
-        dv[u] = ok ? *reinterpret_cast<const f32x4*>(dout + pu * C + c4 * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const long long pc = pu < p_hi ? pu : p;
+        xv[u] = *reinterpret_cast<const f32x4*>(x + pc * C + c4 * 4);
+        dv[u] = *reinterpret_cast<const f32x4*>(dout + pc * C + c4 * 4);
       }
+#pragma unroll
+      for (int u = 1; u < 4; ++u)
+        if (p + u * stride >= p_hi) dv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
