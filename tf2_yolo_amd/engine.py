@@ -18,6 +18,9 @@ libyolo_hip.so on the current stream. Design points (MI355X-first, see DESIGN.md
 """
 import math
 
+import contextlib
+import os
+
 import numpy as np
 import torch
 
@@ -287,6 +290,9 @@ class Network:
         self.grads = torch.zeros_like(self.params.data)
         self._wT = torch.empty(self._wT_total, device=self.device, dtype=torch.float32)
         self._wT_valid = False
+        self._overlap_wgrad = os.environ.get("YOLO_BWD_OVERLAP", "1") != "0"
+        self._wgrad_stream = None
+        self._wgrad_pending = False
         self._bn_f32 = torch.zeros(max(self._bn_f32_total, 1), device=self.device, dtype=torch.float32)
         self._bn_f64 = torch.zeros(max(self._bn_f64_total, 1), device=self.device, dtype=torch.float64)
         self._anchors_dev = {}
@@ -600,23 +606,27 @@ class Network:
                 else:
                     dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
                     dyp = self._dyp(u, dy)
-                if u.planes_wgrad:
-                    ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dyp, self._gview(u.p_kernel), dy=dy,
-                                            dbias=self._gview(u.p_bias) if u.p_bias is not None else None)
-                else:
-                    ops.conv2d_wgrad(u.desc, xin, dy, self._gview(u.p_kernel),
-                                     self._gview(u.p_bias) if u.p_bias is not None else None)
+                with self._beside_dgrad(u):
+                    if u.planes_wgrad:
+                        ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dyp, self._gview(u.p_kernel), dy=dy,
+                                                dbias=self._gview(u.p_bias) if u.p_bias is not None else None)
+                    else:
+                        ops.conv2d_wgrad(u.desc, xin, dy, self._gview(u.p_kernel),
+                                         self._gview(u.p_bias) if u.p_bias is not None else None)
                 self._dgrad(grads, u, dy, u.cout * u.k * u.k * u.src.c, dyp)
+                self._join_wgrad()
             elif u.kind == "head":
                 xin = self.act[u.src.tid]
                 dt = ops.head_act_bwd(u.yact, dout, u.A, u.C, u.version, self._anchors_dev.get(u.name))
                 dtp = self._dyp(u, dt)
-                if u.planes_wgrad:
-                    ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dtp, self._gview(u.p_kernel), dy=dt,
-                                            dbias=self._gview(u.p_bias))
-                else:
-                    ops.conv2d_wgrad(u.desc, xin, dt, self._gview(u.p_kernel), self._gview(u.p_bias))
+                with self._beside_dgrad(u):
+                    if u.planes_wgrad:
+                        ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dtp, self._gview(u.p_kernel), dy=dt,
+                                                dbias=self._gview(u.p_bias))
+                    else:
+                        ops.conv2d_wgrad(u.desc, xin, dt, self._gview(u.p_kernel), self._gview(u.p_bias))
                 self._dgrad(grads, u, dt, u.out.c * u.src.c, dtp)
+                self._join_wgrad()
             elif u.kind == "upsample":
                 if self._needs_grad[u.src.tid]:
                     cur = grads.get(u.src.tid)
@@ -656,6 +666,24 @@ class Network:
                         ops.space_to_depth2_bwd(dout, u.out.c, 0, cur, accumulate=True)
             if self.grad_ready_hook is not None and u.kind in ("conv", "head"):
                 self.grad_ready_hook(u)
+
+    # The filter gradient and the data gradient of a layer are independent: the filter gradient is enqueued on
+    # a second stream so that the two kernels share the chip (each alone leaves workgroup slots idle in its
+    # last round: 344 or 676 tiles on 512 slots). The main stream waits for it before the next layer, so
+    # buffer lifetimes and the order seen by grad_ready_hook are those of the serial schedule.
+    def _beside_dgrad(self, u):
+        if not self._overlap_wgrad or not self._needs_grad[u.src.tid]:
+            return contextlib.nullcontext()
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+        self._wgrad_stream.wait_stream(torch.cuda.current_stream())
+        self._wgrad_pending = True
+        return torch.cuda.stream(self._wgrad_stream)
+
+    def _join_wgrad(self):
+        if self._wgrad_pending:
+            torch.cuda.current_stream().wait_stream(self._wgrad_stream)
+            self._wgrad_pending = False
 
     def _dyp(self, u, dy):
         """planes of this layer's dy (one scratch, consumed by the filter and data gradients right away)"""
