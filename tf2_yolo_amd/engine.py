@@ -420,7 +420,11 @@ class Network:
                                                        dtype=torch.uint8)
             if u.planes_dgrad or u.planes_wgrad:
                 dyp = max(dyp, ops.planes_bytes(N * u.out.h * u.out.w, u.cout if u.kind == "conv" else u.out.c))
-        self._dyplanes = torch.empty(dyp, device=dev, dtype=torch.uint8) if dyp else None
+        # (two scratch buffers, used alternately: the filter gradient of layer L may still be reading its dy
+        # planes on the second stream while layer L-1 produces its own)
+        self._dyplanes2 = [torch.empty(dyp, device=dev, dtype=torch.uint8) if dyp else None for _ in range(2)]
+        self._dyp_events = [None, None]
+        self._dyp_idx = 0
         self._xp_valid = set()
 
     def _xp(self, t):
@@ -599,14 +603,14 @@ class Network:
                     need_pl = u.planes_wgrad or u.planes_dgrad
                     need_f32 = ((not u.planes_wgrad) or u.p_bias is not None
                                 or (self._needs_grad[u.src.tid] and not u.planes_dgrad))
-                    dyp = self._dyplanes if need_pl else None
+                    dyp = self._next_dyp_buffer() if need_pl else None
                     dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
                                         sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta),
                                         planes=dyp, want_dx=need_f32)
                 else:
                     dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
                     dyp = self._dyp(u, dy)
-                with self._beside_dgrad(u):
+                with self._beside_backward(dy):
                     if u.planes_wgrad:
                         ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dyp, self._gview(u.p_kernel), dy=dy,
                                                 dbias=self._gview(u.p_bias) if u.p_bias is not None else None)
@@ -614,19 +618,17 @@ class Network:
                         ops.conv2d_wgrad(u.desc, xin, dy, self._gview(u.p_kernel),
                                          self._gview(u.p_bias) if u.p_bias is not None else None)
                 self._dgrad(grads, u, dy, u.cout * u.k * u.k * u.src.c, dyp)
-                self._join_wgrad()
             elif u.kind == "head":
                 xin = self.act[u.src.tid]
                 dt = ops.head_act_bwd(u.yact, dout, u.A, u.C, u.version, self._anchors_dev.get(u.name))
                 dtp = self._dyp(u, dt)
-                with self._beside_dgrad(u):
+                with self._beside_backward(dt):
                     if u.planes_wgrad:
                         ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dtp, self._gview(u.p_kernel), dy=dt,
                                                 dbias=self._gview(u.p_bias))
                     else:
                         ops.conv2d_wgrad(u.desc, xin, dt, self._gview(u.p_kernel), self._gview(u.p_bias))
                 self._dgrad(grads, u, dt, u.out.c * u.src.c, dtp)
-                self._join_wgrad()
             elif u.kind == "upsample":
                 if self._needs_grad[u.src.tid]:
                     cur = grads.get(u.src.tid)
@@ -666,19 +668,44 @@ class Network:
                         ops.space_to_depth2_bwd(dout, u.out.c, 0, cur, accumulate=True)
             if self.grad_ready_hook is not None and u.kind in ("conv", "head"):
                 self.grad_ready_hook(u)
+        self._join_wgrad()
 
-    # The filter gradient and the data gradient of a layer are independent: the filter gradient is enqueued on
-    # a second stream so that the two kernels share the chip (each alone leaves workgroup slots idle in its
-    # last round: 344 or 676 tiles on 512 slots). The main stream waits for it before the next layer, so
-    # buffer lifetimes and the order seen by grad_ready_hook are those of the serial schedule.
-    def _beside_dgrad(self, u):
-        if not self._overlap_wgrad or not self._needs_grad[u.src.tid]:
-            return contextlib.nullcontext()
+    # The filter gradient of a layer is independent of everything the backward pass does next (its data
+    # gradient, the BatchNorm backward of the layer below, ...): it is enqueued on a second stream so that it
+    # shares the chip with them -- the conv kernels alone leave workgroup slots idle in their last round (344
+    # or 676 tiles on 512 slots) and the BatchNorm kernels leave the matrix pipe idle. Hazards: the dy planes
+    # scratch is double-buffered and re-used only after the filter gradient that read it has finished (event);
+    # fp32 tensors read on the second stream are marked with record_stream; the main stream joins the second
+    # one at the end of backward -- or after every layer when a grad_ready_hook (data parallel gradient
+    # buckets) wants the gradients in stream order.
+    def _next_dyp_buffer(self):
+        self._dyp_idx ^= 1
+        ev = self._dyp_events[self._dyp_idx]
+        if ev is not None:
+            torch.cuda.current_stream().wait_event(ev)
+            self._dyp_events[self._dyp_idx] = None
+        return self._dyplanes2[self._dyp_idx]
+
+    @contextlib.contextmanager
+    def _beside_backward(self, *tensors):
+        if not self._overlap_wgrad:
+            yield
+            return
         if self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
-        self._wgrad_stream.wait_stream(torch.cuda.current_stream())
+        side = self._wgrad_stream
+        side.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            if t is not None:
+                t.record_stream(side)
+        with torch.cuda.stream(side):
+            yield
+            ev = torch.cuda.Event()
+            ev.record(side)
+        self._dyp_events[self._dyp_idx] = ev
         self._wgrad_pending = True
-        return torch.cuda.stream(self._wgrad_stream)
+        if self.grad_ready_hook is not None:
+            self._join_wgrad()
 
     def _join_wgrad(self):
         if self._wgrad_pending:
@@ -690,7 +717,7 @@ class Network:
         if not (u.planes_wgrad or u.planes_dgrad):
             return None
         cout = u.cout if u.kind == "conv" else u.out.c
-        return ops.split_planes(dy, self.batch * u.out.h * u.out.w, cout, out=self._dyplanes)
+        return ops.split_planes(dy, self.batch * u.out.h * u.out.w, cout, out=self._next_dyp_buffer())
 
     def _dgrad(self, grads, u, dy, wsize, dyp=None):
         if not self._needs_grad[u.src.tid]:
