@@ -48,6 +48,9 @@ class GradReducer:
         self.on_gpu = flat_grads.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
         self._works = []
+        # callable -> list of further CUDA streams that produce gradients (the engine's filter-gradient
+        # stream): a bucket is reduced only after the work enqueued on them so far has finished too
+        self.extra_streams = None
 
     def segment_done(self, i):
         if self.world == 1:
@@ -59,6 +62,10 @@ class GradReducer:
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
                 self.comm_stream.wait_event(ev)
+                for st in (self.extra_streams() if self.extra_streams is not None else ()):
+                    ev2 = torch.cuda.Event()
+                    ev2.record(st)
+                    self.comm_stream.wait_event(ev2)
                 with torch.cuda.stream(self.comm_stream):
                     self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
             else:

@@ -676,8 +676,8 @@ class Network:
     # or 676 tiles on 512 slots) and the BatchNorm kernels leave the matrix pipe idle. Hazards: the dy planes
     # scratch is double-buffered and re-used only after the filter gradient that read it has finished (event);
     # fp32 tensors read on the second stream are marked with record_stream; the main stream joins the second
-    # one at the end of backward -- or after every layer when a grad_ready_hook (data parallel gradient
-    # buckets) wants the gradients in stream order.
+    # one at the end of backward. A grad_ready_hook (data parallel gradient buckets) must order its work after
+    # BOTH streams (dp.GradReducer.extra_streams).
     def _next_dyp_buffer(self):
         self._dyp_idx ^= 1
         ev = self._dyp_events[self._dyp_idx]
@@ -704,8 +704,6 @@ class Network:
             ev.record(side)
         self._dyp_events[self._dyp_idx] = ev
         self._wgrad_pending = True
-        if self.grad_ready_hook is not None:
-            self._join_wgrad()
 
     def _join_wgrad(self):
         if self._wgrad_pending:

@@ -263,6 +263,8 @@ class Model:
         self._reducer = dp_mod.GradReducer(self.net.grads, segs, process_group, bucket_bytes)
         index = {id(u): i for i, u in enumerate(units)}
         self.net.grad_ready_hook = lambda u: self._reducer.segment_done(index[id(u)])
+        net = self.net
+        self._reducer.extra_streams = lambda: [net._wgrad_stream] if net._wgrad_stream is not None else []
         dp_mod.broadcast_parameters([self.net.params.data, self.net.state.data], 0, process_group)
         self.net.mark_params_changed()
 
