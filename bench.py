@@ -175,6 +175,22 @@ def main():
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     loss_val = float(sum(b[0].item() for b in bufs))
 
+    # Outside the timed region (rank 0, informational): the same step with the filter-gradient stream
+    # switched off, so that every conv kernel has the chip to itself. In the timed region the filter gradient
+    # runs BESIDE the data gradient / BatchNorm backward; that shortens the step but lengthens each of the
+    # overlapped launches, so per-launch rates measured there understate the kernels.
+    iso = None
+    if timer is not None and rank == 0 and world == 1:
+        model.net._overlap_wgrad = False
+        iso_timer = ops.KernelTimer()
+        ops.TIMER = iso_timer
+        for _ in range(2):
+            model.train_step_device(x, ys)
+        torch.cuda.synchronize()
+        ops.TIMER = None
+        model.net._overlap_wgrad = True
+        iso = iso_timer.summary()
+
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,6 +222,12 @@ def main():
                     "traffic_source": "newest profiles/r*_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                       "passes, gfx950 x2 FETCH correction), bytes per launch",
                     "launches": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
+                    "isolated": (None if iso is None or name not in iso else
+                                 {"note": "same kernel, same step, filter-gradient stream off (no concurrent kernels); "
+                                          "2 extra steps outside the timed region",
+                                  "achieved": round(iso[name]["flops"] / (iso[name]["ms"] * 1e-3) / 1e12, 2),
+                                  "frac": round(iso[name]["flops"] / (iso[name]["ms"] * 1e-3) / 1e12 / peak, 4),
+                                  "avg_launch_us": round(iso[name]["ms"] * 1e3 / iso[name]["launches"], 2)}),
                     "flops_per_launch": a["flops"] / a["launches"],
                     "all_conv_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
                                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),

@@ -306,6 +306,35 @@ int yolo_nms(const double* rows, int n, int class_num, int mode, double nms_thre
              double conf_threshold, double sigma, unsigned char* keep_out,
              void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Detection evaluation after decode / NMS (replaces the arithmetic of create_score_mat and
+ * PRfunc, utils/measurement.py:16-150, 153-337). Rows are the (n,7) float64 arrays of
+ * yolo_decode_level: x, y, w, h, conf, class, class prob. All fp64 / integer, bit-exact.
+ * ------------------------------------------------------------------------------------ */
+
+/* One image. For every detection: best_gt = index (inside the subset of ground truths of the detection's
+ * class, np.argmax = first maximum) of the ground truth with the highest IoU, matched = that IoU >=
+ * iou_threshold, best_iou (0 / 0 / 0 when the class has no ground truth: measurement.py:275-277).
+ * class_counts[c*4 + {0,1,2,3}] += #detections, #ground truths, #matched detections, #distinct matched
+ * ground truths of class c (accumulates over images; zero it first). gt_flags: scratch of ngt bytes. */
+int yolo_match_detections(const double* gt_rows, int ngt, const double* det_rows, int ndet, int class_num,
+                          double iou_threshold, int* best_gt, unsigned char* matched, double* best_iou,
+                          unsigned char* gt_flags, long long* class_counts, void* stream);
+
+/* rank[i] = number of rows of the same segment that sort before row i when keys are ordered descending
+ * (np.argsort(key)[::-1]; equal keys: the later row first). segment may be NULL (one segment). */
+int yolo_rank_desc(const double* key, const int* segment, int n, int* rank, void* stream);
+
+/* Precision / recall curve of ONE class (measurement.py:299-323): detections (joint confidence, id of the
+ * best ground truth, matched flag) are sorted by confidence; point i (0 <= i < n) is computed from the i+1
+ * best detections: num_tpp = #matched, num_tp = #distinct matched ground truths, precision = num_tpp/(i+1)
+ * (mode 0), num_tp/(num_tp + i+1 - num_tpp) (mode 1), num_tp/(i+1) (mode 2), recall = num_tp/num_gts;
+ * point n = (0, last recall). precision and recall hold n+1 doubles. Needs n > 0 and num_gts > 0. */
+size_t yolo_pr_curve_workspace_bytes(int n, int num_gts);
+int yolo_pr_curve(const double* joint, const int* gt_id, const unsigned char* matched, int n, int num_gts,
+                  int precision_mode, void* workspace, size_t workspace_bytes, double* precision,
+                  double* recall, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

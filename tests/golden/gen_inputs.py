@@ -44,3 +44,54 @@ def misc_inputs():
     d["label52"] = lab
     d["iou_boxes"] = rng.random((40, 5))
     return d
+
+
+def measurement_inputs(seed=5, n_img=8, C=3, A=3, g=8):
+    """Evaluation fixture (utils/measurement.py): labels on a g x g grid (float64, as the data path makes them)
+    and two prediction levels (g and g/2, float32) that contain noisy copies of the labelled boxes (true
+    positives of varying quality, some with the wrong class, some duplicated) plus random false positives.
+    Scores are continuous random numbers: no ties."""
+    rng = np.random.default_rng(seed)
+    y_true = np.zeros((n_img, g, g, 5 + C))
+    lv0 = np.zeros((n_img, g, g, A * (5 + C)), dtype=np.float32)
+    lv1 = np.zeros((n_img, g // 2, g // 2, A * (5 + C)), dtype=np.float32)
+    v0 = lv0.reshape(n_img, g, g, A, 5 + C)
+    v1 = lv1.reshape(n_img, g // 2, g // 2, A, 5 + C)
+    for b in range(n_img):
+        for _ in range(int(rng.integers(3, 9))):
+            y, x = rng.integers(0, g, 2)
+            if y_true[b, y, x, 4] == 1:
+                continue
+            xy = rng.random(2)
+            wh = rng.random(2) * 0.3 + 0.08
+            c = int(rng.integers(0, C))
+            y_true[b, y, x, :2] = xy
+            y_true[b, y, x, 2:4] = wh
+            y_true[b, y, x, 4] = 1
+            y_true[b, y, x, 5 + c] = 1
+            for a in range(A):   # up to A noisy copies on the fine level
+                if rng.random() < 0.6:
+                    noise = rng.normal(0, 0.08 * (1 + a), 4)
+                    v0[b, y, x, a, :2] = np.clip(xy + noise[:2] * 0.5, 0.01, 0.99)
+                    v0[b, y, x, a, 2:4] = np.clip(wh * (1 + noise[2:]), 0.02, 0.9)
+                    v0[b, y, x, a, 4] = rng.random() * 0.7 + 0.3
+                    cc = c if rng.random() < 0.8 else int(rng.integers(0, C))
+                    v0[b, y, x, a, 5:] = rng.random(C) * 0.2
+                    v0[b, y, x, a, 5 + cc] = rng.random() * 0.5 + 0.5
+            if rng.random() < 0.5:   # a coarse-level copy (cell = (y//2, x//2), offset re-expressed)
+                a = int(rng.integers(0, A))
+                v1[b, y // 2, x // 2, a, 0] = ((x + xy[0]) / 2) % 1
+                v1[b, y // 2, x // 2, a, 1] = ((y + xy[1]) / 2) % 1
+                v1[b, y // 2, x // 2, a, 2:4] = wh * (1 + rng.normal(0, 0.1, 2))
+                v1[b, y // 2, x // 2, a, 4] = rng.random() * 0.6 + 0.2
+                v1[b, y // 2, x // 2, a, 5:] = rng.random(C) * 0.3
+                v1[b, y // 2, x // 2, a, 5 + c] = rng.random() * 0.5 + 0.5
+        for _ in range(int(rng.integers(4, 12))):   # false positives
+            y, x, a = rng.integers(0, g), rng.integers(0, g), rng.integers(0, A)
+            if v0[b, y, x, a, 4] > 0:
+                continue
+            v0[b, y, x, a, :2] = rng.random(2)
+            v0[b, y, x, a, 2:4] = rng.random(2) * 0.3 + 0.05
+            v0[b, y, x, a, 4] = rng.random() * 0.8 + 0.1
+            v0[b, y, x, a, 5:] = rng.random(C) * 0.9 + 0.05
+    return y_true, lv0, lv1

@@ -523,3 +523,49 @@ def nms_keep(rows, class_num, mode, nms_threshold, conf_threshold=0.5, sigma=0.5
     check(lib.yolo_nms(_p(rows), n, class_num, mode, float(nms_threshold), float(conf_threshold), float(sigma),
                        _p(keep), _p(ws), nbytes, _stream()), "yolo_nms")
     return keep
+
+
+# ---- evaluation after decode / NMS (csrc/measure.hip) ---------------------------------------------------
+def match_detections(gt_rows, det_rows, class_num, iou_threshold, class_counts):
+    """gt_rows [ngt,7], det_rows [ndet,7] float64 CUDA tensors of ONE image; class_counts int64 CUDA tensor
+    [class_num,4] (accumulated). Returns (best_gt int32 [ndet], matched uint8 [ndet], best_iou float64 [ndet])."""
+    dev = class_counts.device
+    ngt, ndet = int(gt_rows.shape[0]), int(det_rows.shape[0])
+    if ((ngt and gt_rows.dtype != torch.float64) or (ndet and det_rows.dtype != torch.float64)
+            or class_counts.dtype != torch.int64 or class_counts.numel() != class_num * 4):
+        raise YoloHipError("match_detections: rows must be float64 [n,7], class_counts int64 [class_num,4]")
+    best_gt = torch.empty(ndet, device=dev, dtype=torch.int32)
+    matched = torch.empty(ndet, device=dev, dtype=torch.uint8)
+    best_iou = torch.empty(ndet, device=dev, dtype=torch.float64)
+    flags = torch.empty(max(ngt, 1), device=dev, dtype=torch.uint8)
+    check(_lib.load().yolo_match_detections(_p(gt_rows.contiguous()) if ngt else None, ngt,
+                                            _p(det_rows.contiguous()) if ndet else None, ndet, class_num,
+                                            float(iou_threshold), _p(best_gt), _p(matched), _p(best_iou), _p(flags),
+                                            _p(class_counts), _stream()), "yolo_match_detections")
+    return best_gt, matched, best_iou
+
+
+def rank_desc(key, segment=None):
+    """rank of every element inside its segment, keys descending (ties: later element first)"""
+    n = int(key.numel())
+    rank = torch.empty(n, device=key.device, dtype=torch.int32)
+    if n:
+        if key.dtype != torch.float64 or (segment is not None and segment.dtype != torch.int32):
+            raise YoloHipError("rank_desc: key must be float64, segment int32")
+        check(_lib.load().yolo_rank_desc(_p(key.contiguous()), _p(segment), n, _p(rank), _stream()), "yolo_rank_desc")
+    return rank
+
+
+def pr_curve(joint, gt_id, matched, num_gts, precision_mode):
+    """one class: (precision, recall) float64 CUDA tensors of n+1 points"""
+    n = int(joint.numel())
+    if joint.dtype != torch.float64 or gt_id.dtype != torch.int32 or matched.dtype != torch.uint8:
+        raise YoloHipError("pr_curve: joint float64, gt_id int32, matched uint8 expected")
+    lib = _lib.load()
+    nbytes = int(lib.yolo_pr_curve_workspace_bytes(n, int(num_gts)))
+    ws = torch.empty(nbytes, device=joint.device, dtype=torch.uint8)
+    prec = torch.empty(n + 1, device=joint.device, dtype=torch.float64)
+    rec = torch.empty(n + 1, device=joint.device, dtype=torch.float64)
+    check(lib.yolo_pr_curve(_p(joint.contiguous()), _p(gt_id.contiguous()), _p(matched.contiguous()), n, int(num_gts),
+                            int(precision_mode), _p(ws), nbytes, _p(prec), _p(rec), _stream()), "yolo_pr_curve")
+    return prec, rec

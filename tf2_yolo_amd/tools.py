@@ -101,3 +101,62 @@ def nms(xywhcp, class_num=1, nms_threshold=0.45, iou_mode=1):
 def soft_nms(xywhcp, class_num=1, nms_threshold=0.45, conf_threshold=0.5, sigma=0.5):
     """Soft Non-Maximum Suppression."""
     return _nms_impl(xywhcp, class_num, NMS_SOFT, nms_threshold, conf_threshold, sigma)
+
+
+# ---- on-disk formats of detections (utils/tools.py:800-965) ---------------------------------------------
+def _detections(label_datas, class_num, conf_threshold, nms_mode, nms_threshold, nms_sigma, version):
+    """decode (+ NMS mode 1: NMS, 2: soft-NMS, 3: DIoU-NMS) on the GPU -> NumPy rows (n, 7)"""
+    rows = decode_device(*label_datas, class_num=class_num, threshold=conf_threshold, version=version)
+    if nms_mode > 0 and rows.shape[0] > 0:
+        if nms_mode == 1:
+            rows = nms(rows, class_num, nms_threshold)
+        elif nms_mode == 2:
+            rows = soft_nms(rows, class_num, nms_threshold, conf_threshold, nms_sigma)
+        elif nms_mode == 3:
+            rows = nms(rows, class_num, nms_threshold, 2)
+    return rows.cpu().numpy().reshape(-1, 7)
+
+
+def _pixel_boxes(rows, img_size):
+    """(label index, x_min, y_min, x_max, y_max, confidence) per row, in pixels of the original image"""
+    out = []
+    for obj in rows:
+        box_x, box_y = obj[0] * img_size[1], obj[1] * img_size[0]
+        box_w, box_h = obj[2] * img_size[1], obj[3] * img_size[0]
+        out.append((int(obj[5]), box_x - box_w / 2, box_y - box_h / 2, box_x + box_w / 2, box_y + box_h / 2,
+                    obj[4] * obj[6]))
+    return out
+
+
+def array_to_json(path, img_size, *label_datas, class_names=[""], conf_threshold=0.5, nms_mode=0,
+                  nms_threshold=0.45, nms_sigma=0.5, version=3):
+    """Write the detections of one image as a labelme-style json file (utils/tools.py:800-876): rectangles as
+    [[x_min, y_min], [x_max, y_max]] in pixels plus "confidence" = conf * class prob, encoding big5.
+    Numbers are written as plain decimals (what the reference writes under NumPy 1.x; under NumPy 2 its
+    str(dict) leaks `np.float64(...)` wrappers into the file, which is not json)."""
+    rows = _detections(label_datas, len(class_names), conf_threshold, nms_mode, nms_threshold, nms_sigma, version)
+    shapes = []
+    for ci, x0, y0, x1, y1, conf in _pixel_boxes(rows, img_size):
+        shapes.append('{"label": "%s", "points": [[%r, %r], [%r, %r]], "shape_type": "rectangle", "confidence": %r}'
+                      % (class_names[ci], float(x0), float(y0), float(x1), float(y1), float(conf)))
+    text = '{"shapes": [%s], "imageHeight": %r, "imageWidth": %r}' % (", ".join(shapes), img_size[0], img_size[1])
+    with open(path, "w", encoding="big5") as file:
+        file.write(text)
+
+
+def array_to_xml(path, img_size, *label_datas, class_names=[], conf_threshold=0.5, nms_mode=0,
+                 nms_threshold=0.45, nms_sigma=0.5, version=3):
+    """Write the detections of one image as a VOC-style xml file (utils/tools.py:879-965): per object <name>,
+    <bndbox> with integer (truncated) xmin / ymin / xmax / ymax in pixels, <confidence>."""
+    import xml.etree.ElementTree as ET
+    rows = _detections(label_datas, len(class_names), conf_threshold, nms_mode, nms_threshold, nms_sigma, version)
+    root = ET.Element("annotation")
+    for ci, x0, y0, x1, y1, conf in _pixel_boxes(rows, img_size):
+        node = ET.SubElement(root, "object")
+        ET.SubElement(node, "name").text = class_names[ci]
+        box = ET.SubElement(node, "bndbox")
+        for tag, v in (("xmin", x0), ("ymin", y0), ("xmax", x1), ("ymax", y1)):
+            ET.SubElement(box, tag).text = str(int(v))
+        ET.SubElement(node, "confidence").text = str(float(conf))
+    with open(path, "wb") as file:
+        ET.ElementTree(root).write(file)
