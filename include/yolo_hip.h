@@ -103,6 +103,14 @@ int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin
 size_t yolo_planes_bytes(long long rows, int C);
 int yolo_split_planes(const float* x, long long rows, int C, void* planes, void* stream);
 
+/* Batched forms for the filters of a whole network: ONE launch instead of one per layer. `jobs` is a device
+ * array of njobs records of six int64: {source pointer, destination pointer, a, b, c, first_block};
+ * first_block = number of 256-thread workgroups of all earlier jobs, total_blocks = their sum.
+ * split job:     a = rows, b = C (c unused);  workgroups = ceil(((ceil(rows/16)+1)*16 * C/8) / 256)
+ * transpose job: a = Cout, b = taps, c = Cin;  workgroups = ceil(Cin/32) * ceil(Cout/32) * taps */
+int yolo_split_planes_batch(const void* jobs, int njobs, long long total_blocks, void* stream);
+int yolo_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, void* stream);
+
 /* yolo_conv2d_fwd / yolo_conv2d_dgrad on pre-split operands (same conv, same fused epilogue, same
  * fp32-accurate result): x_planes = planes of x viewed as [N*H*W][Cin], w_planes = planes of w viewed as
  * [Cout][kh*kw*Cin]; dy_planes = planes of dy [N*Ho*Wo][Cout], wT_planes = planes of wT [Cin][kh*kw*Cout].

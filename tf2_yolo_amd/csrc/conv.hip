@@ -768,6 +768,16 @@ extern "C" size_t yolo_planes_bytes(long long rows, int C) {
   return (size_t)planes_bytes(rows, C);
 }
 
+extern "C" int yolo_split_planes_batch(const void* jobs, int njobs, long long total_blocks, void* stream) {
+  YOLO_REQUIRE(jobs, "split_planes_batch: null job table");
+  return launch_split_planes_batch(jobs, njobs, total_blocks, as_stream(stream));
+}
+
+extern "C" int yolo_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, void* stream) {
+  YOLO_REQUIRE(jobs, "filter_transpose_batch: null job table");
+  return launch_filter_transpose_batch(jobs, njobs, total_blocks, as_stream(stream));
+}
+
 extern "C" int yolo_split_planes(const float* x, long long rows, int C, void* planes, void* stream) {
   YOLO_REQUIRE(x && planes, "split_planes: null pointer");
   return launch_split_planes(x, rows, C, planes, as_stream(stream));

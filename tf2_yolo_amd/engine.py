@@ -328,6 +328,7 @@ class Network:
         self._wplanes = torch.empty(wp, device=self.device, dtype=torch.uint8) if wp else None
         self._wp_valid = False
         self._wTp_valid = False
+        self._jobs_wp = self._jobs_wTp = self._jobs_wT = None
 
     # ---- construction -------------------------------------------------------------------
     def _declare_params(self):
@@ -438,24 +439,30 @@ class Network:
     def _refresh_wplanes(self):
         if self._wp_valid or self._wplanes is None:
             return
-        for u in self.units:
-            if u.kind in ("conv", "head") and u.planes_fwd:
-                cout = u.cout if u.kind == "conv" else u.out.c
-                k = u.k if u.kind == "conv" else 1
-                ops.split_planes(self.params.view(u.p_kernel.name), cout, k * k * u.src.c,
-                                 out=self._wplanes[u.wp_off:u.wp_off + u.wp_bytes])
+        if self._jobs_wp is None:   # one batched launch for the planes of every filter (pointers never change)
+            self._jobs_wp = ops.BatchJobs("split", self.device)
+            for u in self.units:
+                if u.kind in ("conv", "head") and u.planes_fwd:
+                    cout = u.cout if u.kind == "conv" else u.out.c
+                    k = u.k if u.kind == "conv" else 1
+                    self._jobs_wp.add_split(self.params.view(u.p_kernel.name),
+                                            self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], cout, k * k * u.src.c)
+        self._jobs_wp.run()
         self._wp_valid = True
 
     def _refresh_wTplanes(self):
         if self._wTp_valid or self._wplanes is None:
             return
-        for u in self.units:
-            if u.kind in ("conv", "head") and u.planes_dgrad:
-                cout = u.cout if u.kind == "conv" else u.out.c
-                k = u.k if u.kind == "conv" else 1
-                n = cout * k * k * u.src.c
-                ops.split_planes(self._wT[u.wT_off:u.wT_off + n], u.src.c, k * k * cout,
-                                 out=self._wplanes[u.wTp_off:u.wTp_off + u.wTp_bytes])
+        if self._jobs_wTp is None:
+            self._jobs_wTp = ops.BatchJobs("split", self.device)
+            for u in self.units:
+                if u.kind in ("conv", "head") and u.planes_dgrad:
+                    cout = u.cout if u.kind == "conv" else u.out.c
+                    k = u.k if u.kind == "conv" else 1
+                    n = cout * k * k * u.src.c
+                    self._jobs_wTp.add_split(self._wT[u.wT_off:u.wT_off + n],
+                                             self._wplanes[u.wTp_off:u.wTp_off + u.wTp_bytes], u.src.c, k * k * cout)
+        self._jobs_wTp.run()
         self._wTp_valid = True
 
     def _conv_fwd(self, u, xin, w, bias, out, stats=None):
@@ -563,15 +570,16 @@ class Network:
     def _refresh_wT(self):
         if self._wT_valid:
             return
-        for u in self.units:
-            if u.kind == "conv":
-                n = u.cout * u.k * u.k * u.src.c
-                ops.filter_transpose(self.params.view(u.p_kernel.name), u.cout, u.k * u.k, u.src.c,
-                                     out=self._wT[u.wT_off:u.wT_off + n])
-            elif u.kind == "head":
-                n = u.out.c * u.src.c
-                ops.filter_transpose(self.params.view(u.p_kernel.name), u.out.c, 1, u.src.c,
-                                     out=self._wT[u.wT_off:u.wT_off + n])
+        if self._jobs_wT is None:
+            self._jobs_wT = ops.BatchJobs("transpose", self.device)
+            for u in self.units:
+                if u.kind in ("conv", "head"):
+                    cout = u.cout if u.kind == "conv" else u.out.c
+                    taps = u.k * u.k if u.kind == "conv" else 1
+                    n = cout * taps * u.src.c
+                    self._jobs_wT.add_transpose(self.params.view(u.p_kernel.name), self._wT[u.wT_off:u.wT_off + n],
+                                                cout, taps, u.src.c)
+        self._jobs_wT.run()
         self._wT_valid = True
 
     def _gview(self, spec):

@@ -173,6 +173,32 @@ def split_planes(x, rows, c, out=None):
     return out
 
 
+class BatchJobs:
+    """Device job table for yolo_split_planes_batch / yolo_filter_transpose_batch (built once, re-run every step)."""
+
+    def __init__(self, kind, device):
+        self.kind, self.device = kind, device
+        self.rows, self.blocks, self.table = [], 0, None
+
+    def add_split(self, src, dst, rows, c):
+        nb = -(-(((rows + 15) // 16 + 1) * 16 * (c // 8)) // 256)
+        self.rows.append([src.data_ptr(), dst.data_ptr(), rows, c, 0, self.blocks])
+        self.blocks += nb
+
+    def add_transpose(self, src, dst, cout, taps, cin):
+        nb = -(-cin // 32) * -(-cout // 32) * taps
+        self.rows.append([src.data_ptr(), dst.data_ptr(), cout, taps, cin, self.blocks])
+        self.blocks += nb
+
+    def run(self):
+        if not self.rows:
+            return
+        if self.table is None:
+            self.table = torch.tensor(self.rows, dtype=torch.int64).to(self.device)
+        fn = _lib.load().yolo_split_planes_batch if self.kind == "split" else _lib.load().yolo_filter_transpose_batch
+        check(fn(_p(self.table), len(self.rows), self.blocks, _stream()), "yolo_%s_batch" % self.kind)
+
+
 def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None):
     _chk_f32(bias)
     if out is None:
