@@ -15,6 +15,8 @@ x = torch.randn(N, h, h, cin, device="cuda")
 w = torch.randn(cout, k, k, cin, device="cuda") * 0.05
 y = torch.empty(N, d.Ho, d.Wo, cout, device="cuda")
 dy = torch.randn(N, d.Ho, d.Wo, cout, device="cuda")
+if os.environ.get("YOLO_ONE_CONV_ZEROS") == "1":   # DVFS probe: same cycles, (almost) no switching energy
+    x.zero_(); w.zero_(); dy.zero_()
 dw = torch.zeros_like(w)
 wT = ops.filter_transpose(w, cout, k * k, cin)
 dx = torch.empty_like(x)
