@@ -11,7 +11,7 @@ HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -munsafe-fp-atomics -Wal
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/conv_args.hpp include/yolo_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/conv_args.hpp $(CSRC)/planes.hpp include/yolo_hip.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

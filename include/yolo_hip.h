@@ -95,11 +95,14 @@ int yolo_conv2d_wgrad_bias(const float* dy, long long P, int Cout, float* dbias,
 int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream);
 
 /* "Planes" operands: a row-major fp32 matrix X[rows][C] (the pixels of an NHWC tensor, or the output
- * channels of a [Cout][kh*kw*Cin] filter), C % 16 == 0, split EXACTLY into three bf16 planes
- * (x = h + m + l) and blocked 16 rows x 16 channels so that the conv kernels can bring MFMA operand
- * fragments into LDS by DMA (layout: tf2_yolo_amd/csrc/conv_planes.hip). yolo_planes_bytes gives the
- * buffer size (0 for unsupported shapes); yolo_split_planes fills it from fp32. A tensor that feeds
- * several convolutions (forward, filter gradient) is split once. */
+ * channels of a [Cout][kh*kw*Cin] filter), C % 16 == 0, stored as TWO fp16 planes h + l of s*X (s = one
+ * power of two per tensor, kept in the buffer's trailing header; |s*x - h - l| <= 2^-24 |s*x|) and blocked 16
+ * rows x 16 channels so that the conv kernels can bring MFMA operand fragments into LDS by DMA (format and
+ * error analysis: tf2_yolo_amd/csrc/planes.hpp). A product is three fp16 MFMA passes (hh + hl + lh, each exact
+ * in the fp32 accumulator): ~3 fp32 roundings per product, i.e. fp32-grade, at half the matrix work of the
+ * exact bf16 x 6 scheme of yolo_conv2d_fwd. yolo_planes_bytes gives the buffer size (0 for unsupported
+ * shapes); yolo_split_planes fills it from fp32 (max|x| pass + split pass). A tensor that feeds several
+ * convolutions (forward, filter gradient) is split once. */
 size_t yolo_planes_bytes(long long rows, int C);
 int yolo_split_planes(const float* x, long long rows, int C, void* planes, void* stream);
 
@@ -175,14 +178,29 @@ int yolo_bn_act_bwd_apply(const float* x, const float* dout, long long P, int C,
 
 /* yolo_bn_act_fwd / yolo_bn_act_bwd_apply that ALSO emit their result in the conv kernels' "planes"
  * operand format (yolo_planes_bytes(P, C) bytes, C % 16 == 0), so that the consumer convolutions need no
- * yolo_split_planes pass. planes == NULL: plain forms. yolo_bn_act_bwd_apply_planes: dx may be NULL when
- * only the planes are wanted. */
+ * yolo_split_planes pass. planes == NULL: plain forms. The planes need an upper bound of max|result| for
+ * their power-of-two scale; it comes from the statistics, not from a pass over the data:
+ *  - forward: yolo_bn_finalize_bound leaves in *bound (one uint32, zeroed by the caller before) the bit
+ *    pattern of max_c |gamma_c| sqrt(P var_c / (var_c + eps)) + |beta_c| >= max|act(BN(x))|; yolo_bn_act_fwd_planes
+ *    adds *residual_bound (bound of the residual tensor) and stores the sum in *out_bound (optional);
+ *  - backward: yolo_bn_act_bwd_reduce_bound leaves in bound_aux[0..2] (zeroed by the caller) max|dz|,
+ *    max_c|scale_c| and max_c |scale_c| (|mean(dz xhat)_c| sqrt(P) + |mean(dz)_c|), which bound dx.
+ * yolo_bn_act_bwd_apply_planes: dx may be NULL when only the planes are wanted. */
+int yolo_bn_finalize_bound(double* stats, long long P, int C, const float* gamma, const float* beta, float eps,
+                           float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
+                           float* scale, float* shift, float* save_mean, float* save_invstd,
+                           unsigned* bound, void* stream);
 int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scale, const float* shift,
-                           int act, const float* residual, float* out, void* planes, void* stream);
+                           int act, const float* residual, float* out, void* planes,
+                           const unsigned* bn_bound, const float* residual_bound, float* out_bound,
+                           void* stream);
+int yolo_bn_act_bwd_reduce_bound(const float* x, const float* dout, long long P, int C, const float* scale,
+                                 const float* shift, const float* save_mean, const float* save_invstd,
+                                 int act, double* red, unsigned* bound_aux, void* stream);
 int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, long long P, int C, const float* gamma,
                                  const float* scale, const float* shift, const float* save_mean,
                                  const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,
-                                 float* dx, void* planes, void* stream);
+                                 float* dx, void* planes, const unsigned* bound_aux, void* stream);
 
 /* plain activation (no BN) forward / backward on [n] elements; used by conv(+bias)+act
  * units without BN, if any */

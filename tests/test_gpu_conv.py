@@ -136,25 +136,29 @@ PLANES_CASES = [
 ]
 
 
-def test_split_planes_is_exact():
-    """h + m + l reproduces every fp32 value of magnitude >= 2^-110 bit for bit (the three 8-bit pieces
-    need exponents down to e-23 >= -133, the smallest bf16 subnormal); smaller values lose bits below
-    2^-133 only; rows past the end and the extra block are zero"""
+def test_split_planes_accuracy_and_layout():
+    """planes format (csrc/planes.hpp): |s*x - h - l| <= max(2^-22 |s*x|, 2^-25), s a power of two with
+    s*max|x| in (2^14, 2^15]; rows past the end and the extra block are zero; header = {bits of max|x|, s, 1/s}"""
     from tf2_yolo_amd import ops
     g = torch.Generator().manual_seed(11)
     rows, c = 37, 48
-    x = (torch.randn(rows, c, generator=g) * torch.logspace(-30, 30, rows * c).reshape(rows, c)).float()
-    x[0, :4] = torch.tensor([0.0, 3.0e-33, 1e-40, float(2 ** -126)])   # zero, ~2^-108, a subnormal, the smallest normal
+    x = (torch.randn(rows, c, generator=g) * torch.logspace(-9, 0, rows * c).reshape(rows, c)).float()
+    x[0, :3] = torch.tensor([0.0, 1e-30, -2.5])
     pl = ops.split_planes(x.cuda(), rows, c).cpu()
     nblk = (rows + 15) // 16
-    assert pl.numel() == (nblk + 1) * (c // 16) * 1536
-    u = pl.view(torch.int16).reshape(nblk + 1, c // 16, 3, 2, 16, 8)          # [blk][kb][plane][half][row][8]
-    f = (u.to(torch.int32) << 16).view(torch.float32)                          # bf16 -> fp32 (exact)
-    f = f.permute(2, 0, 4, 1, 3, 5).reshape(3, (nblk + 1) * 16, c)             # [plane][row][channel]
-    rec = (f[2].double() + f[1].double() + f[0].double())
-    big = x.abs() >= 2.0 ** -110
-    assert torch.equal(rec[:rows][big].float(), x[big])
-    assert ((rec[:rows] - x.double()).abs()[~big] <= 2.0 ** -133).all()
+    body = (nblk + 1) * (c // 16) * 1024
+    assert pl.numel() == body + 256 == ops.planes_bytes(rows, c)
+    hdr = pl[body:body + 12].view(torch.float32)
+    amax = x.abs().max()
+    assert hdr[0] == amax and hdr[1] * hdr[2] == 1.0
+    s = float(hdr[1])
+    assert 2.0 ** 14 < s * float(amax) <= 2.0 ** 15 and s == 2.0 ** round(torch.log2(hdr[1]).item())
+    u = pl[:body].view(torch.float16).reshape(nblk + 1, c // 16, 2, 2, 16, 8)       # [blk][kb][plane][half][row][8]
+    f = u.permute(2, 0, 4, 1, 3, 5).reshape(2, (nblk + 1) * 16, c).double()         # [plane][row][channel]
+    rec = (f[0] + f[1])[:rows]
+    t = x.double() * s
+    err = (rec - t).abs()
+    assert (err <= torch.maximum(2.0 ** -22 * t.abs(), torch.tensor(2.0 ** -25, dtype=torch.float64))).all()
     assert (f[:, rows:] == 0).all()
 
 
@@ -173,9 +177,10 @@ def test_conv_fwd_planes(case):
     y = ops.conv2d_fwd_planes(d, xp, wp, bd, stats=stats)
     torch.cuda.synchronize()
     assert _relerr(y.double().cpu(), ref) < TOL
-    # same products in the same order as the register-staged split kernel: bit-identical results
+    # the exact bf16 x 6 kernel (register-staged, fp32 operands) and the fp16 x 3 planes kernel agree to a few
+    # fp32 roundings of the accumulated magnitude
     if cin % 32 == 0 and ops.CONV_MODE == "split":
-        assert torch.equal(y, ops.conv2d_fwd(d, xd, wd, bd))
+        assert _relerr(y.double(), ops.conv2d_fwd(d, xd, wd, bd).double()) < 1e-5
     got = stats.cpu().reshape(ops.BN_STAT_SLOTS, 2, cout).sum(0)
     r2 = ref.reshape(-1, cout)
     assert _relerr(got[1], (r2 * r2).sum(0)) < 1e-5

@@ -59,8 +59,12 @@ SIGNATURES = {
     "yolo_bn_act_fwd": (c_int, [_P, _LL, c_int, _P, _P, c_int, _P, _P, _P]),
     "yolo_bn_act_bwd_reduce": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "yolo_bn_act_bwd_apply": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
-    "yolo_bn_act_fwd_planes": (c_int, [_P, _LL, c_int, _P, _P, c_int, _P, _P, _P, _P]),
-    "yolo_bn_act_bwd_apply_planes": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
+    "yolo_bn_act_fwd_planes": (c_int, [_P, _LL, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "yolo_bn_act_bwd_apply_planes": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
+                                             _P]),
+    "yolo_bn_finalize_bound": (c_int, [_P, _LL, c_int, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
+                                       _P]),
+    "yolo_bn_act_bwd_reduce_bound": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "yolo_act_fwd": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_act_bwd": (c_int, [_P, _P, _LL, c_int, _P, _P]),
     "yolo_copy_channels_in": (c_int, [_P, _LL, c_int, _P, c_int, c_int, _P]),

@@ -104,7 +104,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, int unbiased, float* __restrict__ mmean, float* __restrict__ mvar,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
-                                   float* __restrict__ sinv) {
+                                   float* __restrict__ sinv, unsigned* __restrict__ bound) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   double s1 = 0.0, s2 = 0.0;
@@ -121,6 +121,12 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
   shift[c] = (float)((double)beta[c] - mean * (double)gamma[c] * inv);
   smean[c] = (float)mean;
   sinv[c] = (float)inv;
+  if (bound != nullptr) {
+    // |act(scale*y + shift)| <= |gamma| * |y - mean| * inv + |beta| and (y_i - mean)^2 <= sum_j (y_j - mean)^2 = P*var:
+    // an upper bound of the layer's output that needs no pass over the data (planes.hpp: any B >= max|x| will do)
+    const double b = fabs((double)gamma[c]) * inv * sqrt((double)P * var) * 1.001 + fabs((double)beta[c]) + 1e-30;
+    atomicMax(bound, __builtin_bit_cast(unsigned, (float)b));
+  }
   if (mmean != nullptr) {
     double fed = var;
     if (unbiased && P > 1) fed = var * (double)P / (double)(P - 1);
@@ -166,8 +172,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ smean,
                                                             const float* __restrict__ sinv, int act,
-                                                            double* __restrict__ red) {
+                                                            double* __restrict__ red, unsigned* __restrict__ aux) {
   __shared__ double smem[8 * 256];
+  float mdz = 0.f;
   const int tid = threadIdx.x;
   const int row_lane = tid / cw, col = tid - row_lane * cw;
   const int C4 = C >> 2;
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         for (int e = 0; e < 4; ++e) {
           const float z = fmaf(sc[e], xv[u][e], sh[e]);
           const float dz = dv[u][e] * act_grad(z, act);   // dv = 0 for out-of-range rows
+          mdz = fmaxf(mdz, fabsf(dz));
           const float xh = (xv[u][e] - mu[e]) * iv[e];
           v[0][e] += (double)dz;
           v[1][e] += (double)dz * (double)xh;
@@ -210,6 +218,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
   }
   block_col_reduce<2>(v, cw, rpp, row_lane, col, active, smem, red, C, c4);
+  if (aux != nullptr) {   // max |dz| of the tensor (bit patterns of non-negative floats order like integers)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mdz = fmaxf(mdz, __shfl_xor(mdz, o, 64));
+    if ((threadIdx.x & 63) == 0 && mdz > 0.f) atomicMax(&aux[0], __builtin_bit_cast(unsigned, mdz));
+  }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x,
@@ -273,12 +286,23 @@ static inline RowGeom row_geom(long long rows, int C) {
 }
 
 __device__ __forceinline__ void store_planes8(unsigned char* planes, long long row, int g8, int C, const f32x4 v0,
-                                              const f32x4 v1) {
-  const Planes8 s = split8(v0, v1);
+                                              const f32x4 v1, const float sc) {
+  const Planes8 s = split8(v0, v1, sc);
   unsigned char* o = planes + planes_unit_offset(row, g8, C);
   *reinterpret_cast<u32x4*>(o) = s.h;
-  *reinterpret_cast<u32x4*>(o + 512) = s.m;
-  *reinterpret_cast<u32x4*>(o + 1024) = s.l;
+  *reinterpret_cast<u32x4*>(o + 512) = s.l;
+}
+// every thread derives the tensor's scale from the bound; one thread completes the planes header
+__device__ __forceinline__ float planes_begin(unsigned char* planes, long long P, int C, float bound) {
+  const unsigned bits = __builtin_bit_cast(unsigned, bound);
+  const float sc = planes_scale_from_bound(bits);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    unsigned* header = reinterpret_cast<unsigned*>(planes + planes_body_bytes(P, C));
+    header[0] = bits;
+    reinterpret_cast<float*>(header)[1] = sc;
+    reinterpret_cast<float*>(header)[2] = 1.f / sc;
+  }
+  return sc;
 }
 
 template <bool PLANES>
@@ -287,8 +311,19 @@ __global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restric
                                                           const float* __restrict__ scale,
                                                           const float* __restrict__ shift, int act,
                                                           const float* __restrict__ res, float* __restrict__ out,
-                                                          unsigned char* __restrict__ planes) {
+                                                          unsigned char* __restrict__ planes,
+                                                          const unsigned* __restrict__ bn_bound,
+                                                          const float* __restrict__ res_bound,
+                                                          float* __restrict__ out_bound) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // bound of the output = bound of the BN/activation part (bn_finalize) + bound of the residual
+  float psc = 1.f;
+  if (PLANES || out_bound != nullptr) {
+    const float b = (bn_bound ? __builtin_bit_cast(float, bn_bound[0]) : 0.f) +
+                    ((res != nullptr && res_bound != nullptr) ? res_bound[0] : 0.f);
+    if (out_bound != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) out_bound[0] = b;
+    if (PLANES) psc = planes_begin(planes, P, C, b);
+  }
   const int g8 = (blockIdx.y * wpr + wave % wpr) * 4 + (lane >> 4);
   if (g8 >= (C >> 3)) return;
   const int slots = 4 / wpr;
@@ -315,7 +350,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restric
       *reinterpret_cast<f32x4*>(out + e) = o0;
       *reinterpret_cast<f32x4*>(out + e + 4) = o1;
     }
-    if (PLANES) store_planes8(planes, p, g8, C, o0, o1);
+    if (PLANES) store_planes8(planes, p, g8, C, o0, o1, psc);
   }
 }
 
@@ -331,8 +366,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
                                                             const float* __restrict__ smean,
                                                             const float* __restrict__ sinv, int act,
                                                             const double* __restrict__ red, float* __restrict__ dx,
-                                                            unsigned char* __restrict__ planes) {
+                                                            unsigned char* __restrict__ planes,
+                                                            const unsigned* __restrict__ aux) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // |dx| <= max_c|scale_c| * max|dz| + max_c |scale_c| (|mean(dz xhat)| sqrt(P) + |mean(dz)|): aux = {max|dz|,
+  // max|scale|, max of the second term} from the reduce / sum kernels
+  float psc = 1.f;
+  if (PLANES) {
+    const float b = __builtin_bit_cast(float, aux[0]) * __builtin_bit_cast(float, aux[1]) * 1.001f +
+                    __builtin_bit_cast(float, aux[2]) + 1e-30f;
+    psc = planes_begin(planes, P, C, b);
+  }
   const int g8 = (blockIdx.y * wpr + wave % wpr) * 4 + (lane >> 4);
   if (g8 >= (C >> 3)) return;
   const int slots = 4 / wpr;
@@ -370,17 +414,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
         *reinterpret_cast<f32x4*>(dx + e + 4) = o1;
       }
     }
-    if (PLANES) store_planes8(planes, p, g8, C, o0, o1);
+    if (PLANES) store_planes8(planes, p, g8, C, o0, o1, psc);
   }
 }
 
 // red layout: [SLOTS replicas][2][C] followed by the final [2][C] sums
-__global__ void bn_bwd_sum_kernel(int C, double* __restrict__ red) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 2C
-  if (i >= 2 * C) return;
-  double s = 0.0;
-  for (int r = 0; r < YOLO_BN_STAT_SLOTS; ++r) s += red[(long long)r * 2 * C + i];
-  red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + i] = s;
+__global__ void bn_bwd_sum_kernel(int C, double* __restrict__ red, long long P, const float* __restrict__ scale,
+                                  unsigned* __restrict__ aux) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s0 = 0.0, s1 = 0.0;
+  for (int r = 0; r < YOLO_BN_STAT_SLOTS; ++r) {
+    s0 += red[(long long)r * 2 * C + c];
+    s1 += red[(long long)r * 2 * C + C + c];
+  }
+  red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + c] = s0;
+  red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + C + c] = s1;
+  if (aux != nullptr) {   // per-channel parts of the bound of dx (bn_bwd_apply8_kernel): |x - mean| * invstd <= sqrt(P)
+    const double asc = fabs((double)scale[c]);
+    const double t2 = asc * (fabs(s1 / (double)P) * sqrt((double)P) + fabs(s0 / (double)P)) * 1.001;
+    atomicMax(&aux[1], __builtin_bit_cast(unsigned, (float)asc));
+    atomicMax(&aux[2], __builtin_bit_cast(unsigned, (float)t2));
+  }
 }
 
 __global__ void bn_bwd_params_kernel(int C, const double* __restrict__ redsum, float* __restrict__ dgamma,
@@ -421,16 +476,24 @@ extern "C" int yolo_bn_stats(const float* x, long long P, int C, double* stats, 
   return check_launch("bn_stats_kernel");
 }
 
-extern "C" int yolo_bn_finalize(double* stats, long long P, int C, const float* gamma, const float* beta, float eps,
-                                float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
-                                float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+extern "C" int yolo_bn_finalize_bound(double* stats, long long P, int C, const float* gamma, const float* beta,
+                                      float eps, float momentum, int unbiased_moving_var, float* moving_mean,
+                                      float* moving_var, float* scale, float* shift, float* save_mean,
+                                      float* save_invstd, unsigned* bound, void* stream) {
   YOLO_REQUIRE(stats && gamma && beta && scale && shift && save_mean && save_invstd && P > 0 && C > 0,
                "bn_finalize: bad args");
   YOLO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must come in pairs");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), stats, P, C, gamma,
                      beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var, scale, shift, save_mean,
-                     save_invstd);
+                     save_invstd, bound);
   return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int yolo_bn_finalize(double* stats, long long P, int C, const float* gamma, const float* beta, float eps,
+                                float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
+                                float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+  return yolo_bn_finalize_bound(stats, P, C, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
+                                scale, shift, save_mean, save_invstd, nullptr, stream);
 }
 
 extern "C" int yolo_bn_fold_inference(int C, const float* gamma, const float* beta, const float* moving_mean,
@@ -442,21 +505,27 @@ extern "C" int yolo_bn_fold_inference(int C, const float* gamma, const float* be
 }
 
 extern "C" int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scale, const float* shift,
-                                      int act, const float* residual, float* out, void* planes, void* stream) {
+                                      int act, const float* residual, float* out, void* planes,
+                                      const unsigned* bn_bound, const float* residual_bound, float* out_bound,
+                                      void* stream) {
   YOLO_REQUIRE(x && scale && shift && out && P > 0 && C > 0, "bn_act_fwd: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_fwd: C=%d must be a multiple of 4", C);
   YOLO_REQUIRE(act >= 0 && act <= 2, "bn_act_fwd: bad activation %d", act);
   YOLO_REQUIRE(planes == nullptr || C % 16 == 0, "bn_act_fwd: planes output needs C %% 16 == 0 (C=%d)", C);
+  YOLO_REQUIRE(planes == nullptr || bn_bound != nullptr, "bn_act_fwd: planes output needs the bound from bn_finalize");
+  YOLO_REQUIRE(planes == nullptr || residual == nullptr || residual_bound != nullptr,
+               "bn_act_fwd: planes output with a residual needs the residual's bound");
   if (C % 8 == 0) {
     const long long rows = planes ? ((P + 15) / 16 + 1) * 16 : P;
     const RowGeom g = row_geom(rows, C);
     if (planes)
       hipLaunchKernelGGL(bn_act_fwd8_kernel<true>, dim3(g.gx, g.gy), dim3(256), 0, as_stream(stream), x, P, C, g.wpr,
                          g.blocks_per_wg, rows, scale, shift, act, residual, out,
-                         reinterpret_cast<unsigned char*>(planes));
+                         reinterpret_cast<unsigned char*>(planes), bn_bound, residual_bound, out_bound);
     else
       hipLaunchKernelGGL(bn_act_fwd8_kernel<false>, dim3(g.gx, g.gy), dim3(256), 0, as_stream(stream), x, P, C, g.wpr,
-                         g.blocks_per_wg, rows, scale, shift, act, residual, out, (unsigned char*)nullptr);
+                         g.blocks_per_wg, rows, scale, shift, act, residual, out, (unsigned char*)nullptr, bn_bound,
+                         residual_bound, out_bound);
     return check_launch("bn_act_fwd8_kernel");
   }
   const long long n4 = P * (C / 4);
@@ -467,32 +536,42 @@ extern "C" int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const 
 
 extern "C" int yolo_bn_act_fwd(const float* x, long long P, int C, const float* scale, const float* shift, int act,
                                const float* residual, float* out, void* stream) {
-  return yolo_bn_act_fwd_planes(x, P, C, scale, shift, act, residual, out, nullptr, stream);
+  return yolo_bn_act_fwd_planes(x, P, C, scale, shift, act, residual, out, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-extern "C" int yolo_bn_act_bwd_reduce(const float* x, const float* dout, long long P, int C, const float* scale,
-                                      const float* shift, const float* save_mean, const float* save_invstd, int act,
-                                      double* red, void* stream) {
+extern "C" int yolo_bn_act_bwd_reduce_bound(const float* x, const float* dout, long long P, int C, const float* scale,
+                                            const float* shift, const float* save_mean, const float* save_invstd,
+                                            int act, double* red, unsigned* bound_aux, void* stream) {
   YOLO_REQUIRE(x && dout && scale && shift && save_mean && save_invstd && red && P > 0 && C > 0,
                "bn_act_bwd_reduce: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_reduce: C=%d must be a multiple of 4", C);
   const ColGeom g = col_geom(C / 4);
   dim3 grid(reduce_grid_x(P, g.rpp), (C / 4 + g.cw - 1) / g.cw);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, dout, P, C, g.cw, g.rpp, scale,
-                     shift, save_mean, save_invstd, act, red);
-  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((2 * C + 255) / 256), dim3(256), 0, as_stream(stream), C, red);
+                     shift, save_mean, save_invstd, act, red, bound_aux);
+  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), C, red, P, scale,
+                     bound_aux);
   return check_launch("bn_bwd_reduce_kernel");
+}
+
+extern "C" int yolo_bn_act_bwd_reduce(const float* x, const float* dout, long long P, int C, const float* scale,
+                                      const float* shift, const float* save_mean, const float* save_invstd, int act,
+                                      double* red, void* stream) {
+  return yolo_bn_act_bwd_reduce_bound(x, dout, P, C, scale, shift, save_mean, save_invstd, act, red, nullptr, stream);
 }
 
 extern "C" int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, long long P, int C, const float* gamma,
                                             const float* scale, const float* shift, const float* save_mean,
                                             const float* save_invstd, int act, double* red, float* dgamma,
-                                            float* dbeta, float* dx, void* planes, void* stream) {
+                                            float* dbeta, float* dx, void* planes, const unsigned* bound_aux,
+                                            void* stream) {
   (void)gamma;
   YOLO_REQUIRE(x && dout && scale && shift && save_mean && save_invstd && red && (dx || planes) && P > 0 && C > 0,
                "bn_act_bwd_apply: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_apply: C=%d must be a multiple of 4", C);
   YOLO_REQUIRE(planes == nullptr || C % 16 == 0, "bn_act_bwd_apply: planes output needs C %% 16 == 0 (C=%d)", C);
+  YOLO_REQUIRE(planes == nullptr || bound_aux != nullptr,
+               "bn_act_bwd_apply: planes output needs the bound words of yolo_bn_act_bwd_reduce_bound");
   const long long n4 = P * (C / 4);
   hipStream_t st = as_stream(stream);
   const double* redsum = red + (long long)YOLO_BN_STAT_SLOTS * 2 * C;
@@ -502,7 +581,8 @@ extern "C" int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, l
     unsigned char* pl = reinterpret_cast<unsigned char*>(planes);
 #define YOLO_BWD8(PL, DX)                                                                                            \
   hipLaunchKernelGGL((bn_bwd_apply8_kernel<PL, DX>), dim3(g.gx, g.gy), dim3(256), 0, st, x, dout, P, C, g.wpr,       \
-                     g.blocks_per_wg, rows, 1.0 / (double)P, scale, shift, save_mean, save_invstd, act, redsum, dx, pl)
+                     g.blocks_per_wg, rows, 1.0 / (double)P, scale, shift, save_mean, save_invstd, act, redsum, dx, pl,  \
+                     bound_aux)
     if (planes && dx) YOLO_BWD8(true, true);
     else if (planes) YOLO_BWD8(true, false);
     else YOLO_BWD8(false, true);
@@ -525,7 +605,7 @@ extern "C" int yolo_bn_act_bwd_apply(const float* x, const float* dout, long lon
                                      float* dx, void* stream) {
   YOLO_REQUIRE(dx != nullptr, "bn_act_bwd_apply: bad args");
   return yolo_bn_act_bwd_apply_planes(x, dout, P, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma,
-                                      dbeta, dx, nullptr, stream);
+                                      dbeta, dx, nullptr, nullptr, stream);
 }
 
 extern "C" int yolo_act_fwd(const float* x, long long n, int act, float* out, void* stream) {

@@ -1,30 +1,39 @@
-// Convolution forward / dgrad on operands that were split into bf16 planes BEFORE the kernel runs
-// ("planes" format, yolo_split_planes) and that reach LDS by LDS-DMA (buffer_load ... lds): the main
-// loop has no VALU split arithmetic, no ds_write and no VGPR staging -- only DMA issue, fragment
-// reads and the 6 MFMA passes per 32x32 fragment pair of the exact bf16 x 6 product (conv_split.hip).
-//
-// Planes format of a row-major fp32 matrix X[rows][C] (rows = pixels of an NHWC tensor or the output
-// channels of a KRSC filter; C % 16 == 0): 16-row blocks, inside a block one 1536-byte record per
-// 16-channel block kb, inside a record six 256-byte sub-blocks (plane p in {h,m,l}) x (half hf in {0,1}),
-// each sub-block = 16 rows x 8 bf16 (one 16-byte unit per row):
-//     byte(row, c) = ((row>>4) * C/16 + c/16) * 1536 + (2*p + (c%16)/8) * 256 + (row&15) * 16 + (c%8)*2
-// followed by ONE all-zero block (the target of padding taps and of rows/columns past the matrix edge).
-// Why this shape: an MFMA 32x32x16 operand fragment is "lane (r, hf) holds 8 consecutive k of row r";
-// a DMA wave-instruction writes 64 lanes x 16 B lane-linearly into LDS. With lane (r, hf) fetching unit
-// (row r, half hf) the LDS image of a 32-row block IS the fragment: reads are linear ds_read_b128
-// (conflict-free), while adjacent lanes = adjacent rows fetch adjacent 16-byte units of one 256-byte
-// sub-block, i.e. whole cache lines (a row-major planes layout cannot have both).
+// Convolution forward / dgrad on operands that were split into fp16 planes BEFORE the kernel runs ("planes"
+// format, planes.hpp) and that reach LDS by LDS-DMA (buffer_load ... lds): the main loop has no VALU split
+// arithmetic, no ds_write and no VGPR staging -- only DMA issue, fragment reads and the 3 fp16 MFMA passes
+// (l*h, h*l, h*h) per 32x32 fragment pair; the epilogue undoes the two power-of-two operand scales.
 #include "planes.hpp"
 #include <cstdlib>
 #include <type_traits>
 
 namespace yolo {
 
-// one thread = (row, 8-channel group); adjacent lanes read adjacent 32-byte pieces of a row
+// ---- producing planes from fp32 (tensors that no fused producer writes: filters, concat outputs, ...) ----
+// pass 1: max |x| -> header[0] (bit pattern; non-negative floats order like unsigned integers)
+__global__ __launch_bounds__(256) void planes_amax_kernel(const float* __restrict__ x, long long n4,
+                                                         unsigned* __restrict__ header) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(header, __builtin_bit_cast(unsigned, m));
+}
+
+// pass 2: one thread = (row, 8-channel group); adjacent lanes read adjacent 32-byte pieces of a row.
+// Also zero-fills the rows past the end + the zero block and completes the header (scale, 1/scale).
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long rows, int C,
                                                           unsigned char* __restrict__ out, long long rows_padded) {
+  unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
+  const float sc = planes_scale_from_bound(header[0]);
   const int G = C >> 3;
   const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) {
+    reinterpret_cast<float*>(header)[1] = sc;
+    reinterpret_cast<float*>(header)[2] = 1.f / sc;
+  }
   if (t >= rows_padded * G) return;
   const long long row = t / G;
   const int g = (int)(t - row * G);
@@ -34,20 +43,19 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     v0 = *reinterpret_cast<const f32x4*>(p);
     v1 = *reinterpret_cast<const f32x4*>(p + 4);
   }
-  const Planes8 s = split8(v0, v1);
-  unsigned char* o = out + ((row >> 4) * (C >> 4) + (g >> 1)) * PL_RECORD + (g & 1) * 256 + (row & 15) * 16;
+  const Planes8 s = split8(v0, v1, sc);
+  unsigned char* o = out + planes_unit_offset(row, g, C);
   *reinterpret_cast<u32x4*>(o) = s.h;
-  *reinterpret_cast<u32x4*>(o + 512) = s.m;
-  *reinterpret_cast<u32x4*>(o + 1024) = s.l;
+  *reinterpret_cast<u32x4*>(o + 512) = s.l;
 }
 
 // Workgroup tile BM x BN, NW = WGM*WGN waves; every wave is also the loader of ONE 32-row block of
-// A (waves 0 .. BM/32-1) or B (the rest): three DMA instructions (planes h, m, l) per 16-k stage.
+// A (waves 0 .. BM/32-1) or B (the rest): two DMA instructions (planes h, l) per 16-k stage.
 // Ring of 3 stage buffers in LDS + 2 fragment register sets, one barrier per stage. Iteration kt:
-//   wait vmcnt(3)  -> my DMAs of stage kt+1 have landed (those of kt+2 may still fly)
+//   wait vmcnt(2)  -> my DMAs of stage kt+1 have landed (those of kt+2 may still fly)
 //   barrier        -> everybody's have; everybody finished reading stage kt's buffer (last iteration)
 //   read fragments of stage kt+1 into the other register set
-//   6 MFMA passes per fragment pair on stage kt's registers, with the 3 DMAs of stage kt+3 (into stage
+//   3 MFMA passes per fragment pair on stage kt's registers, with the 2 DMAs of stage kt+3 (into stage
 //   kt's buffer) issued between them
 template <int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(const GatherConvArgs a) {
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   constexpr int TN = BN / WGN / 32;
   constexpr int RBA = BM / 32, RBB = BN / 32;
   static_assert(RBA + RBB <= NW, "at least one loader wave per 32-row block");
-  constexpr int STAGE_BYTES = (RBA + RBB) * 3 * 1024;
+  constexpr int STAGE_BYTES = (RBA + RBB) * PL_PLANES * 1024;
   constexpr int NBUF = 3;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -101,7 +109,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   const void* pbase = loadA ? (const void*)a.src : (const void*)a.wgt;
   const unsigned pbytes = loadA ? a.src_bytes : a.wgt_bytes;
   const i32x4 rsrc = planes_rsrc(pbase, pbytes);
-  const unsigned lds_mine = lds_base + ((loadA ? 0 : RBA) + rb) * 3 * 1024;
+  const unsigned lds_mine = lds_base + ((loadA ? 0 : RBA) + rb) * PL_PLANES * 1024;
 
   const int cpt = a.Cs >> 4;  // stages per tap
   const int nk = a.ntaps * cpt;
@@ -142,7 +150,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   auto issue_stage = [&](int buf) {
     issue_plane(0, buf);
     issue_plane(1, buf);
-    issue_plane(2, buf);
     loader_next();
   };
 
@@ -155,40 +162,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
 
   // two fragment register sets: the MFMAs of stage kt run on one while stage kt+1 is read into the other
-  bf16x8 fa[2][3][TM], fb[2][3][TN];
+  f16x8 fa[2][PL_PLANES][TM], fb[2][PL_PLANES][TN];
   auto read_frags = [&](int buf, auto SET) {
     constexpr int S = decltype(SET)::value;
     const unsigned char* sb = smem + buf * STAGE_BYTES + lane * 16;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < PL_PLANES; ++p) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        fa[S][p][i] = *reinterpret_cast<const bf16x8*>(sb + ((wm * TM + i) * 3 + p) * 1024);
+        fa[S][p][i] = *reinterpret_cast<const f16x8*>(sb + ((wm * TM + i) * PL_PLANES + p) * 1024);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        fb[S][p][j] = *reinterpret_cast<const bf16x8*>(sb + ((RBA + wn * TN + j) * 3 + p) * 1024);
+        fb[S][p][j] = *reinterpret_cast<const f16x8*>(sb + ((RBA + wn * TN + j) * PL_PLANES + p) * 1024);
     }
   };
-  // six partial products, smallest first: l*h, h*l, m*m, m*h, h*m, h*h (planes: 0 = h, 1 = m, 2 = l).
-  // The three DMA instructions of the stage being issued sit between MFMA groups: their issue slots are
-  // covered by the matrix pipe working on the MFMAs already queued.
+  // three partial products, smallest first: l*h, h*l, h*h (planes: 0 = h, 1 = l). The two DMA instructions
+  // of the stage being issued sit between the MFMAs: their issue slots are covered by the matrix pipe working
+  // on the MFMAs already queued.
   auto mfma_stage = [&](auto SET, int wbuf) {
     constexpr int S = decltype(SET)::value;
-    constexpr int NM = TM * TN * 6;
+    constexpr int NM = TM * TN * 3;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      // q: (A plane, B plane) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-      const int pa = (q == 0) ? 2 : (q == 2 || q == 3) ? 1 : 0;
-      const int pb = (q == 1) ? 2 : (q == 2 || q == 4) ? 1 : 0;
+    for (int q = 0; q < 3; ++q) {
+      const int pa = (q == 0) ? 1 : 0;
+      const int pb = (q == 1) ? 1 : 0;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
           const int idx = (q * TM + i) * TN + j;
-          if (idx == NM / 4 - 1 || idx == NM / 2 - 1 || idx == (3 * NM) / 4 - 1) {
+          if (idx == NM / 3 - 1 || idx == (2 * NM) / 3 - 1) {
             __builtin_amdgcn_sched_barrier(0);
-            issue_plane(idx == NM / 4 - 1 ? 0 : idx == NM / 2 - 1 ? 1 : 2, wbuf);
+            issue_plane(idx == NM / 3 - 1 ? 0 : 1, wbuf);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -200,19 +206,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   using S1 = std::integral_constant<int, 1>;
 
   // prologue: stages 0..2 in flight (stages >= nk are dummies that read the zero block, so that every
-  // wave always has exactly 3 DMAs per stage on its counter), stage 0's fragments in set 0
+  // wave always has exactly 2 DMAs per stage on its counter), stage 0's fragments in set 0
   loader_tap();
   issue_stage(0);
   issue_stage(1);
   issue_stage(2);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, S0{});
 
   // iteration kt: MFMAs of stage kt (registers) | fragment reads of stage kt+1 | DMA issue of stage kt+3
   // (into stage kt's buffer: everybody finished reading it before this iteration's barrier)
   auto step = [&](int rbuf, int wbuf, auto CUR, auto NXT) {
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // my pieces of stage kt+1 have landed
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // my pieces of stage kt+1 have landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage kt's buffer are done
     __builtin_amdgcn_s_barrier();
     read_frags(rbuf, NXT);
@@ -252,6 +258,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   }
   __syncthreads();
 
+  // 1 / (scale of A * scale of B): both powers of two (planes headers)
+  const float unscale =
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2] *
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wgt) + a.wgt_bytes - PL_HEADER)[2];
   float* sred = smf + 2 * BM;
   float csum[TN], csq[TN];
 #pragma unroll
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
         const int row = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
         const long long off = rowoff[row];
         if (cok && off >= 0) {
-          float v = acc[i][j][q] + bv;
+          float v = fmaf(acc[i][j][q], unscale, bv);
           if (a.accumulate) v += a.dst[off + col];
           a.dst[off + col] = v;
           s1 += v;
@@ -317,7 +327,7 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
     return YOLO_ERR_INVALID_ARG;
   }
   a.nblocks = (int)nb;
-  constexpr size_t lds = 3 * (BM / 32 + BN / 32) * 3 * 1024;
+  constexpr size_t lds = 3 * (BM / 32 + BN / 32) * PL_PLANES * 1024;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN>),
@@ -328,9 +338,7 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
   return check_launch("gather_conv_planes_kernel");
 }
 
-long long planes_bytes(long long rows, int C) {
-  return ((rows + 15) / 16 + 1) * (long long)(C / 16) * PL_RECORD;
-}
+long long planes_bytes(long long rows, int C) { return planes_body_bytes(rows, C) + PL_HEADER; }
 
 bool gather_planes_supported(const GatherConvArgs& a) { return (a.Cs % 16) == 0 && a.Cout > 32; }
 
@@ -366,16 +374,48 @@ __device__ __forceinline__ int find_job(const BatchJob* jobs, int njobs, long lo
   return lo;
 }
 
-// split job: a = rows, b = C
+// split job: a = rows, b = C. Three launches over the same job table: clear the bound, max |x|, split.
+__global__ void planes_header_clear_batch_kernel(const BatchJob* __restrict__ jobs, int njobs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= njobs) return;
+  unsigned* header = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(jobs[i].dst) +
+                                                 planes_body_bytes(jobs[i].a, (int)jobs[i].b));
+  header[0] = 0u;
+}
+__global__ __launch_bounds__(256) void planes_amax_batch_kernel(const BatchJob* __restrict__ jobs, int njobs) {
+  const BatchJob j = jobs[find_job(jobs, njobs, blockIdx.x)];
+  const float* x = reinterpret_cast<const float*>(j.src);
+  const long long n8 = j.a * (j.b >> 3);   // the job's workgroups cover rows_padded * C/8 >= n8 threads
+  const long long t = ((long long)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+  float m = 0.f;
+  if (t < n8) {
+    const f32x4 v0 = reinterpret_cast<const f32x4*>(x)[2 * t], v1 = reinterpret_cast<const f32x4*>(x)[2 * t + 1];
+    m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
+              fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) {
+    unsigned* header = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(j.dst) +
+                                                   planes_body_bytes(j.a, (int)j.b));
+    atomicMax(header, __builtin_bit_cast(unsigned, m));
+  }
+}
 __global__ __launch_bounds__(256) void split_planes_batch_kernel(const BatchJob* __restrict__ jobs, int njobs) {
   const BatchJob j = jobs[find_job(jobs, njobs, blockIdx.x)];
   const float* x = reinterpret_cast<const float*>(j.src);
   unsigned char* out = reinterpret_cast<unsigned char*>(j.dst);
   const long long rows = j.a;
   const int C = (int)j.b;
+  unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
+  const float sc = planes_scale_from_bound(header[0]);
   const long long rows_padded = ((rows + 15) / 16 + 1) * 16;
   const int G = C >> 3;
   const long long t = ((long long)blockIdx.x - j.first_block) * 256 + threadIdx.x;
+  if (t == 0) {
+    reinterpret_cast<float*>(header)[1] = sc;
+    reinterpret_cast<float*>(header)[2] = 1.f / sc;
+  }
   if (t >= rows_padded * G) return;
   const long long row = t / G;
   const int g = (int)(t - row * G);
@@ -385,11 +425,10 @@ __global__ __launch_bounds__(256) void split_planes_batch_kernel(const BatchJob*
     v0 = *reinterpret_cast<const f32x4*>(p);
     v1 = *reinterpret_cast<const f32x4*>(p + 4);
   }
-  const Planes8 s = split8(v0, v1);
+  const Planes8 s = split8(v0, v1, sc);
   unsigned char* o = out + planes_unit_offset(row, g, C);
   *reinterpret_cast<u32x4*>(o) = s.h;
-  *reinterpret_cast<u32x4*>(o + 512) = s.m;
-  *reinterpret_cast<u32x4*>(o + 1024) = s.l;
+  *reinterpret_cast<u32x4*>(o + 512) = s.l;
 }
 
 // transpose job: a = Cout, b = taps, c = Cin;  wT[ci][t][co] = w[co][t][ci]
@@ -421,8 +460,10 @@ int launch_split_planes_batch(const void* jobs, int njobs, long long total_block
     set_error("split_planes_batch: bad job table");
     return YOLO_ERR_INVALID_ARG;
   }
-  hipLaunchKernelGGL(split_planes_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st,
-                     reinterpret_cast<const BatchJob*>(jobs), njobs);
+  const BatchJob* jb = reinterpret_cast<const BatchJob*>(jobs);
+  hipLaunchKernelGGL(planes_header_clear_batch_kernel, dim3((njobs + 255) / 256), dim3(256), 0, st, jb, njobs);
+  hipLaunchKernelGGL(planes_amax_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jb, njobs);
+  hipLaunchKernelGGL(split_planes_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st, jb, njobs);
   return check_launch("split_planes_batch_kernel");
 }
 
@@ -448,8 +489,15 @@ int launch_split_planes(const float* x, long long rows, int C, void* planes, hip
     set_error("split_planes: tensor too large");
     return YOLO_ERR_INVALID_ARG;
   }
-  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, rows, C,
-                     reinterpret_cast<unsigned char*>(planes), rows_padded);
+  unsigned char* out = reinterpret_cast<unsigned char*>(planes);
+  unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
+  if (hipMemsetAsync(header, 0, 16, st) != hipSuccess) {
+    set_error("split_planes: hipMemsetAsync failed");
+    return YOLO_ERR_LAUNCH;
+  }
+  const long long n4 = rows * (C / 4);
+  hipLaunchKernelGGL(planes_amax_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, st, x, n4, header);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, rows, C, out, rows_padded);
   return check_launch("split_planes_kernel");
 }
 

@@ -4,7 +4,8 @@
 // grid.y and combined with fp32 atomics (as wgrad_split_kernel). Both operands are pixel-major, the
 // MFMA wants 8 consecutive pixels per lane: the fragments come from the transposing LDS read
 // ds_read_b64_tr_b16, which per 16-lane group turns a 4(pixel) x 16(channel) block into "4 pixels of MY
-// channel" -- and a 256-byte sub-block of the planes format IS a 16(pixel) x 8(channel) matrix.
+// channel" -- and a 256-byte sub-block of the planes format IS a 16(pixel) x 8(channel) matrix. Three fp16
+// MFMA passes (l*h, h*l, h*h) per fragment pair; the epilogue undoes the two power-of-two operand scales.
 //
 // One DMA piece (64 lanes x 16 B = 1 KiB) = 16 pixels x 32 channels of one plane = 4 sub-blocks.
 // Lane l fetches the unit (pixel 4*(l>>4) + (l&3), sub-block (l>>2)&3): quads of lanes read 64 contiguous
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   constexpr int TN = BN / WGN / 32;
   constexpr int RBA = BM / 32, RBB = BN / 32;
   static_assert(RBA + RBB <= NW, "at least one loader wave per 32-channel block");
-  constexpr int STAGE_BYTES = (RBA + RBB) * 3 * 1024;
+  constexpr int STAGE_BYTES = (RBA + RBB) * PL_PLANES * 1024;
   constexpr int NBUF = 3;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   const unsigned strideB = (unsigned)((a.Cs >> 4) * PL_RECORD);
   const unsigned zeroA = (unsigned)a.zero_blk_dy * strideA, zeroB = (unsigned)a.zero_blk_src * strideB;
   const i32x4 rsrc = planes_rsrc(loadA ? (const void*)a.dy : (const void*)a.src, loadA ? a.dy_bytes : a.src_bytes);
-  const unsigned lds_mine = lds_base + ((loadA ? 0 : RBA) + rb) * 3 * 1024;
+  const unsigned lds_mine = lds_base + ((loadA ? 0 : RBA) + rb) * PL_PLANES * 1024;
 
   // A (dy): unit (pixel block, 16-channel block co16, half, pixel); advances one pixel block per stage
   bool lane_ok;
@@ -123,7 +124,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   auto issue_stage = [&](int buf) {
     issue_plane(0, buf);
     issue_plane(1, buf);
-    issue_plane(2, buf);
     loader_next();
   };
 
@@ -141,42 +141,42 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   const int qq = i16 >> 2, pq = i16 & 3;
   const int tr_off = ((2 * (grp >> 1)) * 16 + ((grp & 1) * 2 + (pq >> 1)) * 4 + qq) * 16 + (pq & 1) * 8;
   typedef s16x4 __attribute__((address_space(3))) * lds_p;
-  auto tr_frag = [&](const unsigned char* piece) -> bf16x8 {
+  auto tr_frag = [&](const unsigned char* piece) -> f16x8 {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(piece + tr_off));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(piece + tr_off + 256));
     const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-    return __builtin_bit_cast(bf16x8, v);
+    return __builtin_bit_cast(f16x8, v);
   };
 
-  bf16x8 fa[2][3][TM], fb[2][3][TN];
+  f16x8 fa[2][PL_PLANES][TM], fb[2][PL_PLANES][TN];
   auto read_frags = [&](int buf, auto SET) {
     constexpr int S = decltype(SET)::value;
     const unsigned char* sb = smem + buf * STAGE_BYTES;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < PL_PLANES; ++p) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[S][p][i] = tr_frag(sb + ((wm * TM + i) * 3 + p) * 1024);
+      for (int i = 0; i < TM; ++i) fa[S][p][i] = tr_frag(sb + ((wm * TM + i) * PL_PLANES + p) * 1024);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[S][p][j] = tr_frag(sb + ((RBA + wn * TN + j) * 3 + p) * 1024);
+      for (int j = 0; j < TN; ++j) fb[S][p][j] = tr_frag(sb + ((RBA + wn * TN + j) * PL_PLANES + p) * 1024);
     }
   };
   auto mfma_stage = [&](auto SET, int wbuf) {
     constexpr int S = decltype(SET)::value;
-    constexpr int NM = TM * TN * 6;
+    constexpr int NM = TM * TN * 3;
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-      // q: (A plane, B plane) = (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-      const int pa = (q == 0) ? 2 : (q == 2 || q == 3) ? 1 : 0;
-      const int pb = (q == 1) ? 2 : (q == 2 || q == 4) ? 1 : 0;
+    for (int q = 0; q < 3; ++q) {
+      // q: (A plane, B plane) = (l,h) (h,l) (h,h)
+      const int pa = (q == 0) ? 1 : 0;
+      const int pb = (q == 1) ? 1 : 0;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
           const int idx = (q * TM + i) * TN + j;
-          if (idx == NM / 4 - 1 || idx == NM / 2 - 1 || idx == (3 * NM) / 4 - 1) {
+          if (idx == NM / 3 - 1 || idx == (2 * NM) / 3 - 1) {
             __builtin_amdgcn_sched_barrier(0);
-            issue_plane(idx == NM / 4 - 1 ? 0 : idx == NM / 2 - 1 ? 1 : 2, wbuf);
+            issue_plane(idx == NM / 3 - 1 ? 0 : 1, wbuf);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -191,12 +191,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   issue_stage(0);
   issue_stage(1);
   issue_stage(2);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, S0{});
 
   auto step = [&](int rbuf, int wbuf, auto CUR, auto NXT) {
-    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");   // my pieces of the next stage have landed
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // my pieces of the next stage have landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of the current stage's buffer are done
     __builtin_amdgcn_s_barrier();
     read_frags(rbuf, NXT);
@@ -218,6 +218,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy tail DMAs too
 
+  // 1 / (scale of dy * scale of x): both powers of two (planes headers)
+  const float unscale =
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.dy) + a.dy_bytes - PL_HEADER)[2] *
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int cj = j0 + (wn * TN + j) * 32 + (lane & 31);
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (cok && co < a.Cout) atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[i][j][r]);
+        if (cok && co < a.Cout) atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[i][j][r] * unscale);
       }
     }
   }
@@ -258,7 +262,7 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
     set_error("wgrad(planes): bad grid %lld x %lld", tiles, splits);
     return YOLO_ERR_INVALID_ARG;
   }
-  constexpr size_t lds = 3 * (BM / 32 + BN / 32) * 3 * 1024;
+  constexpr size_t lds = 3 * (BM / 32 + BN / 32) * PL_PLANES * 1024;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN>),

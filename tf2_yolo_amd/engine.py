@@ -329,6 +329,12 @@ class Network:
         self._wp_valid = False
         self._wTp_valid = False
         self._jobs_wp = self._jobs_wTp = self._jobs_wT = None
+        # bounds for the planes scales (planes.hpp): 4 words per conv unit {forward bound, max|dz|, max|scale|,
+        # second term of the dx bound}, zeroed every step; one float per tensor = bound of that activation
+        for i, u in enumerate(self.units):
+            u.aux_off = 4 * i
+        self._aux = torch.zeros(4 * max(len(self.units), 1), device=self.device, dtype=torch.int32)
+        self._tbound = torch.zeros(max(len(self.tensors), 1) + 1, device=self.device, dtype=torch.float32)
 
     # ---- construction -------------------------------------------------------------------
     def _declare_params(self):
@@ -499,8 +505,10 @@ class Network:
         self.training = training
         self.act[self.input.tid] = x
         self._xp_valid = set()
+        self._tbound_set = set()
         self._refresh_wplanes()
         if training:
+            self._aux.zero_()
             self._bn_f64.zero_()
             self._infer_scale_valid = False  # moving statistics (and the shared scale/shift) change
         P = self.params
@@ -516,16 +524,26 @@ class Network:
                         self._conv_fwd(u, xin, w, bias, u.y, stats)
                         ops.bn_finalize(stats, u.y.numel() // u.cout, u.cout, gamma, beta,
                                         self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
-                                        scale, shift, smean, sinv, unbiased=self.unbiased_moving_var)
+                                        scale, shift, smean, sinv, unbiased=self.unbiased_moving_var,
+                                        bound=self._aux[u.aux_off:u.aux_off + 1])
                     else:
                         self._conv_fwd(u, xin, w, bias, u.y)
                         if not self._infer_scale_valid:
                             ops.bn_fold_inference(u.cout, gamma, beta, self.state.view(u.s_mean.name),
                                                   self.state.view(u.s_var.name), scale, shift)
                     res = self.act[u.residual.tid] if u.residual is not None else None
-                    # consumers that are planes-capable convs get their operand straight from this kernel
-                    pl = self._xplanes.get(u.out.tid) if u.cout % 16 == 0 else None
-                    ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a, planes=pl)
+                    # consumers that are planes-capable convs get their operand straight from this kernel (training:
+                    # its scale comes from the batch statistics; inference has none -> separate split pass)
+                    pl = self._xplanes.get(u.out.tid) if (training and u.cout % 16 == 0) else None
+                    if u.residual is not None and u.residual.tid not in self._tbound_set:
+                        pl = None   # residual without a recorded bound: split its consumers' operand separately
+                    elif training:
+                        self._tbound_set.add(u.out.tid)
+                    tb = self._tbound
+                    ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a, planes=pl,
+                                   bn_bound=self._aux[u.aux_off:u.aux_off + 1] if training else None,
+                                   residual_bound=tb[u.residual.tid:u.residual.tid + 1] if u.residual is not None else None,
+                                   out_bound=tb[u.out.tid:u.out.tid + 1] if training else None)
                     if pl is not None:
                         self._xp_valid.add(u.out.tid)
                 else:
@@ -614,7 +632,8 @@ class Network:
                     dyp = self._next_dyp_buffer() if need_pl else None
                     dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
                                         sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta),
-                                        planes=dyp, want_dx=need_f32)
+                                        planes=dyp, want_dx=need_f32,
+                                        bound_aux=self._aux[u.aux_off + 1:u.aux_off + 4])
                 else:
                     dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
                     dyp = self._dyp(u, dy)

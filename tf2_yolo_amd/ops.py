@@ -312,10 +312,12 @@ def bn_stats(x, C, stats):
 
 
 def bn_finalize(stats, P, C, gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd,
-                eps=BN_EPS, momentum=BN_MOMENTUM, unbiased=False):
-    check(_lib.load().yolo_bn_finalize(_p(stats), P, C, _p(gamma), _p(beta), eps, momentum, int(unbiased),
-                                       _p(moving_mean), _p(moving_var), _p(scale), _p(shift), _p(save_mean),
-                                       _p(save_invstd), _stream()), "yolo_bn_finalize")
+                eps=BN_EPS, momentum=BN_MOMENTUM, unbiased=False, bound=None):
+    """bound: optional int32 CUDA tensor (1 word, zeroed) that receives the bit pattern of an upper bound of
+    max|act(BN(x))| (needed by bn_act_fwd(planes=...))"""
+    check(_lib.load().yolo_bn_finalize_bound(_p(stats), P, C, _p(gamma), _p(beta), eps, momentum, int(unbiased),
+                                             _p(moving_mean), _p(moving_var), _p(scale), _p(shift), _p(save_mean),
+                                             _p(save_invstd), _p(bound), _stream()), "yolo_bn_finalize")
 
 
 def bn_fold_inference(C, gamma, beta, moving_mean, moving_var, scale, shift, eps=BN_EPS):
@@ -323,34 +325,41 @@ def bn_fold_inference(C, gamma, beta, moving_mean, moving_var, scale, shift, eps
                                              _p(scale), _p(shift), _stream()), "yolo_bn_fold_inference")
 
 
-def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None, planes=None):
-    """planes: optional uint8 buffer (planes_bytes(P, C)) that also receives the result in the conv operand format"""
+def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None, planes=None, bn_bound=None, residual_bound=None,
+               out_bound=None):
+    """planes: optional uint8 buffer (planes_bytes(P, C)) that also receives the result in the conv operand format;
+    it needs bn_bound (from bn_finalize) and, with a residual, residual_bound (1 float: bound of the residual
+    tensor). out_bound (1 float, optional) receives the bound of the result."""
     if out is None:
         out = torch.empty_like(x)
     P = x.numel() // C
     if planes is not None and planes.numel() < planes_bytes(P, C):
         raise YoloHipError("bn_act_fwd: planes buffer too small")
     check(_lib.load().yolo_bn_act_fwd_planes(_p(x), P, C, _p(scale), _p(shift), act, _p(residual), _p(out), _p(planes),
-                                             _stream()), "yolo_bn_act_fwd")
+                                             _p(bn_bound), _p(residual_bound), _p(out_bound), _stream()),
+          "yolo_bn_act_fwd")
     return out
 
 
 def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dx=None,
-               planes=None, want_dx=True):
-    """returns dx (None when want_dx is False and only the planes of dx are produced)"""
+               planes=None, want_dx=True, bound_aux=None):
+    """returns dx (None when want_dx is False and only the planes of dx are produced). planes needs bound_aux:
+    int32 CUDA tensor of 3 zeroed words (filled by the reduce step, read by the apply step)."""
     P = x.numel() // C
     if planes is not None and planes.numel() < planes_bytes(P, C):
         raise YoloHipError("bn_act_bwd: planes buffer too small")
+    if planes is not None and bound_aux is None:
+        raise YoloHipError("bn_act_bwd: planes output needs bound_aux")
     if not want_dx and planes is None:
         raise YoloHipError("bn_act_bwd: nothing to produce")
     if dx is None and want_dx:
         dx = torch.empty_like(x)
     lib = _lib.load()
-    check(lib.yolo_bn_act_bwd_reduce(_p(x), _p(dout), P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
-                                     act, _p(red), _stream()), "yolo_bn_act_bwd_reduce")
+    check(lib.yolo_bn_act_bwd_reduce_bound(_p(x), _p(dout), P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
+                                           act, _p(red), _p(bound_aux), _stream()), "yolo_bn_act_bwd_reduce")
     check(lib.yolo_bn_act_bwd_apply_planes(_p(x), _p(dout), P, C, _p(gamma), _p(scale), _p(shift), _p(save_mean),
                                            _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta),
-                                           _p(dx if want_dx else None), _p(planes), _stream()),
+                                           _p(dx if want_dx else None), _p(planes), _p(bound_aux), _stream()),
           "yolo_bn_act_bwd_apply")
     return dx if want_dx else None
 
