@@ -26,13 +26,17 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs @ 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # same guide: dense bf16 MFMA peak
-SPLIT_PASSES = 6                # conv_split.hip: one fp32 product = 6 bf16 MFMA passes
+SPLIT_PASSES = 6                # conv_split.hip: one fp32 product = 6 bf16 MFMA passes (exact 3-way split)
+PLANES_PASSES = 3               # conv_planes.hip: one product = 3 fp16 MFMA passes (two scaled fp16 planes)
 
 
 def kernel_peak(name):
-    """Peak of ALGORITHMIC (fp32-equivalent) TFLOP/s for a kernel: the fp32-MFMA peak for the exact-fp32
-    kernels, the bf16-MFMA peak / 6 for the bf16x6 split kernels (each algorithmic FLOP costs 6 bf16 FLOPs)."""
-    return BF16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if ("split" in name or "planes" in name) else FP32_MFMA_PEAK_TFLOPS
+    """Peak of ALGORITHMIC (fp32-equivalent) TFLOP/s for a kernel: the fp32-MFMA peak for the fp32-MFMA kernels,
+    the 16-bit MFMA peak / 6 for the bf16x6 split kernels, / 3 for the fp16x3 planes kernels (each algorithmic
+    FLOP costs that many 16-bit MFMA FLOPs)."""
+    if "planes" in name:
+        return BF16_MFMA_PEAK_TFLOPS / PLANES_PASSES
+    return BF16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if "split" in name else FP32_MFMA_PEAK_TFLOPS
 BATCH = 32
 HW = 416
 CLASSES = 80
@@ -214,8 +218,10 @@ def main():
             achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
             peak = kernel_peak(name)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
-                    "peak_basis": ("bf16 MFMA dense peak 2500 TFLOP/s / 6 passes per fp32 product (exact 3-way split)"
-                                   if ("split" in name or "planes" in name) else "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"),
+                    "peak_basis": ("fp16 MFMA dense peak 2500 TFLOP/s / 3 passes per product (two scaled fp16 planes)"
+                                   if "planes" in name else
+                                   "bf16 MFMA dense peak 2500 TFLOP/s / 6 passes per fp32 product (exact 3-way split)"
+                                   if "split" in name else "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": hbm_traffic_from_profile(name),
                     "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -237,7 +243,7 @@ def main():
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "arithmetic": "fp32 storage and accumulation everywhere; conv fwd/dgrad/wgrad products = exact 3-way bf16 split x 6 MFMA passes (fp32-accurate, parity 1e-4 vs the float64 oracle); first conv (Cin=3) and Cout<=32 layers use the fp32-input MFMA kernels; YOLO_CONV_MODE=fp32 selects those everywhere",
+               "arithmetic": "fp32 storage and fp32 accumulation everywhere; conv operands enter the matrix cores as two scaled fp16 planes (22-23 significant bits, fp32 has 24), one product = 3 fp16 MFMA passes exact in the fp32 accumulator: measured 2e-6 from the exact kernels at K=9216, parity bar 1e-4 vs the float64 oracle; first conv (Cin=3), Cout<=32 layers and stride-2 filter gradients use the exact bf16x6 / fp32-input MFMA kernels; YOLO_CONV_PLANES=0 selects the exact bf16x6 kernels everywhere (474 img/s), YOLO_CONV_MODE=fp32 the fp32-input MFMA kernels",
                "config": {"workload": "YOLOv3 Darknet-53 416x416, 9 anchors / 3 FPN scales, C=80: training step = "
                                       "forward (batch-stat BN) + 3 fused loss/grad kernels + backward + "
                                       "gradient all-reduce + Adam",
