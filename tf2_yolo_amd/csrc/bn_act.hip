@@ -106,7 +106,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
                                    float* __restrict__ sinv, unsigned* __restrict__ bound) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  float bnd = 0.f;
+  if (c < C) {
   double s1 = 0.0, s2 = 0.0;
   for (int r = 0; r < YOLO_BN_STAT_SLOTS; ++r) {
     s1 += stats[(long long)r * 2 * C + c];
@@ -124,14 +125,19 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
   if (bound != nullptr) {
     // |act(scale*y + shift)| <= |gamma| * |y - mean| * inv + |beta| and (y_i - mean)^2 <= sum_j (y_j - mean)^2 = P*var:
     // an upper bound of the layer's output that needs no pass over the data (planes.hpp: any B >= max|x| will do)
-    const double b = fabs((double)gamma[c]) * inv * sqrt((double)P * var) * 1.001 + fabs((double)beta[c]) + 1e-30;
-    atomicMax(bound, __builtin_bit_cast(unsigned, (float)b));
+    bnd = (float)(fabs((double)gamma[c]) * inv * sqrt((double)P * var) * 1.001 + fabs((double)beta[c]) + 1e-30);
   }
   if (mmean != nullptr) {
     double fed = var;
     if (unbiased && P > 1) fed = var * (double)P / (double)(P - 1);
     mmean[c] = (float)((double)momentum * mmean[c] + (1.0 - (double)momentum) * mean);
     mvar[c] = (float)((double)momentum * mvar[c] + (1.0 - (double)momentum) * fed);
+  }
+  }
+  if (bound != nullptr) {   // one atomic per wave (a thousand atomics on one address cost more than the kernel)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, o, 64));
+    if ((threadIdx.x & 63) == 0 && bnd > 0.f) atomicMax(bound, __builtin_bit_cast(unsigned, bnd));
   }
 }
 
@@ -218,10 +224,17 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
   }
   block_col_reduce<2>(v, cw, rpp, row_lane, col, active, smem, red, C, c4);
-  if (aux != nullptr) {   // max |dz| of the tensor (bit patterns of non-negative floats order like integers)
+  if (aux != nullptr) {   // max |dz| of the tensor (bit patterns of non-negative floats order like integers):
+    // one atomic per workgroup, spread over 64 replica slots aux[4..67] (bn_bwd_sum_kernel folds them)
+    __shared__ float s_max[4];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) mdz = fmaxf(mdz, __shfl_xor(mdz, o, 64));
-    if ((threadIdx.x & 63) == 0 && mdz > 0.f) atomicMax(&aux[0], __builtin_bit_cast(unsigned, mdz));
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = mdz;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+      if (m > 0.f) atomicMax(&aux[4 + ((blockIdx.x + blockIdx.y) & 63)], __builtin_bit_cast(unsigned, m));
+    }
   }
 }
 
@@ -422,19 +435,40 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
 __global__ void bn_bwd_sum_kernel(int C, double* __restrict__ red, long long P, const float* __restrict__ scale,
                                   unsigned* __restrict__ aux) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int r = 0; r < YOLO_BN_STAT_SLOTS; ++r) {
-    s0 += red[(long long)r * 2 * C + c];
-    s1 += red[(long long)r * 2 * C + C + c];
+  float t1 = 0.f, t2 = 0.f;
+  if (c < C) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = 0; r < YOLO_BN_STAT_SLOTS; ++r) {
+      s0 += red[(long long)r * 2 * C + c];
+      s1 += red[(long long)r * 2 * C + C + c];
+    }
+    red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + c] = s0;
+    red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + C + c] = s1;
+    if (aux != nullptr) {   // per-channel parts of the bound of dx (bn_bwd_apply8_kernel): |x - mean| * invstd <= sqrt(P)
+      const double asc = fabs((double)scale[c]);
+      t1 = (float)asc;
+      t2 = (float)(asc * (fabs(s1 / (double)P) * sqrt((double)P) + fabs(s0 / (double)P)) * 1.001);
+    }
   }
-  red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + c] = s0;
-  red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + C + c] = s1;
-  if (aux != nullptr) {   // per-channel parts of the bound of dx (bn_bwd_apply8_kernel): |x - mean| * invstd <= sqrt(P)
-    const double asc = fabs((double)scale[c]);
-    const double t2 = asc * (fabs(s1 / (double)P) * sqrt((double)P) + fabs(s0 / (double)P)) * 1.001;
-    atomicMax(&aux[1], __builtin_bit_cast(unsigned, (float)asc));
-    atomicMax(&aux[2], __builtin_bit_cast(unsigned, (float)t2));
+  if (aux != nullptr) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      t1 = fmaxf(t1, __shfl_xor(t1, o, 64));
+      t2 = fmaxf(t2, __shfl_xor(t2, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (t1 > 0.f) atomicMax(&aux[1], __builtin_bit_cast(unsigned, t1));
+      if (t2 > 0.f) atomicMax(&aux[2], __builtin_bit_cast(unsigned, t2));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 64) {   // fold the 64 replica slots of max|dz|
+      unsigned m = aux[4 + threadIdx.x];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned v = __shfl_xor(m, o, 64);
+        m = v > m ? v : m;
+      }
+      if (threadIdx.x == 0) aux[0] = m;
+    }
   }
 }
 

@@ -329,11 +329,11 @@ class Network:
         self._wp_valid = False
         self._wTp_valid = False
         self._jobs_wp = self._jobs_wTp = self._jobs_wT = None
-        # bounds for the planes scales (planes.hpp): 4 words per conv unit {forward bound, max|dz|, max|scale|,
-        # second term of the dx bound}, zeroed every step; one float per tensor = bound of that activation
+        # bounds for the planes scales (planes.hpp): 72 words per conv unit, zeroed every step; one float per
+        # tensor = bound of that activation
         for i, u in enumerate(self.units):
-            u.aux_off = 4 * i
-        self._aux = torch.zeros(4 * max(len(self.units), 1), device=self.device, dtype=torch.int32)
+            u.aux_off = 72 * i    # [0] forward bound, [1..68] = the 68 words of yolo_bn_act_bwd_reduce_bound
+        self._aux = torch.zeros(72 * max(len(self.units), 1), device=self.device, dtype=torch.int32)
         self._tbound = torch.zeros(max(len(self.tensors), 1) + 1, device=self.device, dtype=torch.float32)
 
     # ---- construction -------------------------------------------------------------------
@@ -633,7 +633,7 @@ class Network:
                     dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
                                         sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta),
                                         planes=dyp, want_dx=need_f32,
-                                        bound_aux=self._aux[u.aux_off + 1:u.aux_off + 4])
+                                        bound_aux=self._aux[u.aux_off + 1:u.aux_off + 69])
                 else:
                     dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
                     dyp = self._dyp(u, dy)

@@ -344,12 +344,12 @@ def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None, planes=None, bn
 def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dx=None,
                planes=None, want_dx=True, bound_aux=None):
     """returns dx (None when want_dx is False and only the planes of dx are produced). planes needs bound_aux:
-    int32 CUDA tensor of 3 zeroed words (filled by the reduce step, read by the apply step)."""
+    int32 CUDA tensor of 68 zeroed words (filled by the reduce step, read by the apply step)."""
     P = x.numel() // C
     if planes is not None and planes.numel() < planes_bytes(P, C):
         raise YoloHipError("bn_act_bwd: planes buffer too small")
-    if planes is not None and bound_aux is None:
-        raise YoloHipError("bn_act_bwd: planes output needs bound_aux")
+    if planes is not None and (bound_aux is None or bound_aux.numel() < 68):
+        raise YoloHipError("bn_act_bwd: planes output needs bound_aux (68 zeroed int32 words)")
     if not want_dx and planes is None:
         raise YoloHipError("bn_act_bwd: nothing to produce")
     if dx is None and want_dx:
