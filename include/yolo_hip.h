@@ -70,6 +70,10 @@ typedef struct yolo_conv_desc {
 /* BatchNorm statistics buffers hold YOLO_BN_STAT_SLOTS replicas of [2*C] doubles (sum, sum of
  * squares); producers spread their atomics over the replicas, yolo_bn_finalize adds them up. */
 #define YOLO_BN_STAT_SLOTS 64
+/* The backward reduction buffer `red` of yolo_bn_act_bwd_* holds YOLO_BN_RED_SLOTS per-workgroup partial
+ * results of [2*C] doubles (every workgroup stores its own slot: no atomics, no zeroing needed) followed by
+ * the final [2*C] sums: (YOLO_BN_RED_SLOTS + 1) * 2 * C doubles. */
+#define YOLO_BN_RED_SLOTS 512
 
 /* y = conv(x, w) (+ bias if bias != NULL). If stats != NULL (double[YOLO_BN_STAT_SLOTS][2*Cout],
  * zeroed by the caller) the epilogue also accumulates per-channel sum / sum-of-squares of y for
@@ -161,7 +165,7 @@ int yolo_bn_act_fwd(const float* x, long long P, int C, const float* scale, cons
 
 /* Backward of out = act(BN_train(x)) given dout = dL/dout (the residual branch, if any,
  * receives dout unchanged and is handled by the caller).
- *   pass 1 (reduce): dgamma/dbeta partial sums -> red (double[(YOLO_BN_STAT_SLOTS+1)*2*C], caller-zeroed:
+ *   pass 1 (reduce): dgamma/dbeta partial sums -> red (double[(YOLO_BN_RED_SLOTS+1)*2*C]:
  *                    SLOTS atomic replicas followed by their sum)
  *   pass 2 (apply) : dx = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); dgamma, dbeta
  *                    are ACCUMULATED (+=) into the flat gradient buffer.

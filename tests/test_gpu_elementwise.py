@@ -38,7 +38,7 @@ def test_bn_act_train_fwd_bwd(C, act, use_res):
     xd = x.detach().float().to(dev)
     P = N * H * W
     stats = torch.zeros(64 * 2 * C, device=dev, dtype=torch.float64)
-    red = torch.zeros(65 * 2 * C, device=dev, dtype=torch.float64)
+    red = torch.zeros(513 * 2 * C, device=dev, dtype=torch.float64)
     f = lambda: torch.empty(C, device=dev)
     scale, shift, smean, sinv = f(), f(), f(), f()
     mm = torch.zeros(C, device=dev)
@@ -206,7 +206,7 @@ def test_bn_kernels_emit_planes(C, act, use_res):
     gd = (torch.rand(C, generator=g) + 0.5).to(dev)
     bd = torch.randn(C, generator=g).to(dev)
     stats = torch.zeros(64 * 2 * C, device=dev, dtype=torch.float64)
-    red = torch.zeros(65 * 2 * C, device=dev, dtype=torch.float64)
+    red = torch.zeros(513 * 2 * C, device=dev, dtype=torch.float64)
     f = lambda: torch.empty(C, device=dev)
     scale, shift, smean, sinv = f(), f(), f(), f()
     aux = torch.zeros(72, device=dev, dtype=torch.int32)

@@ -43,7 +43,7 @@ static inline ColGeom col_geom(int C4) {
   return g;
 }
 
-template <int NQ>
+template <int NQ, bool EXCLUSIVE = false>
 __device__ __forceinline__ void block_col_reduce(double (&v)[NQ][4], int cw, int rpp, int row_lane, int col,
                                                  bool active, double* smem /* [NQ*4][256] */,
                                                  double* out /* [NQ][C] */, int C, int c4) {
@@ -60,7 +60,10 @@ __device__ __forceinline__ void block_col_reduce(double (&v)[NQ][4], int cw, int
       for (int e = 0; e < 4; ++e) {
         double s = 0.0;
         for (int r = 0; r < rpp; ++r) s += smem[(q * 4 + e) * 256 + r * cw + col];
-        atomicAdd(&out[(long long)(blockIdx.x & (YOLO_BN_STAT_SLOTS - 1)) * NQ * C + (long long)q * C + c4 * 4 + e], s);
+        if (EXCLUSIVE)   // slot blockIdx.x belongs to this workgroup alone (gridDim.x <= YOLO_BN_RED_SLOTS)
+          out[(long long)blockIdx.x * NQ * C + (long long)q * C + c4 * 4 + e] = s;
+        else
+          atomicAdd(&out[(long long)(blockIdx.x & (YOLO_BN_STAT_SLOTS - 1)) * NQ * C + (long long)q * C + c4 * 4 + e], s);
       }
   }
 }
@@ -105,14 +108,14 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
                                    float momentum, int unbiased, float* __restrict__ mmean, float* __restrict__ mvar,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
                                    float* __restrict__ sinv, unsigned* __restrict__ bound) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  // one wave per channel: lane r reads replica slot r, shuffle-reduce (128 dependent loads per thread before)
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   float bnd = 0.f;
   if (c < C) {
-  double s1 = 0.0, s2 = 0.0;
-  for (int r = 0; r < YOLO_BN_STAT_SLOTS; ++r) {
-    s1 += stats[(long long)r * 2 * C + c];
-    s2 += stats[(long long)r * 2 * C + C + c];
-  }
+  double s1 = wave_reduce_sum(stats[(long long)lane * 2 * C + c]);
+  double s2 = wave_reduce_sum(stats[(long long)lane * 2 * C + C + c]);
+  if (lane == 0) {
   const double mean = s1 / (double)P;
   double var = s2 / (double)P - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -126,6 +129,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
     // |act(scale*y + shift)| <= |gamma| * |y - mean| * inv + |beta| and (y_i - mean)^2 <= sum_j (y_j - mean)^2 = P*var:
     // an upper bound of the layer's output that needs no pass over the data (planes.hpp: any B >= max|x| will do)
     bnd = (float)(fabs((double)gamma[c]) * inv * sqrt((double)P * var) * 1.001 + fabs((double)beta[c]) + 1e-30);
+    if (bnd > __builtin_bit_cast(float, bound[0])) atomicMax(bound, __builtin_bit_cast(unsigned, bnd));
   }
   if (mmean != nullptr) {
     double fed = var;
@@ -134,10 +138,6 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
     mvar[c] = (float)((double)momentum * mvar[c] + (1.0 - (double)momentum) * fed);
   }
   }
-  if (bound != nullptr) {   // one atomic per wave (a thousand atomics on one address cost more than the kernel)
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, o, 64));
-    if ((threadIdx.x & 63) == 0 && bnd > 0.f) atomicMax(bound, __builtin_bit_cast(unsigned, bnd));
   }
 }
 
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         }
     }
   }
-  block_col_reduce<2>(v, cw, rpp, row_lane, col, active, smem, red, C, c4);
+  block_col_reduce<2, true>(v, cw, rpp, row_lane, col, active, smem, red, C, c4);
   if (aux != nullptr) {   // max |dz| of the tensor (bit patterns of non-negative floats order like integers):
     // one atomic per workgroup, spread over 64 replica slots aux[4..67] (bn_bwd_sum_kernel folds them)
     __shared__ float s_max[4];
@@ -432,43 +432,41 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
 }
 
 // red layout: [SLOTS replicas][2][C] followed by the final [2][C] sums
-__global__ void bn_bwd_sum_kernel(int C, double* __restrict__ red, long long P, const float* __restrict__ scale,
-                                  unsigned* __restrict__ aux) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// one wave per channel: lanes stride over the nslots per-workgroup partials, shuffle-reduce, lane 0 finishes
+__global__ __launch_bounds__(256) void bn_bwd_sum_kernel(int C, double* __restrict__ red, int nslots, long long P,
+                                                         const float* __restrict__ scale,
+                                                         unsigned* __restrict__ aux) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
   float t1 = 0.f, t2 = 0.f;
   if (c < C) {
     double s0 = 0.0, s1 = 0.0;
-    for (int r = 0; r < YOLO_BN_STAT_SLOTS; ++r) {
+    for (int r = lane; r < nslots; r += 64) {
       s0 += red[(long long)r * 2 * C + c];
       s1 += red[(long long)r * 2 * C + C + c];
     }
-    red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + c] = s0;
-    red[(long long)YOLO_BN_STAT_SLOTS * 2 * C + C + c] = s1;
-    if (aux != nullptr) {   // per-channel parts of the bound of dx (bn_bwd_apply8_kernel): |x - mean| * invstd <= sqrt(P)
-      const double asc = fabs((double)scale[c]);
-      t1 = (float)asc;
-      t2 = (float)(asc * (fabs(s1 / (double)P) * sqrt((double)P) + fabs(s0 / (double)P)) * 1.001);
+    s0 = wave_reduce_sum(s0);
+    s1 = wave_reduce_sum(s1);
+    if (lane == 0) {
+      red[(long long)YOLO_BN_RED_SLOTS * 2 * C + c] = s0;
+      red[(long long)YOLO_BN_RED_SLOTS * 2 * C + C + c] = s1;
+      if (aux != nullptr) {   // per-channel parts of the bound of dx (bn_bwd_apply8_kernel): |x - mean| invstd <= sqrt(P)
+        const double asc = fabs((double)scale[c]);
+        t1 = (float)asc;
+        t2 = (float)(asc * (fabs(s1 / (double)P) * sqrt((double)P) + fabs(s0 / (double)P)) * 1.001);
+        if (t1 > __builtin_bit_cast(float, aux[1])) atomicMax(&aux[1], __builtin_bit_cast(unsigned, t1));
+        if (t2 > __builtin_bit_cast(float, aux[2])) atomicMax(&aux[2], __builtin_bit_cast(unsigned, t2));
+      }
     }
   }
-  if (aux != nullptr) {
+  if (aux != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {   // fold the 64 replica slots of max|dz|
+    unsigned m = aux[4 + threadIdx.x];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
-      t1 = fmaxf(t1, __shfl_xor(t1, o, 64));
-      t2 = fmaxf(t2, __shfl_xor(t2, o, 64));
+      const unsigned v = __shfl_xor(m, o, 64);
+      m = v > m ? v : m;
     }
-    if ((threadIdx.x & 63) == 0) {
-      if (t1 > 0.f) atomicMax(&aux[1], __builtin_bit_cast(unsigned, t1));
-      if (t2 > 0.f) atomicMax(&aux[2], __builtin_bit_cast(unsigned, t2));
-    }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {   // fold the 64 replica slots of max|dz|
-      unsigned m = aux[4 + threadIdx.x];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned v = __shfl_xor(m, o, 64);
-        m = v > m ? v : m;
-      }
-      if (threadIdx.x == 0) aux[0] = m;
-    }
+    if (threadIdx.x == 0) aux[0] = m;
   }
 }
 
@@ -517,7 +515,8 @@ extern "C" int yolo_bn_finalize_bound(double* stats, long long P, int C, const f
   YOLO_REQUIRE(stats && gamma && beta && scale && shift && save_mean && save_invstd && P > 0 && C > 0,
                "bn_finalize: bad args");
   YOLO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must come in pairs");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), stats, P, C, gamma,
+  static_assert(YOLO_BN_STAT_SLOTS == 64, "bn_finalize_kernel: one lane per replica slot");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), stats, P, C, gamma,
                      beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var, scale, shift, save_mean,
                      save_invstd, bound);
   return check_launch("bn_finalize_kernel");
@@ -580,10 +579,12 @@ extern "C" int yolo_bn_act_bwd_reduce_bound(const float* x, const float* dout, l
                "bn_act_bwd_reduce: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_reduce: C=%d must be a multiple of 4", C);
   const ColGeom g = col_geom(C / 4);
-  dim3 grid(reduce_grid_x(P, g.rpp), (C / 4 + g.cw - 1) / g.cw);
+  int gx = reduce_grid_x(P, g.rpp);
+  if (gx > YOLO_BN_RED_SLOTS) gx = YOLO_BN_RED_SLOTS;   // every workgroup owns one slot of `red`
+  dim3 grid(gx, (C / 4 + g.cw - 1) / g.cw);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, dout, P, C, g.cw, g.rpp, scale,
                      shift, save_mean, save_invstd, act, red, bound_aux);
-  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), C, red, P, scale,
+  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), C, red, gx, P, scale,
                      bound_aux);
   return check_launch("bn_bwd_reduce_kernel");
 }
@@ -608,7 +609,7 @@ extern "C" int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, l
                "bn_act_bwd_apply: planes output needs the bound words of yolo_bn_act_bwd_reduce_bound");
   const long long n4 = P * (C / 4);
   hipStream_t st = as_stream(stream);
-  const double* redsum = red + (long long)YOLO_BN_STAT_SLOTS * 2 * C;
+  const double* redsum = red + (long long)YOLO_BN_RED_SLOTS * 2 * C;
   if (C % 8 == 0) {
     const long long rows = planes ? ((P + 15) / 16 + 1) * 16 : P;
     const RowGeom g = row_geom(rows, C);

@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void planes_amax_kernel(const float* __restric
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) atomicMax(header, __builtin_bit_cast(unsigned, m));
+  // (skip the atomic when the header already holds a larger value: most waves do after the first few)
+  if ((threadIdx.x & 63) == 0 && __builtin_bit_cast(unsigned, m) > *reinterpret_cast<volatile unsigned*>(header))
+    atomicMax(header, __builtin_bit_cast(unsigned, m));
 }
 
 // pass 2: one thread = (row, 8-channel group); adjacent lanes read adjacent 32-byte pieces of a row.
@@ -398,7 +400,8 @@ __global__ __launch_bounds__(256) void planes_amax_batch_kernel(const BatchJob* 
   if ((threadIdx.x & 63) == 0 && m > 0.f) {
     unsigned* header = reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(j.dst) +
                                                    planes_body_bytes(j.a, (int)j.b));
-    atomicMax(header, __builtin_bit_cast(unsigned, m));
+    if (__builtin_bit_cast(unsigned, m) > *reinterpret_cast<volatile unsigned*>(header))
+      atomicMax(header, __builtin_bit_cast(unsigned, m));
   }
 }
 __global__ __launch_bounds__(256) void split_planes_batch_kernel(const BatchJob* __restrict__ jobs, int njobs) {

@@ -354,7 +354,7 @@ class Network:
                     u.bn_f32_off = f32
                     f32 += 4 * u.cout            # scale, shift, save_mean, save_invstd
                     u.bn_f64_off = f64
-                    f64 += (2 * ops.BN_STAT_SLOTS + 1) * 2 * u.cout   # stats[SLOTS][2C], red[SLOTS+1][2C]
+                    f64 += (ops.BN_STAT_SLOTS + ops.BN_RED_SLOTS + 1) * 2 * u.cout   # stats[SLOTS][2C], red[RED_SLOTS+1][2C]
                 u.wT_off = wT
                 wT += u.cout * u.k * u.k * cin
             elif u.kind == "head":
@@ -481,7 +481,7 @@ class Network:
         c = u.cout
         b = self._bn_f32[u.bn_f32_off:u.bn_f32_off + 4 * c]
         ns = ops.BN_STAT_SLOTS * 2 * c
-        nr = (ops.BN_STAT_SLOTS + 1) * 2 * c
+        nr = (ops.BN_RED_SLOTS + 1) * 2 * c
         d = self._bn_f64[u.bn_f64_off:u.bn_f64_off + ns + nr]
         return b[0:c], b[c:2 * c], b[2 * c:3 * c], b[3 * c:4 * c], d[0:ns], d[ns:ns + nr]
 

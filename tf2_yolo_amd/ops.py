@@ -15,6 +15,7 @@ from ._lib import ConvDesc, LossCfg, YoloHipError, check
 BN_EPS = 1e-3       # Keras BatchNormalization default
 BN_MOMENTUM = 0.99
 BN_STAT_SLOTS = 64  # YOLO_BN_STAT_SLOTS in include/yolo_hip.h
+BN_RED_SLOTS = 512  # YOLO_BN_RED_SLOTS
 
 
 class KernelTimer:
@@ -66,8 +67,7 @@ def planes_dgrad_ok(cin, cout):
 
 
 def planes_wgrad_ok(cin, cout, taps, stride=1):
-    # (stride-2 layers gather every second source pixel: the register-staged kernel is faster there)
-    return USE_PLANES and stride == 1 and cin % 16 == 0 and cout % 16 == 0 and cout >= 64 and taps * cin >= 64
+    return USE_PLANES and cin % 16 == 0 and cout % 16 == 0 and cout >= 64 and taps * cin >= 64
 
 
 def _wgrad_planes_variant(cout, cols):
