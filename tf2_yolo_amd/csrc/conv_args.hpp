@@ -72,6 +72,7 @@ int launch_split_planes(const float* x, long long rows, int C, void* planes, hip
 int launch_split_planes_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st);
+int launch_gather_planes16(GatherConvArgs& a, hipStream_t st);   // conv_planes16.hip (16x16x32 MFMA shape)
 bool gather_planes_supported(const GatherConvArgs& a);
 // conv_wgrad_planes.hip
 int launch_wgrad_planes(WgradArgs& a, hipStream_t st);

@@ -66,7 +66,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   constexpr int TM = BM / WGM / 32;
   constexpr int TN = BN / WGN / 32;
   constexpr int RBA = BM / 32, RBB = BN / 32;
-  static_assert(RBA + RBB <= NW, "at least one loader wave per 32-row block");
+  // loader blocks per wave: 1 (one 32-row block of A or of B per wave; spare waves repeat a B block) or
+  // 2 (4-wave 128x128 tile: every wave loads A block `wave` and B block `wave`)
+  constexpr int LPW = (RBA + RBB <= NW) ? 1 : 2;
+  static_assert(LPW == 1 || (RBA == NW && RBB == NW), "loader layout");
+  constexpr int ND = PL_PLANES * LPW;   // DMA instructions per wave per stage
   constexpr int STAGE_BYTES = (RBA + RBB) * PL_PLANES * 1024;
   constexpr int NBUF = 3;
 
@@ -85,73 +89,82 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   const int n0 = tile_n * BN;
   const int HgWg = a.Hg * a.Wg;
 
-  // ---- loader role ----
-  const bool loadA = wave < RBA;
-  // (spare waves load a B block a second time -- identical bytes to the same LDS address -- so that every
-  // wave has the same number of DMAs on its counter)
-  const int rb = loadA ? wave : (wave - RBA) % RBB;
+  // ---- loader role(s) ----
   const int r = lane & 31, hf = lane >> 5;
-  int nimg = 0, ys0 = -(1 << 28), xs0 = 0;
-  unsigned rowbaseB = 0;
-  if (loadA) {
-    const long long m = m0 + rb * 32 + r;
-    if (m < a.M) {
-      nimg = (int)(m / HgWg);
-      const int rem = (int)(m - (long long)nimg * HgWg);
-      const int y = rem / a.Wg;
-      ys0 = y * a.sy;
-      xs0 = (rem - y * a.Wg) * a.sx;
-    }
-  } else {
-    const int co = n0 + rb * 32 + r;
-    const unsigned blk = co < a.Cout ? (unsigned)(co >> 4) : (unsigned)a.zero_blk_wgt;
-    rowbaseB = blk * (unsigned)((a.ldw >> 4) * PL_RECORD) + (co < a.Cout ? (co & 15) * 16 : 0) + hf * 256;
-  }
   const unsigned blkstrideA = (unsigned)((a.Cs >> 4) * PL_RECORD);
-  const void* pbase = loadA ? (const void*)a.src : (const void*)a.wgt;
-  const unsigned pbytes = loadA ? a.src_bytes : a.wgt_bytes;
-  const i32x4 rsrc = planes_rsrc(pbase, pbytes);
-  const unsigned lds_mine = lds_base + ((loadA ? 0 : RBA) + rb) * PL_PLANES * 1024;
-
+  const unsigned blkstrideB = (unsigned)((a.ldw >> 4) * PL_RECORD);
+  const i32x4 rsrcA = planes_rsrc(a.src, a.src_bytes), rsrcB = planes_rsrc(a.wgt, a.wgt_bytes);
   const int cpt = a.Cs >> 4;  // stages per tap
   const int nk = a.ntaps * cpt;
 
+  bool isA[LPW];
+  int nimg[LPW], ys0[LPW], xs0[LPW];
+  unsigned rowbaseB[LPW], lds_mine[LPW], ld_voff[LPW], ld_soff[LPW];
+#pragma unroll
+  for (int i = 0; i < LPW; ++i) {
+    // (LPW == 1: spare waves load a B block a second time -- identical bytes to the same LDS address -- so
+    // that every wave has the same number of DMAs on its counter)
+    isA[i] = (LPW == 2) ? (i == 0) : (wave < RBA);
+    const int rb = (LPW == 2) ? wave : (isA[i] ? wave : (wave - RBA) % RBB);
+    nimg[i] = 0; ys0[i] = -(1 << 28); xs0[i] = 0; rowbaseB[i] = 0;
+    if (isA[i]) {
+      const long long m = m0 + rb * 32 + r;
+      if (m < a.M) {
+        nimg[i] = (int)(m / HgWg);
+        const int rem = (int)(m - (long long)nimg[i] * HgWg);
+        const int y = rem / a.Wg;
+        ys0[i] = y * a.sy;
+        xs0[i] = (rem - y * a.Wg) * a.sx;
+      }
+    } else {
+      const int co = n0 + rb * 32 + r;
+      const unsigned blk = co < a.Cout ? (unsigned)(co >> 4) : (unsigned)a.zero_blk_wgt;
+      rowbaseB[i] = blk * blkstrideB + (co < a.Cout ? (co & 15) * 16 : 0) + hf * 256;
+    }
+    lds_mine[i] = lds_base + ((isA[i] ? 0 : RBA) + rb) * PL_PLANES * 1024;
+    ld_voff[i] = 0; ld_soff[i] = 0;
+  }
+
   // ---- loader state: the next stage to issue (tap, 16-channel block) and its DMA offsets ----
   int ld_tap = 0, ld_kb = 0;
-  unsigned ld_voff = 0, ld_soff = 0;
   auto loader_tap = [&]() {  // per-tap part of the source address (A: the shifted pixel, B: the filter tap)
-    if (ld_tap >= a.ntaps) {  // stages past the end (issued to keep the DMA count per stage uniform): zero block
-      ld_voff = (loadA ? (unsigned)a.zero_blk_src * blkstrideA : (unsigned)a.zero_blk_wgt * (unsigned)((a.ldw >> 4) * PL_RECORD));
-      ld_soff = 0;
-      return;
-    }
-    if (loadA) {
-      const int ys = ys0 + a.taps[ld_tap].oy, xs = xs0 + a.taps[ld_tap].ox;
-      const bool ok = ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
-      const int pix = (nimg * a.Hs + ys) * a.Ws + xs;
-      ld_voff = (ok ? ((unsigned)pix >> 4) : (unsigned)a.zero_blk_src) * blkstrideA + (ok ? (pix & 15) * 16 : 0) + hf * 256;
-      ld_soff = 0;
-    } else {
-      ld_voff = rowbaseB;
-      ld_soff = (unsigned)(a.taps[ld_tap].woff >> 4) * PL_RECORD;
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) {
+      if (ld_tap >= a.ntaps) {  // stages past the end (issued to keep the DMA count per stage uniform): zero block
+        ld_voff[i] = isA[i] ? (unsigned)a.zero_blk_src * blkstrideA : (unsigned)a.zero_blk_wgt * blkstrideB;
+        ld_soff[i] = 0;
+      } else if (isA[i]) {
+        const int ys = ys0[i] + a.taps[ld_tap].oy, xs = xs0[i] + a.taps[ld_tap].ox;
+        const bool ok = ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
+        const int pix = (nimg[i] * a.Hs + ys) * a.Ws + xs;
+        ld_voff[i] = (ok ? ((unsigned)pix >> 4) : (unsigned)a.zero_blk_src) * blkstrideA + (ok ? (pix & 15) * 16 : 0) + hf * 256;
+        ld_soff[i] = 0;
+      } else {
+        ld_voff[i] = rowbaseB[i];
+        ld_soff[i] = (unsigned)(a.taps[ld_tap].woff >> 4) * PL_RECORD;
+      }
     }
   };
   auto loader_next = [&]() {
-    ld_soff += PL_RECORD;
+#pragma unroll
+    for (int i = 0; i < LPW; ++i) ld_soff[i] += PL_RECORD;
     if (++ld_kb == cpt) {
       ld_kb = 0;
       ++ld_tap;
       loader_tap();
     }
   };
-  auto issue_plane = [&](int p, int buf) {
-    const unsigned so = __builtin_amdgcn_readfirstlane(ld_soff + p * 512);
-    const unsigned l = __builtin_amdgcn_readfirstlane(lds_mine + buf * STAGE_BYTES + p * 1024);
-    dma16(rsrc, ld_voff, so, l);
+  // DMA number d of a stage (0 .. ND-1): plane d % 2 of loader block d / 2
+  auto issue_plane = [&](int d, int buf) {
+    const int i = d / PL_PLANES, p = d - PL_PLANES * i;
+    const unsigned so = __builtin_amdgcn_readfirstlane(ld_soff[i] + p * 512);
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_mine[i] + buf * STAGE_BYTES + p * 1024);
+    if (isA[i]) dma16(rsrcA, ld_voff[i], so, l);
+    else dma16(rsrcB, ld_voff[i], so, l);
   };
   auto issue_stage = [&](int buf) {
-    issue_plane(0, buf);
-    issue_plane(1, buf);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) issue_plane(d, buf);
     loader_next();
   };
 
@@ -194,11 +207,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
           const int idx = (q * TM + i) * TN + j;
-          if (idx == NM / 3 - 1 || idx == (2 * NM) / 3 - 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue_plane(idx == NM / 3 - 1 ? 0 : 1, wbuf);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+            if (idx == ((d + 1) * NM) / (ND + 1) - 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_plane(d, wbuf);
+              __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     loader_next();
@@ -213,14 +228,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   issue_stage(0);
   issue_stage(1);
   issue_stage(2);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (LPW == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, S0{});
 
   // iteration kt: MFMAs of stage kt (registers) | fragment reads of stage kt+1 | DMA issue of stage kt+3
   // (into stage kt's buffer: everybody finished reading it before this iteration's barrier)
   auto step = [&](int rbuf, int wbuf, auto CUR, auto NXT) {
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // my pieces of stage kt+1 have landed
+    // my pieces of stage kt+1 have landed (those of kt+2 may still fly)
+    if (LPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage kt's buffer are done
     __builtin_amdgcn_s_barrier();
     read_frags(rbuf, NXT);
@@ -355,7 +373,12 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   a.wgt_bytes = (unsigned)bytesB;
   a.zero_blk_src = (int)((rowsA + 15) / 16);
   a.zero_blk_wgt = (a.Cout + 15) / 16;
+  // YOLO_PLANES_MFMA=16 selects the 16x16x32-MFMA build of the kernel (conv_planes16.hip): measured equal
+  static const int shape = [] { const char* e = getenv("YOLO_PLANES_MFMA"); return e ? atoi(e) : 32; }();
+  if (shape == 16) return launch_gather_planes16(a, st);
   if (a.Cout <= 64) return launch_planes<128, 64, 4, 2>(a, st);
+  static const int waves = [] { const char* e = getenv("YOLO_PLANES_WAVES"); return e ? atoi(e) : 4; }();
+  if (waves == 4) return launch_planes<128, 128, 2, 2>(a, st);
   return launch_planes<128, 128, 4, 2>(a, st);
 }
 

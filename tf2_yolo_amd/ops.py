@@ -75,8 +75,14 @@ def _wgrad_planes_variant(cout, cols):
                                              "2,2" if (cout <= 64 and cols <= 64) else "2,4" if cout <= 64 else "4,2")
 
 
+_PLANES_WAVES = 8 if _os.environ.get("YOLO_PLANES_WAVES") == "8" else 4
+
+
 def _planes_variant(cout):
-    return "gather_conv_planes_kernel<128,%d,4,2>" % (64 if cout <= 64 else 128)
+    """mirrors launch_gather_planes() in csrc/conv_planes.hip"""
+    if cout <= 64:
+        return "gather_conv_planes_kernel<128,64,4,2>"
+    return "gather_conv_planes_kernel<128,128,%s>" % ("4,2" if _PLANES_WAVES == 8 else "2,2")
 
 
 def _gather_variant(cout, flat, m=None):
