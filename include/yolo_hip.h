@@ -121,7 +121,7 @@ int yolo_filter_transpose_batch(const void* jobs, int njobs, long long total_blo
 /* yolo_conv2d_fwd / yolo_conv2d_dgrad on pre-split operands (same conv, same fused epilogue, same
  * fp32-accurate result): x_planes = planes of x viewed as [N*H*W][Cin], w_planes = planes of w viewed as
  * [Cout][kh*kw*Cin]; dy_planes = planes of dy [N*Ho*Wo][Cout], wT_planes = planes of wT [Cin][kh*kw*Cout].
- * Requires Cin % 16 == 0 and Cout > 32 (dgrad: Cout % 16 == 0 and Cin > 32). */
+ * Requires Cin % 16 == 0 and Cout >= 32 (dgrad: Cout % 16 == 0 and Cin >= 32). */
 int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,
                            const float* bias, float* y, double* stats, void* stream);
 int yolo_conv2d_dgrad_planes(const yolo_conv_desc* d, const void* dy_planes, const void* wT_planes,

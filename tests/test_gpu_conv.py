@@ -122,7 +122,7 @@ def test_conv_fused_bn_statistics(case):
 
 # ---- pre-split ("planes") operands + LDS-DMA kernels (include/yolo_hip.h: yolo_split_planes,
 # ---- yolo_conv2d_fwd_planes, yolo_conv2d_dgrad_planes) ------------------------------------------------
-# (N, H, W, Cin, Cout, k, stride, padding, bias): Cin % 16 == 0 and Cout > 32
+# (N, H, W, Cin, Cout, k, stride, padding, bias): Cin % 16 == 0 and Cout >= 32
 PLANES_CASES = [
     (2, 16, 16, 32, 64, 3, 1, "same", False),        # 128x64 tile, spare loader waves
     (2, 17, 13, 32, 64, 3, 2, "darknet_s2", False),   # stride 2, odd sizes
@@ -133,6 +133,8 @@ PLANES_CASES = [
     (1, 2, 2, 1024, 512, 3, 1, "same", False),       # 4 pixels: every tap but the centre hits padding
     (2, 14, 14, 64, 64, 3, 2, "same", True),         # 'same' stride 2 (asymmetric pad)
     (1, 13, 13, 64, 125, 1, 1, "same", True),
+    (2, 16, 16, 64, 32, 1, 1, "same", False),        # Cout = 32: 128x32 tile (B block loaded by all four waves)
+    (2, 15, 17, 32, 64, 3, 2, "darknet_s2", False),   # dgrad with 32 output columns (Cin = 32), 4 parity launches
 ]
 
 
@@ -186,7 +188,7 @@ def test_conv_fwd_planes(case):
     assert _relerr(got[1], (r2 * r2).sum(0)) < 1e-5
 
 
-@pytest.mark.parametrize("case", [c for c in PLANES_CASES if c[4] % 16 == 0 and c[3] > 32])
+@pytest.mark.parametrize("case", [c for c in PLANES_CASES if c[4] % 16 == 0 and c[3] >= 32])
 def test_conv_dgrad_planes(case):
     from tf2_yolo_amd import ops
     n, h, w, cin, cout, k, s, pad, bias = case
@@ -214,9 +216,9 @@ def test_conv_planes_rejects_unsupported_shapes():
     from tf2_yolo_amd._lib import YoloHipError
     with pytest.raises(YoloHipError):
         ops.planes_bytes(10, 24)          # C % 16 != 0
-    d = ops.conv_desc((1, 8, 8, 32), 32, 3, 3, 1, "same")   # Cout = 32: not covered by the planes kernels
+    d = ops.conv_desc((1, 8, 8, 32), 16, 3, 3, 1, "same")   # Cout = 16: not covered by the planes kernels
     xp = ops.split_planes(torch.zeros(64, 32, device="cuda"), 64, 32)
-    wp = ops.split_planes(torch.zeros(32, 288, device="cuda"), 32, 288)
+    wp = ops.split_planes(torch.zeros(16, 288, device="cuda"), 16, 288)
     with pytest.raises(YoloHipError):
         ops.conv2d_fwd_planes(d, xp, wp)
 

@@ -759,7 +759,7 @@ extern "C" int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_pla
   a.dst = y;
   fill_fwd_args(d, a);
   a.stats = stats;
-  YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_planes: needs Cin %% 16 == 0 and Cout > 32");
+  YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_planes: needs Cin %% 16 == 0 and Cout >= 32");
   return launch_gather_planes(a, as_stream(stream));
 }
 
@@ -833,7 +833,7 @@ static int dgrad_impl(const yolo_conv_desc* d, const float* dy, const float* wT,
         }
       }
       if (planes) {
-        YOLO_REQUIRE(gather_planes_supported(a), "conv_dgrad_planes: needs Cout %% 16 == 0 and Cin > 32");
+        YOLO_REQUIRE(gather_planes_supported(a), "conv_dgrad_planes: needs Cout %% 16 == 0 and Cin >= 32");
         if (int rc = launch_gather_planes(a, as_stream(stream))) return rc;
       } else if (int rc = dispatch_gather(a, flat, as_stream(stream))) {
         return rc;

@@ -66,10 +66,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   constexpr int TM = BM / WGM / 32;
   constexpr int TN = BN / WGN / 32;
   constexpr int RBA = BM / 32, RBB = BN / 32;
-  // loader blocks per wave: 1 (one 32-row block of A or of B per wave; spare waves repeat a B block) or
-  // 2 (4-wave 128x128 tile: every wave loads A block `wave` and B block `wave`)
-  constexpr int LPW = (RBA + RBB <= NW) ? 1 : 2;
-  static_assert(LPW == 1 || (RBA == NW && RBB == NW), "loader layout");
+  // loader slots per wave: 1 (one 32-row block of A or of B per wave) or 2 (4-wave tiles); slots beyond the
+  // RBA + RBB blocks repeat a B block -- identical bytes to the same LDS address -- so that every wave has
+  // the same number of DMAs on its counter
+  constexpr int LPW = (RBA + RBB + NW - 1) / NW;
+  static_assert(LPW <= 2 && RBA <= NW, "loader layout: slot s = wave + i*NW loads A block s, or B block (s - RBA) % RBB");
   constexpr int ND = PL_PLANES * LPW;   // DMA instructions per wave per stage
   constexpr int STAGE_BYTES = (RBA + RBB) * PL_PLANES * 1024;
   constexpr int NBUF = 3;
@@ -102,10 +103,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   unsigned rowbaseB[LPW], lds_mine[LPW], ld_voff[LPW], ld_soff[LPW];
 #pragma unroll
   for (int i = 0; i < LPW; ++i) {
-    // (LPW == 1: spare waves load a B block a second time -- identical bytes to the same LDS address -- so
-    // that every wave has the same number of DMAs on its counter)
-    isA[i] = (LPW == 2) ? (i == 0) : (wave < RBA);
-    const int rb = (LPW == 2) ? wave : (isA[i] ? wave : (wave - RBA) % RBB);
+    const int slot = wave + i * NW;
+    isA[i] = slot < RBA;
+    const int rb = isA[i] ? slot : (slot - RBA) % RBB;
     nimg[i] = 0; ys0[i] = -(1 << 28); xs0[i] = 0; rowbaseB[i] = 0;
     if (isA[i]) {
       const long long m = m0 + rb * 32 + r;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
           const int idx = (q * TM + i) * TN + j;
 #pragma unroll
           for (int d = 0; d < ND; ++d)
-            if (idx == ((d + 1) * NM) / (ND + 1) - 1) {
+            if (idx == (((d + 1) * NM) / (ND + 1) > 0 ? ((d + 1) * NM) / (ND + 1) - 1 : 0)) {
               __builtin_amdgcn_sched_barrier(0);
               issue_plane(d, wbuf);
               __builtin_amdgcn_sched_barrier(0);
@@ -360,7 +360,7 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
 
 long long planes_bytes(long long rows, int C) { return planes_body_bytes(rows, C) + PL_HEADER; }
 
-bool gather_planes_supported(const GatherConvArgs& a) { return (a.Cs % 16) == 0 && a.Cout > 32; }
+bool gather_planes_supported(const GatherConvArgs& a) { return (a.Cs % 16) == 0 && a.Cout >= 32; }
 
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   const long long rowsA = (long long)a.N * a.Hs * a.Ws;
@@ -375,7 +375,8 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   a.zero_blk_wgt = (a.Cout + 15) / 16;
   // YOLO_PLANES_MFMA=16 selects the 16x16x32-MFMA build of the kernel (conv_planes16.hip): measured equal
   static const int shape = [] { const char* e = getenv("YOLO_PLANES_MFMA"); return e ? atoi(e) : 32; }();
-  if (shape == 16) return launch_gather_planes16(a, st);
+  if (shape == 16 && a.Cout > 32) return launch_gather_planes16(a, st);
+  if (a.Cout <= 32) return launch_planes<128, 32, 4, 1>(a, st);
   if (a.Cout <= 64) return launch_planes<128, 64, 4, 2>(a, st);
   static const int waves = [] { const char* e = getenv("YOLO_PLANES_WAVES"); return e ? atoi(e) : 4; }();
   if (waves == 4) return launch_planes<128, 128, 2, 2>(a, st);

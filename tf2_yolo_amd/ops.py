@@ -59,11 +59,11 @@ USE_PLANES = CONV_MODE == "split" and _os.environ.get("YOLO_CONV_PLANES", "1") !
 
 
 def planes_fwd_ok(cin, cout):
-    return USE_PLANES and cin % 16 == 0 and cout > 32
+    return USE_PLANES and cin % 16 == 0 and cout >= 32
 
 
 def planes_dgrad_ok(cin, cout):
-    return USE_PLANES and cout % 16 == 0 and cin > 32
+    return USE_PLANES and cout % 16 == 0 and cin >= 32
 
 
 def planes_wgrad_ok(cin, cout, taps, stride=1):
@@ -80,6 +80,8 @@ _PLANES_WAVES = 8 if _os.environ.get("YOLO_PLANES_WAVES") == "8" else 4
 
 def _planes_variant(cout):
     """mirrors launch_gather_planes() in csrc/conv_planes.hip"""
+    if cout <= 32:
+        return "gather_conv_planes_kernel<128,32,4,1>"
     if cout <= 64:
         return "gather_conv_planes_kernel<128,64,4,2>"
     return "gather_conv_planes_kernel<128,128,%s>" % ("4,2" if _PLANES_WAVES == 8 else "2,2")
