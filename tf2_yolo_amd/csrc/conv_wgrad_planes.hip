@@ -28,7 +28,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   constexpr int TM = BM / WGM / 32;
   constexpr int TN = BN / WGN / 32;
   constexpr int RBA = BM / 32, RBB = BN / 32;
-  static_assert(RBA + RBB <= NW, "at least one loader wave per 32-channel block");
   constexpr int STAGE_BYTES = (RBA + RBB) * PL_PLANES * 1024;
   constexpr int NBUF = 3;
 
@@ -50,33 +49,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   const int nk = (int)((p_end - p_begin + 15) / 16);
   const int Ktot = a.ntaps * a.Cs;
 
-  // ---- loader role: lane -> (pixel of the stage, sub-block of the 32-channel block) ----
-  const bool loadA = wave < RBA;
-  const int rb = loadA ? wave : (wave - RBA) % RBB;
+  // ---- loader role(s): lane -> (pixel of the stage, sub-block of the 32-channel block). An 8-wave
+  // workgroup gives every wave ONE 32-channel block of dy (waves < RBA) or of x; a 4-wave 128x128 workgroup
+  // gives every wave one of each (dy block `wave` and x block `wave`). ----
+  constexpr bool BOTH = (RBA + RBB > NW);
+  static_assert(!BOTH || (RBA == NW && RBB == NW), "loader layout");
+  constexpr int ND = PL_PLANES * (BOTH ? 2 : 1);   // DMA instructions per wave per stage
+  const bool hasA = BOTH || wave < RBA, hasB = BOTH || wave >= RBA;
+  const int rbA = wave, rbB = BOTH ? wave : (wave - RBA) % RBB;
   const int lpix = 4 * (lane >> 4) + (lane & 3);
   const int lsb = (lane >> 2) & 3;
   const unsigned strideA = (unsigned)((a.Cout >> 4) * PL_RECORD);   // bytes per 16-pixel block of dy planes
   const unsigned strideB = (unsigned)((a.Cs >> 4) * PL_RECORD);
   const unsigned zeroA = (unsigned)a.zero_blk_dy * strideA, zeroB = (unsigned)a.zero_blk_src * strideB;
-  const i32x4 rsrc = planes_rsrc(loadA ? (const void*)a.dy : (const void*)a.src, loadA ? a.dy_bytes : a.src_bytes);
-  const unsigned lds_mine = lds_base + ((loadA ? 0 : RBA) + rb) * PL_PLANES * 1024;
+  const i32x4 rsrcA = planes_rsrc(a.dy, a.dy_bytes), rsrcB = planes_rsrc(a.src, a.src_bytes);
+  const unsigned ldsA = lds_base + rbA * PL_PLANES * 1024, ldsB = lds_base + (RBA + rbB) * PL_PLANES * 1024;
 
   // A (dy): unit (pixel block, 16-channel block co16, half, pixel); advances one pixel block per stage
-  bool lane_ok;
-  unsigned ld_voff;
+  bool okA = false, okB = false;
+  unsigned voffA = zeroA, voffB = zeroB;
   // B (x): column block -> (tap, 16-channel block), pixel decoded incrementally
   int b_oy = 0, b_ox = 0, b_chan = 0;
   int pn = 0, py = 0, px = 0;
   long long pcur = p_begin + lpix;
-  if (loadA) {
-    const int co16 = ((co0 + rb * 32) >> 4) + (lsb >> 1);
-    lane_ok = co16 * 16 < a.Cout;
-    ld_voff = lane_ok ? (unsigned)(p_begin >> 4) * strideA + (unsigned)co16 * PL_RECORD + (lsb & 1) * 256 + lpix * 16 : zeroA;
-  } else {
-    const int j16 = ((j0 + rb * 32) >> 4) + (lsb >> 1);
-    lane_ok = j16 * 16 < Ktot;
+  if (hasA) {
+    const int co16 = ((co0 + rbA * 32) >> 4) + (lsb >> 1);
+    okA = co16 * 16 < a.Cout;
+    voffA = okA ? (unsigned)(p_begin >> 4) * strideA + (unsigned)co16 * PL_RECORD + (lsb & 1) * 256 + lpix * 16 : zeroA;
+  }
+  if (hasB) {
+    const int j16 = ((j0 + rbB * 32) >> 4) + (lsb >> 1);
+    okB = j16 * 16 < Ktot;
     const int cpt = a.Cs >> 4;
-    const int t = lane_ok ? j16 / cpt : 0;
+    const int t = okB ? j16 / cpt : 0;
     const int r = t / a.kw;
     b_oy = r - a.pad_t;
     b_ox = (t - r * a.kw) - a.pad_l;
@@ -87,23 +92,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
     const int rem = (int)(pp - (long long)pn * HgWg);
     py = rem / a.Wg;
     px = rem - py * a.Wg;
-    ld_voff = zeroB;
   }
   int ld_stage = 0;  // stage the loader will issue next
 
-  auto loader_addr = [&]() {   // B only: source unit of this lane's pixel for the stage about to be issued
+  auto loader_addr = [&]() {   // x: source unit of this lane's pixel for the stage about to be issued
     const int ys = py * a.sy + b_oy, xs = px * a.sx + b_ox;
-    const bool ok = lane_ok && (ld_stage < nk) && (pcur < p_end) && ((unsigned)ys < (unsigned)a.Hs) &&
+    const bool ok = okB && (ld_stage < nk) && (pcur < p_end) && ((unsigned)ys < (unsigned)a.Hs) &&
                     ((unsigned)xs < (unsigned)a.Ws);
     const int s = (pn * a.Hs + ys) * a.Ws + xs;
-    ld_voff = ok ? ((unsigned)s >> 4) * strideB + (s & 15) * 16 + b_chan : zeroB;
+    voffB = ok ? ((unsigned)s >> 4) * strideB + (s & 15) * 16 + b_chan : zeroB;
   };
   auto loader_next = [&]() {
     ++ld_stage;
-    if (loadA) {
-      if (ld_stage >= nk) ld_voff = zeroA;
-      else if (lane_ok) ld_voff += strideA;
-    } else {
+    if (hasA) {
+      if (ld_stage >= nk) voffA = zeroA;
+      else if (okA) voffA += strideA;
+    }
+    if (hasB) {
       pcur += 16;
       px += 16;
       while (px >= a.Wg) {
@@ -117,13 +122,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
       loader_addr();
     }
   };
-  auto issue_plane = [&](int p, int buf) {
-    const unsigned l = __builtin_amdgcn_readfirstlane(lds_mine + buf * STAGE_BYTES + p * 1024);
-    dma16(rsrc, ld_voff, (unsigned)(p * 512), l);
+  // DMA d of a stage: plane d & 1 of the wave's dy block (d < 2 when it has one) or x block
+  auto issue_plane = [&](int d, int buf) {
+    const int p = d & 1;
+    const bool useA = BOTH ? (d < 2) : hasA;
+    const unsigned l = __builtin_amdgcn_readfirstlane((useA ? ldsA : ldsB) + buf * STAGE_BYTES + p * 1024);
+    if (useA) dma16(rsrcA, voffA, (unsigned)(p * 512), l);
+    else dma16(rsrcB, voffB, (unsigned)(p * 512), l);
   };
   auto issue_stage = [&](int buf) {
-    issue_plane(0, buf);
-    issue_plane(1, buf);
+#pragma unroll
+    for (int d = 0; d < ND; ++d) issue_plane(d, buf);
     loader_next();
   };
 
@@ -174,11 +183,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
         for (int j = 0; j < TN; ++j) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
           const int idx = (q * TM + i) * TN + j;
-          if (idx == NM / 3 - 1 || idx == (2 * NM) / 3 - 1) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue_plane(idx == NM / 3 - 1 ? 0 : 1, wbuf);
-            __builtin_amdgcn_sched_barrier(0);
-          }
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+            if (idx == (((d + 1) * NM) / (ND + 1) > 0 ? ((d + 1) * NM) / (ND + 1) - 1 : 0)) {
+              __builtin_amdgcn_sched_barrier(0);
+              issue_plane(d, wbuf);
+              __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
     loader_next();
@@ -187,16 +198,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
 
-  if (!loadA) loader_addr();
+  if (hasB) loader_addr();
   issue_stage(0);
   issue_stage(1);
   issue_stage(2);
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (!BOTH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, S0{});
 
   auto step = [&](int rbuf, int wbuf, auto CUR, auto NXT) {
-    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");   // my pieces of the next stage have landed
+    // my pieces of the next stage have landed (those of the one after may still fly)
+    if (!BOTH) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of the current stage's buffer are done
     __builtin_amdgcn_s_barrier();
     read_frags(rbuf, NXT);
@@ -293,6 +307,8 @@ int launch_wgrad_planes(WgradArgs& a, hipStream_t st) {
   if (a.Cout <= 64 && cols <= 64) return launch_wp<64, 64, 2, 2>(a, st);
   if (a.Cout <= 64) return launch_wp<64, 128, 2, 4>(a, st);
   if (cols <= 64) return launch_wp<128, 64, 4, 2>(a, st);
+  static const int waves = [] { const char* e = getenv("YOLO_WGRAD_WAVES"); return e ? atoi(e) : 8; }();
+  if (waves == 4) return launch_wp<128, 128, 2, 2>(a, st);
   return launch_wp<128, 128, 4, 2>(a, st);
 }
 

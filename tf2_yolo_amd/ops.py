@@ -71,8 +71,10 @@ def planes_wgrad_ok(cin, cout, taps, stride=1):
 
 
 def _wgrad_planes_variant(cout, cols):
+    big = "2,2" if _os.environ.get("YOLO_WGRAD_WAVES") == "4" else "4,2"
     return "wgrad_planes_kernel<%d,%d,%s>" % (64 if cout <= 64 else 128, 64 if cols <= 64 else 128,
-                                             "2,2" if (cout <= 64 and cols <= 64) else "2,4" if cout <= 64 else "4,2")
+                                             "2,2" if (cout <= 64 and cols <= 64) else "2,4" if cout <= 64
+                                             else "4,2" if cols <= 64 else big)
 
 
 _PLANES_WAVES = 8 if _os.environ.get("YOLO_PLANES_WAVES") == "8" else 4
