@@ -99,3 +99,56 @@ def test_train_steps_reduce_loss(ver):
         hist.append(float(l[0] if isinstance(l, list) else l))
     first, last = hist[0], min(hist[-3:])
     assert np.isfinite(last) and last < first
+
+
+def test_v4_trainable_anchors():
+    """yolov4 `anchors_trainable` (yolov4/__init__.py:147-159): d(loss)/d(anchor) from the head backward kernel
+    agrees with central differences of the loss, and an optimizer step moves the anchors (and only when asked)"""
+    import torch
+    import yolov4
+    from tf2_yolo_amd import labels
+    from tf2_yolo_amd.optimizers import SGD
+    y = yolov4.Yolo((64, 64, 3), ["a", "b"])
+    y.create_model(anchors=A9, pretrained_body=None)
+    rng = np.random.default_rng(5)
+    x_h, ys_h = labels.synthetic_batch(rng, 4, (64, 64), 2)
+    x = torch.from_numpy(x_h).cuda()
+    ys = [torch.from_numpy(v).cuda() for v in ys_h]
+    m = y.model
+    m.compile(optimizer=SGD(learning_rate=1e-3), loss=y.loss())
+    net = m.net
+    a0 = np.array(y.anchors)
+    m.train_step_device(x, ys)
+    assert np.allclose(np.array(y.anchors), a0)           # not trainable: untouched
+    assert y.anchors_trainable is False
+    y.anchors_trainable = True
+
+    def total_loss():
+        outs = net.forward(x, training=True)
+        bufs = [torch.zeros(8, device="cuda", dtype=torch.float64) for _ in outs]
+        dp = [torch.empty_like(o) for o in outs]
+        for i, (o, yt) in enumerate(zip(outs, ys)):
+            m.loss[i].fwd_bwd(yt, o, grad_scale=1.0, dpred=dp[i], loss_out=bufs[i])
+        return sum(float(b[0].item()) for b in bufs), dp
+
+    net.anchor_grads.zero_()
+    _, dp = total_loss()
+    net.backward(dp)
+    g = net.anchor_grads.double().cpu().numpy().copy()
+    net.grads.zero_(); net.anchor_grads.zero_()
+    assert np.isfinite(g).all() and np.abs(g).max() > 0
+    base = net.anchors_flat.clone()
+    k = int(np.argmax(np.abs(g)))
+    eps = 1e-3 * float(base[k])
+    net.anchors_flat[k] = base[k] + eps
+    lp, _ = total_loss()
+    net.anchors_flat[k] = base[k] - eps
+    lm, _ = total_loss()
+    net.anchors_flat.copy_(base)
+    fd = (lp - lm) / (2 * eps)
+    assert abs(fd - g[k]) <= 2e-2 * max(abs(g[k]), abs(fd)), (fd, g[k])
+    # one SGD step moves every anchor against its gradient
+    m.train_step_device(x, ys)
+    moved = net.anchors_flat.double().cpu().numpy() - base.double().cpu().numpy()
+    assert np.abs(moved).max() > 0 and (np.sign(moved[np.abs(g) > 1e-6]) == -np.sign(g[np.abs(g) > 1e-6])).all()
+    assert not np.allclose(np.array(y.anchors), a0)

@@ -295,11 +295,22 @@ class Network:
         self._wgrad_pending = False
         self._bn_f32 = torch.zeros(max(self._bn_f32_total, 1), device=self.device, dtype=torch.float32)
         self._bn_f64 = torch.zeros(max(self._bn_f64_total, 1), device=self.device, dtype=torch.float64)
-        self._anchors_dev = {}
-        for u in self.units:
-            if u.kind == "head" and u.anchors is not None:
-                self._anchors_dev[u.name] = torch.tensor(np.array(u.anchors, dtype=np.float32).reshape(-1),
-                                                         device=self.device)
+        # head anchors (v2-v4): views into ONE flat buffer with a gradient twin, so that trainable anchors
+        # (yolov4/__init__.py:147-159) are one more small optimizer tensor
+        self._anchors_dev, self._anchor_grad_views = {}, {}
+        heads = [u for u in self.units if u.kind == "head" and u.anchors is not None]
+        n_anch = sum(2 * len(u.anchors) for u in heads)
+        self.anchors_flat = torch.zeros(max(n_anch, 1), device=self.device, dtype=torch.float32)
+        self.anchor_grads = torch.zeros_like(self.anchors_flat)
+        self.anchors_trainable = False
+        off = 0
+        for u in heads:
+            n = 2 * len(u.anchors)
+            self.anchors_flat[off:off + n] = torch.tensor(np.array(u.anchors, dtype=np.float32).reshape(-1))
+            self._anchors_dev[u.name] = self.anchors_flat[off:off + n]
+            self._anchor_grad_views[u.name] = self.anchor_grads[off:off + n]
+            off += n
+        self.has_anchors = n_anch > 0
         self.batch = None
         self.act = {}
         self.training = False
@@ -647,7 +658,8 @@ class Network:
                 self._dgrad(grads, u, dy, u.cout * u.k * u.k * u.src.c, dyp)
             elif u.kind == "head":
                 xin = self.act[u.src.tid]
-                dt = ops.head_act_bwd(u.yact, dout, u.A, u.C, u.version, self._anchors_dev.get(u.name))
+                dt = ops.head_act_bwd(u.yact, dout, u.A, u.C, u.version, self._anchors_dev.get(u.name),
+                                      danchors=self._anchor_grad_views.get(u.name) if self.anchors_trainable else None)
                 dtp = self._dyp(u, dt)
                 with self._beside_backward(dt):
                     if u.planes_wgrad:

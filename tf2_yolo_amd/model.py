@@ -196,10 +196,13 @@ class Model:
                 self.get_layer(n).set_weights(w)
 
     def set_anchors_trainable(self, trainable):
-        """yolov4/__init__.py:150-159. The head-activation backward kernel produces d(anchor)
-        (yolo_head_act_bwd `danchors`); training them is not wired into the optimizer yet."""
-        if trainable:
-            raise YoloHipError("trainable anchors are not supported yet (anchors stay constants)")
+        """yolov4/__init__.py:150-159: the Anchor layers' weights join the optimizer. d(loss)/d(anchor) comes from
+        the head-activation backward kernel (yolo_head_act_bwd `danchors`); the loss closures keep the anchors they
+        were created with, as in the reference."""
+        if trainable and not self.net.has_anchors:
+            raise YoloHipError("this model has no anchors")
+        self.net.anchors_trainable = bool(trainable)
+        self.net.anchor_grads.zero_()
 
     def save_weights(self, path):
         """.npz keyed '<keras layer name>/<index>' (h5py is unavailable: SURVEY.md section 5)."""
@@ -292,6 +295,9 @@ class Model:
         if with_metrics:
             mvals = [[m(yt, o) for m in ms] for ms, o, yt in zip(self.metrics, outs, y_list)]
         self.net.backward(self._dpred)
+        if self._reducer is not None and self.net.anchors_trainable and self._reducer.world > 1:
+            import torch.distributed as dist   # a few dozen floats: one plain all-reduce
+            dist.all_reduce(self.net.anchor_grads, group=self._reducer.pg)
         scale = self._reducer.finish() if self._reducer is not None else 1.0
         self.optimizer.step(grad_scale=scale)
         return self._loss_bufs, mvals

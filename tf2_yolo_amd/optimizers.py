@@ -26,11 +26,16 @@ class Adam(Optimizer):
         self.net = net
         self.m = torch.zeros_like(net.params.data)
         self.v = torch.zeros_like(net.params.data)
+        self.am = torch.zeros_like(net.anchors_flat)   # trainable anchors (v4): one more small tensor
+        self.av = torch.zeros_like(net.anchors_flat)
 
     def step(self, grad_scale=1.0):
         self.iterations += 1
         ops.adam_step(self.net.params.data, self.net.grads, self.m, self.v, self.learning_rate, self.iterations,
                       self.beta_1, self.beta_2, self.epsilon, grad_scale=grad_scale, zero_grad=True)
+        if self.net.anchors_trainable and self.net.has_anchors:
+            ops.adam_step(self.net.anchors_flat, self.net.anchor_grads, self.am, self.av, self.learning_rate,
+                          self.iterations, self.beta_1, self.beta_2, self.epsilon, grad_scale=grad_scale, zero_grad=True)
         self.net.mark_params_changed()
 
 
@@ -42,4 +47,7 @@ class SGD(Optimizer):
     def step(self, grad_scale=1.0):
         self.iterations += 1
         ops.sgd_step(self.net.params.data, self.net.grads, self.learning_rate, grad_scale=grad_scale, zero_grad=True)
+        if self.net.anchors_trainable and self.net.has_anchors:
+            ops.sgd_step(self.net.anchors_flat, self.net.anchor_grads, self.learning_rate, grad_scale=grad_scale,
+                         zero_grad=True)
         self.net.mark_params_changed()
