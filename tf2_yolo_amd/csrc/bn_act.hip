@@ -432,41 +432,66 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
 }
 
 // red layout: [SLOTS replicas][2][C] followed by the final [2][C] sums
-// one wave per channel: lanes stride over the nslots per-workgroup partials, shuffle-reduce, lane 0 finishes
+// workgroup = 16 channels x 16 slot groups: a thread sums every 16th per-workgroup partial of its channel (4
+// independent accumulators keep the loads in flight), LDS folds the 16 groups
 __global__ __launch_bounds__(256) void bn_bwd_sum_kernel(int C, double* __restrict__ red, int nslots, long long P,
                                                          const float* __restrict__ scale,
                                                          unsigned* __restrict__ aux) {
-  const int lane = threadIdx.x & 63;
-  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
-  float t1 = 0.f, t2 = 0.f;
+  __shared__ double s_part[2][16][16];
+  const int ch = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + ch;
+  double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
   if (c < C) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int r = lane; r < nslots; r += 64) {
-      s0 += red[(long long)r * 2 * C + c];
-      s1 += red[(long long)r * 2 * C + C + c];
+    int r = grp;
+    for (; r + 16 < nslots; r += 32) {
+      a0 += red[(long long)r * 2 * C + c];
+      a1 += red[(long long)r * 2 * C + C + c];
+      b0 += red[(long long)(r + 16) * 2 * C + c];
+      b1 += red[(long long)(r + 16) * 2 * C + C + c];
     }
-    s0 = wave_reduce_sum(s0);
-    s1 = wave_reduce_sum(s1);
-    if (lane == 0) {
-      red[(long long)YOLO_BN_RED_SLOTS * 2 * C + c] = s0;
-      red[(long long)YOLO_BN_RED_SLOTS * 2 * C + C + c] = s1;
-      if (aux != nullptr) {   // per-channel parts of the bound of dx (bn_bwd_apply8_kernel): |x - mean| invstd <= sqrt(P)
-        const double asc = fabs((double)scale[c]);
-        t1 = (float)asc;
-        t2 = (float)(asc * (fabs(s1 / (double)P) * sqrt((double)P) + fabs(s0 / (double)P)) * 1.001);
-        if (t1 > __builtin_bit_cast(float, aux[1])) atomicMax(&aux[1], __builtin_bit_cast(unsigned, t1));
-        if (t2 > __builtin_bit_cast(float, aux[2])) atomicMax(&aux[2], __builtin_bit_cast(unsigned, t2));
-      }
+    if (r < nslots) {
+      a0 += red[(long long)r * 2 * C + c];
+      a1 += red[(long long)r * 2 * C + C + c];
     }
   }
-  if (aux != nullptr && blockIdx.x == 0 && threadIdx.x < 64) {   // fold the 64 replica slots of max|dz|
-    unsigned m = aux[4 + threadIdx.x];
+  s_part[0][grp][ch] = a0 + b0;
+  s_part[1][grp][ch] = a1 + b1;
+  __syncthreads();
+  float t1 = 0.f, t2 = 0.f;
+  if (grp == 0 && c < C) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      s0 += s_part[0][g][ch];
+      s1 += s_part[1][g][ch];
+    }
+    red[(long long)YOLO_BN_RED_SLOTS * 2 * C + c] = s0;
+    red[(long long)YOLO_BN_RED_SLOTS * 2 * C + C + c] = s1;
+    if (aux != nullptr) {   // per-channel parts of the bound of dx (bn_bwd_apply8_kernel): |x - mean| invstd <= sqrt(P)
+      const double asc = fabs((double)scale[c]);
+      t1 = (float)asc;
+      t2 = (float)(asc * (fabs(s1 / (double)P) * sqrt((double)P) + fabs(s0 / (double)P)) * 1.001);
+    }
+  }
+  if (aux != nullptr && threadIdx.x < 64) {   // wave 0 holds the 16 channel results in lanes 0..15
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+      t1 = fmaxf(t1, __shfl_xor(t1, o, 64));
+      t2 = fmaxf(t2, __shfl_xor(t2, o, 64));
+    }
+    if (threadIdx.x == 0) {
+      if (t1 > __builtin_bit_cast(float, aux[1])) atomicMax(&aux[1], __builtin_bit_cast(unsigned, t1));
+      if (t2 > __builtin_bit_cast(float, aux[2])) atomicMax(&aux[2], __builtin_bit_cast(unsigned, t2));
+    }
+  }
+  if (aux != nullptr && blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 128) {   // fold the 64 slots of max|dz|
+    unsigned m = aux[4 + (threadIdx.x & 63)];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const unsigned v = __shfl_xor(m, o, 64);
       m = v > m ? v : m;
     }
-    if (threadIdx.x == 0) aux[0] = m;
+    if ((threadIdx.x & 63) == 0) aux[0] = m;
   }
 }
 
@@ -584,7 +609,7 @@ extern "C" int yolo_bn_act_bwd_reduce_bound(const float* x, const float* dout, l
   dim3 grid(gx, (C / 4 + g.cw - 1) / g.cw);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, dout, P, C, g.cw, g.rpp, scale,
                      shift, save_mean, save_invstd, act, red, bound_aux);
-  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), C, red, gx, P, scale,
+  hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), C, red, gx, P, scale,
                      bound_aux);
   return check_launch("bn_bwd_reduce_kernel");
 }
