@@ -80,6 +80,11 @@ typedef struct yolo_conv_desc {
  * training-mode BatchNormalization (yolov3/models/backbone.py:54). */
 int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const float* w,
                     const float* bias, float* y, double* stats, void* stream);
+/* the same, and if absmax != NULL (uint32[Cout], zeroed by the caller; needs stats) the epilogue also leaves
+ * the bit pattern of the per-channel max|y| there: the data-derived bound the "planes" scales want
+ * (yolo_bn_finalize_bound) */
+int yolo_conv2d_fwd_absmax(const yolo_conv_desc* d, const float* x, const float* w, const float* bias,
+                           float* y, double* stats, unsigned* absmax, void* stream);
 
 /* dx (+)= conv_transpose(dy, w).  wT is the filter re-laid as [Cin][kh][kw][Cout]
  * (yolo_filter_transpose).  accumulate != 0 adds into dx (fan-out of a tensor). */
@@ -123,7 +128,7 @@ int yolo_filter_transpose_batch(const void* jobs, int njobs, long long total_blo
  * [Cout][kh*kw*Cin]; dy_planes = planes of dy [N*Ho*Wo][Cout], wT_planes = planes of wT [Cin][kh*kw*Cout].
  * Requires Cin % 16 == 0 and Cout >= 32 (dgrad: Cout % 16 == 0 and Cin >= 32). */
 int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,
-                           const float* bias, float* y, double* stats, void* stream);
+                           const float* bias, float* y, double* stats, unsigned* absmax, void* stream);
 int yolo_conv2d_dgrad_planes(const yolo_conv_desc* d, const void* dy_planes, const void* wT_planes,
                              float* dx, int accumulate, void* stream);
 /* yolo_conv2d_wgrad on pre-split operands (dw += ..., same contract; the bias gradient stays with
@@ -185,8 +190,10 @@ int yolo_bn_act_bwd_apply(const float* x, const float* dout, long long P, int C,
  * yolo_split_planes pass. planes == NULL: plain forms. The planes need an upper bound of max|result| for
  * their power-of-two scale; it comes from the statistics, not from a pass over the data:
  *  - forward: yolo_bn_finalize_bound leaves in *bound (one uint32, zeroed by the caller before) the bit
- *    pattern of max_c |gamma_c| sqrt(P var_c / (var_c + eps)) + |beta_c| >= max|act(BN(x))|; yolo_bn_act_fwd_planes
- *    adds *residual_bound (bound of the residual tensor) and stores the sum in *out_bound (optional);
+ *    pattern of max_c |scale_c| (max|x_c| + |mean_c|) + |beta_c| >= max|act(BN(x))| when the conv epilogue's
+ *    per-channel absmax is given, else of max_c |gamma_c| sqrt(P var_c / (var_c + eps)) + |beta_c| (valid because
+ *    (x_i - mean)^2 <= P var, but looser by up to sqrt(P)); yolo_bn_act_fwd_planes adds *residual_bound (bound
+ *    of the residual tensor) and stores the sum in *out_bound (optional);
  *  - backward: yolo_bn_act_bwd_reduce_bound leaves in bound_aux[0..2] max|dz|, max_c|scale_c| and
  *    max_c |scale_c| (|mean(dz xhat)_c| sqrt(P) + |mean(dz)_c|), which bound dx; bound_aux holds 68 uint32,
  *    all zeroed by the caller ([3] unused, [4..67] are replica slots of max|dz|).
@@ -194,7 +201,7 @@ int yolo_bn_act_bwd_apply(const float* x, const float* dout, long long P, int C,
 int yolo_bn_finalize_bound(double* stats, long long P, int C, const float* gamma, const float* beta, float eps,
                            float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
                            float* scale, float* shift, float* save_mean, float* save_invstd,
-                           unsigned* bound, void* stream);
+                           const unsigned* absmax, unsigned* bound, void* stream);
 int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scale, const float* shift,
                            int act, const float* residual, float* out, void* planes,
                            const unsigned* bn_bound, const float* residual_bound, float* out_bound,

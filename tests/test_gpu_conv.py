@@ -113,8 +113,12 @@ def test_conv_fused_bn_statistics(case):
     ref = L.conv2d(x, wk, b, stride=s, padding=pad).reshape(-1, cout)
     d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
     stats = torch.zeros(ops.BN_STAT_SLOTS * 2 * cout, device="cuda", dtype=torch.float64)
-    ops.conv2d_fwd(d, x.float().cuda(), _krsc(wk).float().cuda(), None if b is None else b.float().cuda(), stats=stats)
+    amax = torch.zeros(cout, device="cuda", dtype=torch.int32)
+    y = ops.conv2d_fwd(d, x.float().cuda(), _krsc(wk).float().cuda(), None if b is None else b.float().cuda(),
+                       stats=stats, absmax=amax)
     torch.cuda.synchronize()
+    # per-channel max|y| (bit patterns): exactly the maximum of what the kernel wrote
+    assert torch.equal(amax.view(torch.float32), y.reshape(-1, cout).abs().max(0).values)
     got = stats.cpu().reshape(ops.BN_STAT_SLOTS, 2, cout).sum(0)
     assert _relerr(got[0], ref.sum(0)) < 1e-5 * max(1.0, (ref.abs().sum(0).max() / ref.sum(0).abs().max()).item())
     assert _relerr(got[1], (ref * ref).sum(0)) < 1e-5
@@ -176,8 +180,10 @@ def test_conv_fwd_planes(case):
     xp = ops.split_planes(xd, n * h * w, cin)
     wp = ops.split_planes(wd, cout, k * k * cin)
     stats = torch.zeros(ops.BN_STAT_SLOTS * 2 * cout, device="cuda", dtype=torch.float64)
-    y = ops.conv2d_fwd_planes(d, xp, wp, bd, stats=stats)
+    amax = torch.zeros(cout, device="cuda", dtype=torch.int32)
+    y = ops.conv2d_fwd_planes(d, xp, wp, bd, stats=stats, absmax=amax)
     torch.cuda.synchronize()
+    assert torch.equal(amax.view(torch.float32), y.reshape(-1, cout).abs().max(0).values)
     assert _relerr(y.double().cpu(), ref) < TOL
     # the exact bf16 x 6 kernel (register-staged, fp32 operands) and the fp16 x 3 planes kernel agree to a few
     # fp32 roundings of the accumulated magnitude

@@ -214,6 +214,12 @@ def test_bn_kernels_emit_planes(C, act, use_res):
     ob = torch.zeros(1, device=dev)
     ops.bn_stats(x, C, stats)
     ops.bn_finalize(stats, P, C, gd, bd, None, None, scale, shift, smean, sinv, bound=aux[0:1])
+    loose = float(aux[0:1].view(torch.float32))
+    # with the producer's per-channel max|x| the bound is tight (within the |mean| slack), without it only valid
+    aux[0] = 0
+    amax = x.reshape(P, C).abs().max(0).values.view(torch.int32).contiguous()
+    ops.bn_finalize(stats, P, C, gd, bd, None, None, scale, shift, smean, sinv, bound=aux[0:1], absmax=amax)
+    assert float(aux[0:1].view(torch.float32)) <= loose * 1.01
     pl = torch.zeros(ops.planes_bytes(P, C), device=dev, dtype=torch.uint8)
     o = ops.bn_act_fwd(x, C, scale, shift, act, res, planes=pl, bn_bound=aux[0:1], residual_bound=rb if use_res else None,
                        out_bound=ob)

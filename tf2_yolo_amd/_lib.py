@@ -50,7 +50,8 @@ SIGNATURES = {
     "yolo_split_planes": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_split_planes_batch": (c_int, [_P, c_int, _LL, _P]),
     "yolo_filter_transpose_batch": (c_int, [_P, c_int, _LL, _P]),
-    "yolo_conv2d_fwd_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
+    "yolo_conv2d_fwd_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "yolo_conv2d_fwd_absmax": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "yolo_conv2d_dgrad_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P]),
     "yolo_conv2d_wgrad_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P]),
     "yolo_bn_stats": (c_int, [_P, _LL, c_int, _P, _P]),
@@ -63,7 +64,7 @@ SIGNATURES = {
     "yolo_bn_act_bwd_apply_planes": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
                                              _P]),
     "yolo_bn_finalize_bound": (c_int, [_P, _LL, c_int, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
-                                       _P]),
+                                       _P, _P]),
     "yolo_bn_act_bwd_reduce_bound": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "yolo_act_fwd": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_act_bwd": (c_int, [_P, _P, _LL, c_int, _P, _P]),

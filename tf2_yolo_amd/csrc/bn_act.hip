@@ -107,7 +107,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                    float momentum, int unbiased, float* __restrict__ mmean, float* __restrict__ mvar,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
-                                   float* __restrict__ sinv, unsigned* __restrict__ bound) {
+                                   float* __restrict__ sinv, const unsigned* __restrict__ absmax,
+                                   unsigned* __restrict__ bound) {
   // one wave per channel: lane r reads replica slot r, shuffle-reduce (128 dependent loads per thread before)
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -128,7 +129,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
   if (bound != nullptr) {
     // |act(scale*y + shift)| <= |gamma| * |y - mean| * inv + |beta| and (y_i - mean)^2 <= sum_j (y_j - mean)^2 = P*var:
     // an upper bound of the layer's output that needs no pass over the data (planes.hpp: any B >= max|x| will do)
-    bnd = (float)(fabs((double)gamma[c]) * inv * sqrt((double)P * var) * 1.001 + fabs((double)beta[c]) + 1e-30);
+    // (with the conv epilogue's per-channel max|y| the bound is tight: |y - mean| <= max|y| + |mean|)
+    const double dev = absmax != nullptr ? (double)__builtin_bit_cast(float, absmax[c]) + fabs(mean)
+                                         : sqrt((double)P * var);
+    bnd = (float)(fabs((double)gamma[c]) * inv * dev * 1.001 + fabs((double)beta[c]) + 1e-30);
     if (bnd > __builtin_bit_cast(float, bound[0])) atomicMax(bound, __builtin_bit_cast(unsigned, bnd));
   }
   if (mmean != nullptr) {
@@ -536,14 +540,14 @@ extern "C" int yolo_bn_stats(const float* x, long long P, int C, double* stats, 
 extern "C" int yolo_bn_finalize_bound(double* stats, long long P, int C, const float* gamma, const float* beta,
                                       float eps, float momentum, int unbiased_moving_var, float* moving_mean,
                                       float* moving_var, float* scale, float* shift, float* save_mean,
-                                      float* save_invstd, unsigned* bound, void* stream) {
+                                      float* save_invstd, const unsigned* absmax, unsigned* bound, void* stream) {
   YOLO_REQUIRE(stats && gamma && beta && scale && shift && save_mean && save_invstd && P > 0 && C > 0,
                "bn_finalize: bad args");
   YOLO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must come in pairs");
   static_assert(YOLO_BN_STAT_SLOTS == 64, "bn_finalize_kernel: one lane per replica slot");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), stats, P, C, gamma,
                      beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var, scale, shift, save_mean,
-                     save_invstd, bound);
+                     save_invstd, absmax, bound);
   return check_launch("bn_finalize_kernel");
 }
 
@@ -551,7 +555,7 @@ extern "C" int yolo_bn_finalize(double* stats, long long P, int C, const float* 
                                 float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
                                 float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
   return yolo_bn_finalize_bound(stats, P, C, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
-                                scale, shift, save_mean, save_invstd, nullptr, stream);
+                                scale, shift, save_mean, save_invstd, nullptr, nullptr, stream);
 }
 
 extern "C" int yolo_bn_fold_inference(int C, const float* gamma, const float* beta, const float* moving_mean,

@@ -280,13 +280,13 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
   // (fp32 over <= 128 rows), combined across the waves that share the columns through LDS, then ONE
   // fp64 atomic per column per block into one of YOLO_BN_STAT_SLOTS replicas (spreads contention).
   float* sred = smem + 2 * BM;  // after the row-offset table (BM long longs)
-  float csum[TN], csq[TN];
+  float csum[TN], csq[TN], cmx[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
     const bool cok = col < a.Cout;
     const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, mx = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -299,36 +299,44 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
           a.dst[off + col] = v;
           s1 += v;
           s2 += v * v;
+          mx = fmaxf(mx, fabsf(v));
         }
       }
     }
     csum[j] = s1;
     csq[j] = s2;
+    cmx[j] = mx;
   }
   if (a.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
       const float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      const float mx = fmaxf(cmx[j], __shfl_xor(cmx[j], 32, 64));
       if (lane < 32) {
         const int c = (wn * TN + j) * 32 + lane;  // column within the block tile
-        sred[(wm * BN + c) * 2 + 0] = s1;
-        sred[(wm * BN + c) * 2 + 1] = s2;
+        sred[(wm * BN + c) * 3 + 0] = s1;
+        sred[(wm * BN + c) * 3 + 1] = s2;
+        sred[(wm * BN + c) * 3 + 2] = mx;
       }
     }
     __syncthreads();
     for (int c = tid; c < BN; c += 256) {
       const int col = n0 + c;
       if (col < a.Cout) {
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, mx = 0.f;
 #pragma unroll
         for (int w = 0; w < WGM; ++w) {
-          s1 += sred[(w * BN + c) * 2 + 0];
-          s2 += sred[(w * BN + c) * 2 + 1];
+          s1 += sred[(w * BN + c) * 3 + 0];
+          s2 += sred[(w * BN + c) * 3 + 1];
+          mx = fmaxf(mx, sred[(w * BN + c) * 3 + 2]);
         }
         double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
         atomicAdd(&slot[col], (double)s1);
         atomicAdd(&slot[a.Cout + col], (double)s2);
+        // per-channel max|y| (bit patterns of non-negative floats order like integers); most tiles skip the atomic
+        if (a.absmax != nullptr && __builtin_bit_cast(unsigned, mx) > a.absmax[col])
+          atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, mx));
       }
     }
   }
@@ -733,8 +741,8 @@ static void fill_fwd_args(const yolo_conv_desc* d, GatherConvArgs& a) {
     for (int s = 0; s < d->kw; ++s) a.taps[r * d->kw + s] = Tap{r - d->pad_t, s - d->pad_l, (r * d->kw + s) * d->Cin};
 }
 
-extern "C" int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
-                               double* stats, void* stream) {
+extern "C" int yolo_conv2d_fwd_absmax(const yolo_conv_desc* d, const float* x, const float* w, const float* bias,
+                                      float* y, double* stats, unsigned* absmax, void* stream) {
   if (int rc = validate_desc(d)) return rc;
   YOLO_REQUIRE(x && w && y, "conv_fwd: null pointer");
   GatherConvArgs a{};
@@ -744,12 +752,18 @@ extern "C" int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const fl
   a.dst = y;
   fill_fwd_args(d, a);
   a.stats = stats;
+  a.absmax = stats ? absmax : nullptr;
   const bool flat = (d->Cin % 32) != 0;
   return dispatch_gather(a, flat, as_stream(stream));
 }
 
+extern "C" int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
+                               double* stats, void* stream) {
+  return yolo_conv2d_fwd_absmax(d, x, w, bias, y, stats, nullptr, stream);
+}
+
 extern "C" int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,
-                                      const float* bias, float* y, double* stats, void* stream) {
+                                      const float* bias, float* y, double* stats, unsigned* absmax, void* stream) {
   if (int rc = validate_desc(d)) return rc;
   YOLO_REQUIRE(x_planes && w_planes && y, "conv_fwd_planes: null pointer");
   GatherConvArgs a{};
@@ -759,6 +773,7 @@ extern "C" int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_pla
   a.dst = y;
   fill_fwd_args(d, a);
   a.stats = stats;
+  a.absmax = stats ? absmax : nullptr;
   YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_planes: needs Cin %% 16 == 0 and Cout >= 32");
   return launch_gather_planes(a, as_stream(stream));
 }

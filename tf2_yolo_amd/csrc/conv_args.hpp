@@ -17,6 +17,7 @@ struct GatherConvArgs {
   const float* bias;
   float* dst;
   double* stats;  // optional [YOLO_BN_STAT_SLOTS][2*Cout]: per-channel sum / sum of squares of dst
+  unsigned* absmax;  // optional (with stats) [Cout]: bit patterns of the per-channel max |dst|
   long long M;  // N*Hg*Wg
   int N, Hs, Ws, Cs;
   int Hg, Wg;

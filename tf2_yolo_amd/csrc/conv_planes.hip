@@ -283,13 +283,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
       reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2] *
       reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wgt) + a.wgt_bytes - PL_HEADER)[2];
   float* sred = smf + 2 * BM;
-  float csum[TN], csq[TN];
+  float csum[TN], csq[TN], cmx[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
     const bool cok = col < a.Cout;
     const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, mx = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -302,36 +302,44 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
           a.dst[off + col] = v;
           s1 += v;
           s2 += v * v;
+          mx = fmaxf(mx, fabsf(v));
         }
       }
     }
     csum[j] = s1;
     csq[j] = s2;
+    cmx[j] = mx;
   }
   if (a.stats != nullptr) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
       const float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
+      const float mx = fmaxf(cmx[j], __shfl_xor(cmx[j], 32, 64));
       if (lane < 32) {
         const int c = (wn * TN + j) * 32 + lane;
-        sred[(wm * BN + c) * 2 + 0] = s1;
-        sred[(wm * BN + c) * 2 + 1] = s2;
+        sred[(wm * BN + c) * 3 + 0] = s1;
+        sred[(wm * BN + c) * 3 + 1] = s2;
+        sred[(wm * BN + c) * 3 + 2] = mx;
       }
     }
     __syncthreads();
     for (int c = tid; c < BN; c += NT) {
       const int col = n0 + c;
       if (col < a.Cout) {
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, mx = 0.f;
 #pragma unroll
         for (int w = 0; w < WGM; ++w) {
-          s1 += sred[(w * BN + c) * 2 + 0];
-          s2 += sred[(w * BN + c) * 2 + 1];
+          s1 += sred[(w * BN + c) * 3 + 0];
+          s2 += sred[(w * BN + c) * 3 + 1];
+          mx = fmaxf(mx, sred[(w * BN + c) * 3 + 2]);
         }
         double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
         atomicAdd(&slot[col], (double)s1);
         atomicAdd(&slot[a.Cout + col], (double)s2);
+        // per-channel max|y| (bit patterns of non-negative floats order like integers); most tiles skip the atomic
+        if (a.absmax != nullptr && __builtin_bit_cast(unsigned, mx) > a.absmax[col])
+          atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, mx));
       }
     }
   }

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes16_kernel
     const int col = n0 + cl;
     const bool cok = col < a.Cout;
     const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f, mx = 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -243,6 +243,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes16_kernel
           a.dst[off + col] = v;
           s1 += v;
           s2 += v * v;
+          mx = fmaxf(mx, fabsf(v));
         }
       }
     }
@@ -251,9 +252,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes16_kernel
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64);
       s2 += __shfl_xor(s2, 32, 64);
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       if (lane < 16) {
-        sred[(wm * BN + cl) * 2 + 0] = s1;
-        sred[(wm * BN + cl) * 2 + 1] = s2;
+        sred[(wm * BN + cl) * 3 + 0] = s1;
+        sred[(wm * BN + cl) * 3 + 1] = s2;
+        sred[(wm * BN + cl) * 3 + 2] = mx;
       }
     }
   }
@@ -262,15 +266,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes16_kernel
     for (int c = tid; c < BN; c += NT) {
       const int col = n0 + c;
       if (col < a.Cout) {
-        float s1 = 0.f, s2 = 0.f;
+        float s1 = 0.f, s2 = 0.f, mx = 0.f;
 #pragma unroll
         for (int w = 0; w < WGM; ++w) {
-          s1 += sred[(w * BN + c) * 2 + 0];
-          s2 += sred[(w * BN + c) * 2 + 1];
+          s1 += sred[(w * BN + c) * 3 + 0];
+          s2 += sred[(w * BN + c) * 3 + 1];
+          mx = fmaxf(mx, sred[(w * BN + c) * 3 + 2]);
         }
         double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
         atomicAdd(&slot[col], (double)s1);
         atomicAdd(&slot[a.Cout + col], (double)s2);
+        if (a.absmax != nullptr && __builtin_bit_cast(unsigned, mx) > a.absmax[col])
+          atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, mx));
       }
     }
   }

@@ -342,9 +342,13 @@ class Network:
         self._jobs_wp = self._jobs_wTp = self._jobs_wT = None
         # bounds for the planes scales (planes.hpp): 72 words per conv unit, zeroed every step; one float per
         # tensor = bound of that activation
-        for i, u in enumerate(self.units):
-            u.aux_off = 72 * i    # [0] forward bound, [1..68] = the 68 words of yolo_bn_act_bwd_reduce_bound
-        self._aux = torch.zeros(72 * max(len(self.units), 1), device=self.device, dtype=torch.int32)
+        off = 0
+        for u in self.units:
+            u.aux_off = off       # [0] forward bound, [1..68] = the 68 words of yolo_bn_act_bwd_reduce_bound,
+            off += 72             # [72 .. 72+C) = per-channel max|conv out| from the conv epilogue
+            if u.kind == "conv" and u.bn:
+                off += (u.cout + 7) // 8 * 8
+        self._aux = torch.zeros(max(off, 1), device=self.device, dtype=torch.int32)
         self._tbound = torch.zeros(max(len(self.tensors), 1) + 1, device=self.device, dtype=torch.float32)
 
     # ---- construction -------------------------------------------------------------------
@@ -483,10 +487,11 @@ class Network:
         self._wTp_valid = True
 
     def _conv_fwd(self, u, xin, w, bias, out, stats=None):
+        amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout] if stats is not None else None
         if u.planes_fwd:
             return ops.conv2d_fwd_planes(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias,
-                                         out=out, stats=stats)
-        return ops.conv2d_fwd(u.desc, xin, w, bias, out=out, stats=stats)
+                                         out=out, stats=stats, absmax=amax)
+        return ops.conv2d_fwd(u.desc, xin, w, bias, out=out, stats=stats, absmax=amax)
 
     def _bn_bufs(self, u):
         c = u.cout
@@ -536,7 +541,8 @@ class Network:
                         ops.bn_finalize(stats, u.y.numel() // u.cout, u.cout, gamma, beta,
                                         self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
                                         scale, shift, smean, sinv, unbiased=self.unbiased_moving_var,
-                                        bound=self._aux[u.aux_off:u.aux_off + 1])
+                                        bound=self._aux[u.aux_off:u.aux_off + 1],
+                                        absmax=self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout])
                     else:
                         self._conv_fwd(u, xin, w, bias, u.y)
                         if not self._infer_scale_valid:

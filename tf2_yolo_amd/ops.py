@@ -142,7 +142,7 @@ def conv_desc(x_shape, cout, kh, kw, stride, padding):
     return ConvDesc(n, h, w, cin, cout, kh, kw, ho, wo, stride, stride, pt, pl)
 
 
-def conv2d_fwd(d, x, w, bias=None, out=None, stats=None):
+def conv2d_fwd(d, x, w, bias=None, out=None, stats=None, absmax=None):
     _chk_f32(x, w, bias)
     if out is None:
         out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=x.device, dtype=torch.float32)
@@ -153,8 +153,8 @@ def conv2d_fwd(d, x, w, bias=None, out=None, stats=None):
     if stats is not None and stats.numel() != BN_STAT_SLOTS * 2 * d.Cout:
         raise YoloHipError("conv2d_fwd: stats must hold BN_STAT_SLOTS x 2 x Cout doubles")
     def run():
-        check(_lib.load().yolo_conv2d_fwd(byref(d), _p(x), _p(w), _p(bias), _p(out), _p(stats), _stream()),
-              "yolo_conv2d_fwd")
+        check(_lib.load().yolo_conv2d_fwd_absmax(byref(d), _p(x), _p(w), _p(bias), _p(out), _p(stats), _p(absmax),
+                                                 _stream()), "yolo_conv2d_fwd")
     if TIMER is not None:
         TIMER.bracket(_gather_variant(d.Cout, d.Cin % 32 != 0, d.N * d.Ho * d.Wo), _conv_flops(d), 1, run)
     else:
@@ -209,7 +209,7 @@ class BatchJobs:
         check(fn(_p(self.table), len(self.rows), self.blocks, _stream()), "yolo_%s_batch" % self.kind)
 
 
-def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None):
+def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None, absmax=None):
     _chk_f32(bias)
     if out is None:
         out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=xp.device, dtype=torch.float32)
@@ -220,8 +220,8 @@ def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None):
     if stats is not None and stats.numel() != BN_STAT_SLOTS * 2 * d.Cout:
         raise YoloHipError("conv2d_fwd_planes: stats must hold BN_STAT_SLOTS x 2 x Cout doubles")
     def run():
-        check(_lib.load().yolo_conv2d_fwd_planes(byref(d), _p(xp), _p(wp), _p(bias), _p(out), _p(stats), _stream()),
-              "yolo_conv2d_fwd_planes")
+        check(_lib.load().yolo_conv2d_fwd_planes(byref(d), _p(xp), _p(wp), _p(bias), _p(out), _p(stats), _p(absmax),
+                                                 _stream()), "yolo_conv2d_fwd_planes")
     if TIMER is not None:
         TIMER.bracket(_planes_variant(d.Cout), _conv_flops(d), 1, run)
     else:
@@ -322,12 +322,13 @@ def bn_stats(x, C, stats):
 
 
 def bn_finalize(stats, P, C, gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd,
-                eps=BN_EPS, momentum=BN_MOMENTUM, unbiased=False, bound=None):
+                eps=BN_EPS, momentum=BN_MOMENTUM, unbiased=False, bound=None, absmax=None):
     """bound: optional int32 CUDA tensor (1 word, zeroed) that receives the bit pattern of an upper bound of
-    max|act(BN(x))| (needed by bn_act_fwd(planes=...))"""
+    max|act(BN(x))| (needed by bn_act_fwd(planes=...)); absmax: optional int32 [C] per-channel max|x| bit patterns
+    from the conv epilogue (makes the bound tight)"""
     check(_lib.load().yolo_bn_finalize_bound(_p(stats), P, C, _p(gamma), _p(beta), eps, momentum, int(unbiased),
                                              _p(moving_mean), _p(moving_var), _p(scale), _p(shift), _p(save_mean),
-                                             _p(save_invstd), _p(bound), _stream()), "yolo_bn_finalize")
+                                             _p(save_invstd), _p(absmax), _p(bound), _stream()), "yolo_bn_finalize")
 
 
 def bn_fold_inference(C, gamma, beta, moving_mean, moving_var, scale, shift, eps=BN_EPS):
