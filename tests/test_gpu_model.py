@@ -307,3 +307,29 @@ def test_weights_roundtrip_and_layer_views(tmp_path):
         yolov3.Yolo((64, 64, 3), ["a"]).create_model(backbone="nope", pretrained_body=None)
     with pytest.raises(ValueError, match="multiple"):
         yolov3.Yolo((64, 64, 3), ["a"]).create_model(anchors=A9[:8], pretrained_body=None)
+
+
+def test_planes_path_agrees_with_exact_kernels_at_full_layer_sizes():
+    """YOLOv3-416 (the benchmark's layer sizes, batch 4): the fp16 x 3 planes path against the exact bf16 x 6
+    kernels (YOLO_CONV_PLANES=0), each in its own process. The unit tests run small tensors; this one exercises
+    the per-tensor scales and bounds on 5.5 M-pixel activations. Head outputs and losses must agree to 1e-4
+    (fp32 parity bar); gradient norms to 1e-3 (LeakyReLU branch flips near zero move individual gradients)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for planes in ("1", "0"):
+        env = dict(os.environ, YOLO_CONV_PLANES=planes)
+        out = subprocess.run([sys.executable, os.path.join(root, "scripts", "full_size_step.py"), "4"], env=env,
+                             capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    a, b = res
+    assert a["grad_finite"] and b["grad_finite"]
+    for la, lb in zip(a["loss"], b["loss"]):
+        assert abs(la - lb) <= 1e-4 * abs(lb), (a["loss"], b["loss"])
+    for oa, ob in zip(a["out_abs_sum"], b["out_abs_sum"]):
+        assert abs(oa - ob) <= 1e-4 * abs(ob), (a["out_abs_sum"], b["out_abs_sum"])
+    assert abs(a["grad_l2"] - b["grad_l2"]) <= 1e-3 * b["grad_l2"], (a["grad_l2"], b["grad_l2"])
