@@ -202,6 +202,10 @@ int yolo_bn_finalize_bound(double* stats, long long P, int C, const float* gamma
                            float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
                            float* scale, float* shift, float* save_mean, float* save_invstd,
                            const unsigned* absmax, unsigned* bound, void* stream);
+/* inference (folded scale / shift, no batch statistics): *bound = bit pattern of
+ * max_c |scale_c| max|x_c| + |shift_c| from the conv epilogue's per-channel absmax */
+int yolo_bn_infer_bound(int C, const float* scale, const float* shift, const unsigned* absmax,
+                        unsigned* bound, void* stream);
 int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scale, const float* shift,
                            int act, const float* residual, float* out, void* planes,
                            const unsigned* bn_bound, const float* residual_bound, float* out_bound,

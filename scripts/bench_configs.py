@@ -70,7 +70,12 @@ if "c5" in which:
         return (time.perf_counter() - t0) / n * 1e3, r
 
     t_fwd, outs = timed(lambda: m.net.forward(x, training=False))
-    print(json.dumps({"config": "C5 YOLOv3 416 bs=1 inference forward (random weights)", "ms": round(t_fwd, 3)}), flush=True)
+    print(json.dumps({"config": "C5 YOLOv3 416 bs=1 inference forward (random weights), launches enqueued one by one",
+                      "ms": round(t_fwd, 3)}), flush=True)
+    t_g, outs_g = timed(lambda: m.net.infer(x))
+    same = all(torch.equal(a, b) for a, b in zip(outs_g, m.net.forward(x, training=False)))
+    print(json.dumps({"config": "C5 YOLOv3 416 bs=1 inference forward, hipGraph replay (Model.predict)", "ms": round(t_g, 3),
+                      "same_as_eager": bool(same)}), flush=True)
     # decode + NMS on the model's own predictions (random weights) and on the BASELINE.md noise inputs
     lv = [outs[2][0], outs[1][0], outs[0][0]]
     t_dec, dec = timed(lambda: tools.decode_device(*lv, class_num=80, threshold=0.5, version=3))

@@ -152,3 +152,33 @@ def test_v4_trainable_anchors():
     moved = net.anchors_flat.double().cpu().numpy() - base.double().cpu().numpy()
     assert np.abs(moved).max() > 0 and (np.sign(moved[np.abs(g) > 1e-6]) == -np.sign(g[np.abs(g) > 1e-6])).all()
     assert not np.allclose(np.array(y.anchors), a0)
+
+
+def test_graph_inference_matches_eager_and_tracks_weight_updates():
+    """Network.infer (hipGraph replay, used by Model.predict) == forward(training=False); a weight change drops the graph"""
+    import torch
+    import yolov3
+    y = yolov3.Yolo((64, 64, 3), ["a", "b"])
+    y.create_model(anchors=A9, pretrained_body=None)
+    net = y.model.net
+    rng = np.random.default_rng(0)
+    x1 = torch.from_numpy(rng.random((2, 64, 64, 3), dtype=np.float32)).cuda()
+    x2 = torch.from_numpy(rng.random((2, 64, 64, 3), dtype=np.float32)).cuda()
+    for x in (x1, x2, x1):
+        g = [o.clone() for o in net.infer(x)]
+        e = [o.clone() for o in net.forward(x, training=False)]
+        assert all(torch.equal(a, b) for a, b in zip(g, e))
+    assert 2 in net._infer_graphs
+    k = net.params.order[0]
+    before = [o.clone() for o in net.infer(x1)]
+    net.params.view(k).mul_(0.5)
+    net.mark_params_changed()
+    assert not net._infer_graphs
+    g = [o.clone() for o in net.infer(x1)]
+    e = [o.clone() for o in net.forward(x1, training=False)]
+    # (an untrained net in inference mode may overflow to inf/nan, as in Keras: compare nan-aware)
+    same = lambda a, b: bool(torch.isclose(a, b, rtol=0, atol=0, equal_nan=True).all())
+    assert all(same(a, b) for a, b in zip(g, e))
+    assert not all(same(a, b) for a, b in zip(g, before))          # the new weights are in the new graph
+    p = y.model.predict(x1.cpu().numpy())
+    assert all(np.array_equal(a, b.cpu().numpy(), equal_nan=True) for a, b in zip(p, e))

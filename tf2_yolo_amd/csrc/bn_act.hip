@@ -43,6 +43,23 @@ static inline ColGeom col_geom(int C4) {
   return g;
 }
 
+// inference: bound of act(scale*y + shift) from the conv epilogue's per-channel max|y| (one workgroup)
+__global__ __launch_bounds__(256) void bn_infer_bound_kernel(int C, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift,
+                                                             const unsigned* __restrict__ absmax,
+                                                             unsigned* __restrict__ bound) {
+  __shared__ float s_max[4];
+  float b = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256)
+    b = fmaxf(b, fabsf(scale[c]) * __builtin_bit_cast(float, absmax[c]) * 1.001f + fabsf(shift[c]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = b;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    bound[0] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])) + 1e-30f);
+}
+
 template <int NQ, bool EXCLUSIVE = false>
 __device__ __forceinline__ void block_col_reduce(double (&v)[NQ][4], int cw, int rpp, int row_lane, int col,
                                                  bool active, double* smem /* [NQ*4][256] */,
@@ -564,6 +581,13 @@ extern "C" int yolo_bn_fold_inference(int C, const float* gamma, const float* be
   hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), C, gamma, beta,
                      moving_mean, moving_var, eps, scale, shift);
   return check_launch("bn_fold_kernel");
+}
+
+extern "C" int yolo_bn_infer_bound(int C, const float* scale, const float* shift, const unsigned* absmax,
+                                   unsigned* bound, void* stream) {
+  YOLO_REQUIRE(C > 0 && scale && shift && absmax && bound, "bn_infer_bound: bad args");
+  hipLaunchKernelGGL(bn_infer_bound_kernel, dim3(1), dim3(256), 0, as_stream(stream), C, scale, shift, absmax, bound);
+  return check_launch("bn_infer_bound_kernel");
 }
 
 extern "C" int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scale, const float* shift,

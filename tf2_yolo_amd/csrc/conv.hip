@@ -307,7 +307,7 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
     csq[j] = s2;
     cmx[j] = mx;
   }
-  if (a.stats != nullptr) {
+  if (a.stats != nullptr || a.absmax != nullptr) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
@@ -331,9 +331,11 @@ __global__ __launch_bounds__(256) void gather_conv_kernel(const GatherConvArgs a
           s2 += sred[(w * BN + c) * 3 + 1];
           mx = fmaxf(mx, sred[(w * BN + c) * 3 + 2]);
         }
-        double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
-        atomicAdd(&slot[col], (double)s1);
-        atomicAdd(&slot[a.Cout + col], (double)s2);
+        if (a.stats != nullptr) {
+          double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
+          atomicAdd(&slot[col], (double)s1);
+          atomicAdd(&slot[a.Cout + col], (double)s2);
+        }
         // per-channel max|y| (bit patterns of non-negative floats order like integers); most tiles skip the atomic
         if (a.absmax != nullptr && __builtin_bit_cast(unsigned, mx) > a.absmax[col])
           atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, mx));
@@ -752,7 +754,7 @@ extern "C" int yolo_conv2d_fwd_absmax(const yolo_conv_desc* d, const float* x, c
   a.dst = y;
   fill_fwd_args(d, a);
   a.stats = stats;
-  a.absmax = stats ? absmax : nullptr;
+  a.absmax = absmax;
   const bool flat = (d->Cin % 32) != 0;
   return dispatch_gather(a, flat, as_stream(stream));
 }
@@ -773,7 +775,7 @@ extern "C" int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_pla
   a.dst = y;
   fill_fwd_args(d, a);
   a.stats = stats;
-  a.absmax = stats ? absmax : nullptr;
+  a.absmax = absmax;
   YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_planes: needs Cin %% 16 == 0 and Cout >= 32");
   return launch_gather_planes(a, as_stream(stream));
 }

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
     csq[j] = s2;
     cmx[j] = mx;
   }
-  if (a.stats != nullptr) {
+  if (a.stats != nullptr || a.absmax != nullptr) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
@@ -334,9 +334,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
           s2 += sred[(w * BN + c) * 3 + 1];
           mx = fmaxf(mx, sred[(w * BN + c) * 3 + 2]);
         }
-        double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
-        atomicAdd(&slot[col], (double)s1);
-        atomicAdd(&slot[a.Cout + col], (double)s2);
+        if (a.stats != nullptr) {
+          double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
+          atomicAdd(&slot[col], (double)s1);
+          atomicAdd(&slot[a.Cout + col], (double)s2);
+        }
         // per-channel max|y| (bit patterns of non-negative floats order like integers); most tiles skip the atomic
         if (a.absmax != nullptr && __builtin_bit_cast(unsigned, mx) > a.absmax[col])
           atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, mx));

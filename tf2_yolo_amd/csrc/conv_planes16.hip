@@ -247,7 +247,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes16_kernel
         }
       }
     }
-    if (a.stats != nullptr) {
+    if (a.stats != nullptr || a.absmax != nullptr) {
       s1 += __shfl_xor(s1, 16, 64);
       s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64);
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes16_kernel
       }
     }
   }
-  if (a.stats != nullptr) {
+  if (a.stats != nullptr || a.absmax != nullptr) {
     __syncthreads();
     for (int c = tid; c < BN; c += NT) {
       const int col = n0 + c;
@@ -273,9 +273,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes16_kernel
           s2 += sred[(w * BN + c) * 3 + 1];
           mx = fmaxf(mx, sred[(w * BN + c) * 3 + 2]);
         }
-        double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
-        atomicAdd(&slot[col], (double)s1);
-        atomicAdd(&slot[a.Cout + col], (double)s2);
+        if (a.stats != nullptr) {
+          double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
+          atomicAdd(&slot[col], (double)s1);
+          atomicAdd(&slot[a.Cout + col], (double)s2);
+        }
         if (a.absmax != nullptr && __builtin_bit_cast(unsigned, mx) > a.absmax[col])
           atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, mx));
       }

@@ -291,6 +291,8 @@ class Network:
         self._wT = torch.empty(self._wT_total, device=self.device, dtype=torch.float32)
         self._wT_valid = False
         self._overlap_wgrad = os.environ.get("YOLO_BWD_OVERLAP", "1") != "0"
+        self._use_infer_graph = os.environ.get("YOLO_INFER_GRAPH", "1") != "0"
+        self._infer_graphs = {}
         self._wgrad_stream = None
         self._wgrad_pending = False
         self._bn_f32 = torch.zeros(max(self._bn_f32_total, 1), device=self.device, dtype=torch.float32)
@@ -403,6 +405,7 @@ class Network:
         if self.batch == N:
             return
         self.batch = N
+        self._infer_graphs = {}   # captured graphs point into the buffers re-allocated below
         self.act = {}
         dev = self.device
         for u in self.units:
@@ -501,7 +504,33 @@ class Network:
         d = self._bn_f64[u.bn_f64_off:u.bn_f64_off + ns + nr]
         return b[0:c], b[c:2 * c], b[2 * c:3 * c], b[3 * c:4 * c], d[0:ns], d[ns:ns + nr]
 
+    # ---- inference through a captured HIP graph ------------------------------------------------------------
+    def infer(self, x):
+        """forward(x, training=False) replayed from a hipGraph: a batch-1 forward is ~230 launches of a few
+        microseconds each, i.e. launch-bound when enqueued one by one. The graph is captured per batch size after an
+        eager pass (which also refreshes the filter planes and the folded BN scales) and dropped whenever the
+        parameters change. Outputs are the network's persistent head buffers, as with forward()."""
+        if not self._use_infer_graph:
+            return self.forward(x, training=False)
+        x = x.contiguous()
+        N = x.shape[0]
+        g = self._infer_graphs.get(N)
+        if g is None:
+            self.forward(x, training=False)                      # eager: allocations, weight prep, lazy module init
+            static_in = x.clone()
+            self.forward(static_in, training=False)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = self.forward(static_in, training=False)
+            g = self._infer_graphs[N] = (graph, static_in, outs)
+        graph, static_in, outs = g
+        static_in.copy_(x)
+        graph.replay()
+        return outs
+
     def mark_params_changed(self):
+        self._infer_graphs = {}
         self._wT_valid = False
         self._wp_valid = False
         self._wTp_valid = False
@@ -523,8 +552,8 @@ class Network:
         self._xp_valid = set()
         self._tbound_set = set()
         self._refresh_wplanes()
+        self._aux.zero_()   # bounds / per-channel maxima of this pass
         if training:
-            self._aux.zero_()
             self._bn_f64.zero_()
             self._infer_scale_valid = False  # moving statistics (and the shared scale/shift) change
         P = self.params
@@ -544,23 +573,30 @@ class Network:
                                         bound=self._aux[u.aux_off:u.aux_off + 1],
                                         absmax=self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout])
                     else:
-                        self._conv_fwd(u, xin, w, bias, u.y)
+                        amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout]
+                        if u.planes_fwd:
+                            ops.conv2d_fwd_planes(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes],
+                                                  bias, out=u.y, absmax=amax)
+                        else:
+                            ops.conv2d_fwd(u.desc, xin, w, bias, out=u.y, absmax=amax)
                         if not self._infer_scale_valid:
                             ops.bn_fold_inference(u.cout, gamma, beta, self.state.view(u.s_mean.name),
                                                   self.state.view(u.s_var.name), scale, shift)
+                        ops.bn_infer_bound(u.cout, scale, shift, amax, self._aux[u.aux_off:u.aux_off + 1])
                     res = self.act[u.residual.tid] if u.residual is not None else None
-                    # consumers that are planes-capable convs get their operand straight from this kernel (training:
-                    # its scale comes from the batch statistics; inference has none -> separate split pass)
-                    pl = self._xplanes.get(u.out.tid) if (training and u.cout % 16 == 0) else None
+                    # consumers that are planes-capable convs get their operand straight from this kernel; the scale
+                    # comes from the bound bn_finalize (training) / bn_infer_bound (inference) derived from the conv
+                    # epilogue's per-channel max|y|
+                    pl = self._xplanes.get(u.out.tid) if u.cout % 16 == 0 else None
                     if u.residual is not None and u.residual.tid not in self._tbound_set:
                         pl = None   # residual without a recorded bound: split its consumers' operand separately
-                    elif training:
+                    else:
                         self._tbound_set.add(u.out.tid)
                     tb = self._tbound
                     ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a, planes=pl,
-                                   bn_bound=self._aux[u.aux_off:u.aux_off + 1] if training else None,
+                                   bn_bound=self._aux[u.aux_off:u.aux_off + 1],
                                    residual_bound=tb[u.residual.tid:u.residual.tid + 1] if u.residual is not None else None,
-                                   out_bound=tb[u.out.tid:u.out.tid + 1] if training else None)
+                                   out_bound=tb[u.out.tid:u.out.tid + 1])
                     if pl is not None:
                         self._xp_valid.add(u.out.tid)
                 else:

@@ -236,7 +236,7 @@ class Model:
             chunks = [x[i:i + batch_size] for i in range(0, n, batch_size)]
         outs = None
         for c in chunks:
-            o = self.net.forward(_to_input(c), training=False)
+            o = self.net.infer(_to_input(c))
             o = [t.cpu().numpy() for t in o]
             outs = [[a] for a in o] if outs is None else [acc + [a] for acc, a in zip(outs, o)]
         res = [np.concatenate(a, axis=0) for a in outs]

@@ -331,6 +331,11 @@ def bn_finalize(stats, P, C, gamma, beta, moving_mean, moving_var, scale, shift,
                                              _p(save_invstd), _p(absmax), _p(bound), _stream()), "yolo_bn_finalize")
 
 
+def bn_infer_bound(C, scale, shift, absmax, bound):
+    """inference: bound[0] (int32 view of a float) = max_c |scale_c| max|x_c| + |shift_c| >= max|act(scale x + shift)|"""
+    check(_lib.load().yolo_bn_infer_bound(C, _p(scale), _p(shift), _p(absmax), _p(bound), _stream()), "yolo_bn_infer_bound")
+
+
 def bn_fold_inference(C, gamma, beta, moving_mean, moving_var, scale, shift, eps=BN_EPS):
     check(_lib.load().yolo_bn_fold_inference(C, _p(gamma), _p(beta), _p(moving_mean), _p(moving_var), eps,
                                              _p(scale), _p(shift), _stream()), "yolo_bn_fold_inference")
