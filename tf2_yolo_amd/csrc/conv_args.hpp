@@ -32,6 +32,7 @@ struct GatherConvArgs {
   // planes kernels (conv_planes.hip): src / wgt point to bf16 planes; byte sizes and all-zero block indices
   unsigned src_bytes, wgt_bytes;
   int zero_blk_src, zero_blk_wgt;
+  int nt_store;  // planes kernels: non-temporal stores of the output (it is not re-read by this kernel)
   Tap taps[MAX_TAPS];
 };
 

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
         if (cok && off >= 0) {
           float v = fmaf(acc[i][j][q], unscale, bv);
           if (a.accumulate) v += a.dst[off + col];
-          a.dst[off + col] = v;
+          if (a.nt_store) __builtin_nontemporal_store(v, &a.dst[off + col]); else a.dst[off + col] = v;
           s1 += v;
           s2 += v * v;
           mx = fmaxf(mx, fabsf(v));
@@ -383,6 +383,8 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   a.wgt_bytes = (unsigned)bytesB;
   a.zero_blk_src = (int)((rowsA + 15) / 16);
   a.zero_blk_wgt = (a.Cout + 15) / 16;
+  static const int nt = [] { const char* e = getenv("YOLO_NT_STORE"); return e ? atoi(e) : 1; }();
+  a.nt_store = nt;
   // YOLO_PLANES_MFMA=16 selects the 16x16x32-MFMA build of the kernel (conv_planes16.hip): measured equal
   static const int shape = [] { const char* e = getenv("YOLO_PLANES_MFMA"); return e ? atoi(e) : 32; }();
   if (shape == 16 && a.Cout > 32) return launch_gather_planes16(a, st);
