@@ -33,6 +33,7 @@ struct GatherConvArgs {
   unsigned src_bytes, wgt_bytes;
   int zero_blk_src, zero_blk_wgt;
   int nt_store;  // planes kernels: non-temporal stores of the output (it is not re-read by this kernel)
+  int kc;        // planes kernels: 16-channel blocks per chunk of the stage order
   Tap taps[MAX_TAPS];
 };
 

@@ -125,12 +125,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
     ld_voff[i] = 0; ld_soff[i] = 0;
   }
 
-  // ---- loader state: the next stage to issue (tap, 16-channel block) and its DMA offsets ----
-  int ld_tap = 0, ld_kb = 0;
-  auto loader_tap = [&]() {  // per-tap part of the source address (A: the shifted pixel, B: the filter tap)
+  // ---- loader state: the next stage to issue and its DMA offsets. Stage order: the 16-channel blocks are
+  // walked in chunks of a.kc blocks; inside a chunk all taps, inside a tap the chunk's blocks. kc = Cs/16 is
+  // plain tap-major order (every tap re-streams the whole input window: its lines have left L2 by the next tap
+  // when 40+ workgroups share the 4 MB); a small kc makes the taps re-read the same few KB per pixel block
+  // back to back while still streaming whole records. ----
+  int ld_tap = 0, ld_kk = 0, ld_cb = 0;   // tap, block inside the chunk, first block of the chunk
+  auto loader_tap = [&]() {  // per-(chunk, tap) part of the source address (A: the shifted pixel, B: the filter tap)
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
-      if (ld_tap >= a.ntaps) {  // stages past the end (issued to keep the DMA count per stage uniform): zero block
+      if (ld_cb >= cpt) {  // stages past the end (issued to keep the DMA count per stage uniform): zero block
         ld_voff[i] = isA[i] ? (unsigned)a.zero_blk_src * blkstrideA : (unsigned)a.zero_blk_wgt * blkstrideB;
         ld_soff[i] = 0;
       } else if (isA[i]) {
@@ -138,19 +142,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
         const bool ok = ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
         const int pix = (nimg[i] * a.Hs + ys) * a.Ws + xs;
         ld_voff[i] = (ok ? ((unsigned)pix >> 4) : (unsigned)a.zero_blk_src) * blkstrideA + (ok ? (pix & 15) * 16 : 0) + hf * 256;
-        ld_soff[i] = 0;
+        ld_soff[i] = (unsigned)ld_cb * PL_RECORD;
       } else {
         ld_voff[i] = rowbaseB[i];
-        ld_soff[i] = (unsigned)(a.taps[ld_tap].woff >> 4) * PL_RECORD;
+        ld_soff[i] = (unsigned)((a.taps[ld_tap].woff >> 4) + ld_cb) * PL_RECORD;
       }
     }
   };
   auto loader_next = [&]() {
 #pragma unroll
     for (int i = 0; i < LPW; ++i) ld_soff[i] += PL_RECORD;
-    if (++ld_kb == cpt) {
-      ld_kb = 0;
-      ++ld_tap;
+    const int kc_cur = (cpt - ld_cb < a.kc) ? (cpt - ld_cb) : a.kc;
+    if (++ld_kk >= kc_cur) {
+      ld_kk = 0;
+      if (++ld_tap == a.ntaps) {
+        ld_tap = 0;
+        ld_cb += a.kc;
+      }
       loader_tap();
     }
   };
@@ -385,6 +393,10 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   a.zero_blk_wgt = (a.Cout + 15) / 16;
   static const int nt = [] { const char* e = getenv("YOLO_NT_STORE"); return e ? atoi(e) : 1; }();
   a.nt_store = nt;
+  // channel-block chunk of the stage order (see the kernel): YOLO_PLANES_KC overrides
+  static const int kc_env = [] { const char* e = getenv("YOLO_PLANES_KC"); return e ? atoi(e) : 0; }();
+  a.kc = kc_env > 0 ? kc_env : (a.Cs >> 4);
+  if (a.kc > (a.Cs >> 4)) a.kc = a.Cs >> 4;
   // YOLO_PLANES_MFMA=16 selects the 16x16x32-MFMA build of the kernel (conv_planes16.hip): measured equal
   static const int shape = [] { const char* e = getenv("YOLO_PLANES_MFMA"); return e ? atoi(e) : 32; }();
   if (shape == 16 && a.Cout > 32) return launch_gather_planes16(a, st);
