@@ -1,0 +1,101 @@
+"""Properties at BASELINE.json's full sizes, where the CPU oracle is too slow to be the checker: linearity of
+the conv kernels, idempotence and order of decode / NMS, agreement of the BN kernels with a closed form.
+(torch ops on the GPU serve as the checker here, never as the product.)"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return (a.double() - b.double()).abs().max().item() / max(b.double().abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize("shape", [(32, 52, 128, 256, 3, 1), (32, 26, 512, 256, 1, 1), (32, 104, 64, 128, 3, 2)])
+def test_conv_planes_linearity_full_size(shape):
+    """conv(x1 + x2, w) = conv(x1, w) + conv(x2, w) and conv(x, 2w) = 2 conv(x, w) on benchmark-size layers
+    (bs 32): forward, dgrad and wgrad of the planes kernels, each operand with its own scale"""
+    from tf2_yolo_amd import ops
+    n, h, cin, cout, k, s = shape
+    d = ops.conv_desc((n, h, h, cin), cout, k, k, s, "same")
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x1 = torch.randn(n, h, h, cin, device="cuda", generator=g)
+    x2 = torch.randn(n, h, h, cin, device="cuda", generator=g) * 7.0     # different magnitudes -> different scales
+    w = torch.randn(cout, k, k, cin, device="cuda", generator=g) * 0.05
+    rows = n * h * h
+    P = lambda t, r, c: ops.split_planes(t.contiguous(), r, c)
+    wp, w2p = P(w, cout, k * k * cin), P(2 * w, cout, k * k * cin)
+    y1 = ops.conv2d_fwd_planes(d, P(x1, rows, cin), wp)
+    y2 = ops.conv2d_fwd_planes(d, P(x2, rows, cin), wp)
+    y12 = ops.conv2d_fwd_planes(d, P(x1 + x2, rows, cin), wp)
+    assert _rel(y12, y1 + y2) < 2e-6
+    assert _rel(ops.conv2d_fwd_planes(d, P(x1, rows, cin), w2p), 2 * y1) < 1e-6
+    # dgrad / wgrad
+    dy1 = torch.randn(n, d.Ho, d.Wo, cout, device="cuda", generator=g) * 1e-3
+    dy2 = torch.randn(n, d.Ho, d.Wo, cout, device="cuda", generator=g)
+    orow = n * d.Ho * d.Wo
+    wT = ops.filter_transpose(w, cout, k * k, cin)
+    wTp = P(wT, cin, k * k * cout)
+    dx1 = ops.conv2d_dgrad_planes(d, P(dy1, orow, cout), wTp)
+    dx2 = ops.conv2d_dgrad_planes(d, P(dy2, orow, cout), wTp)
+    dx12 = ops.conv2d_dgrad_planes(d, P(dy1 + dy2, orow, cout), wTp)
+    assert _rel(dx12, dx1 + dx2) < 2e-6
+    dw1 = torch.zeros_like(w); dw2 = torch.zeros_like(w); dw12 = torch.zeros_like(w)
+    xp = P(x1, rows, cin)
+    ops.conv2d_wgrad_planes(d, xp, P(dy1, orow, cout), dw1)
+    ops.conv2d_wgrad_planes(d, xp, P(dy2, orow, cout), dw2)
+    ops.conv2d_wgrad_planes(d, xp, P(dy1 + dy2, orow, cout), dw12)
+    assert _rel(dw12, dw1 + dw2) < 5e-6
+
+
+def test_bn_kernels_full_size_closed_form():
+    """training-mode BN + LeakyReLU on a benchmark-size activation (32 x 104 x 104 x 128): mean / variance of the
+    normalised tensor, the fused planes output and the backward identities sum(dx) = 0, sum(dx * xhat) = 0"""
+    from tf2_yolo_amd import ops
+    n, h, C = 32, 104, 128
+    P = n * h * h
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(n, h, h, C, device="cuda", generator=g) * 3 + 1.5
+    stats = torch.zeros(64 * 2 * C, device="cuda", dtype=torch.float64)
+    red = torch.zeros(513 * 2 * C, device="cuda", dtype=torch.float64)
+    f = lambda: torch.empty(C, device="cuda")
+    scale, shift, smean, sinv = f(), f(), f(), f()
+    gamma, beta = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+    aux = torch.zeros(72, device="cuda", dtype=torch.int32)
+    ops.bn_stats(x, C, stats)
+    ops.bn_finalize(stats, P, C, gamma, beta, None, None, scale, shift, smean, sinv, bound=aux[0:1])
+    x2 = x.reshape(P, C).double()
+    assert _rel(smean, x2.mean(0)) < 1e-6
+    z = ops.bn_act_fwd(x, C, scale, shift, 0)      # linear activation: z = xhat
+    z2 = z.reshape(P, C).double()
+    assert z2.mean(0).abs().max().item() < 1e-5 and (z2.var(0, unbiased=False) - 1).abs().max().item() < 2e-3
+    dout = torch.randn(n, h, h, C, device="cuda", generator=g) * 1e-2
+    dx = ops.bn_act_bwd(x, dout, C, gamma, scale, shift, smean, sinv, 0, red, None, None)
+    dx2 = dx.reshape(P, C).double()
+    ref_scale = dout.double().abs().sum().item() / C
+    assert dx2.sum(0).abs().max().item() < 1e-6 * ref_scale
+    assert (dx2 * z2).sum(0).abs().max().item() < 1e-5 * ref_scale
+
+
+def test_decode_nms_properties_full_size():
+    """BASELINE.md's large case (uniform noise, thr 0.5: ~132 k candidates, 80 classes): decode emits exactly the
+    candidates in C order; NMS output is a subset in reference order and NMS is idempotent (bit-exact)"""
+    from tf2_yolo_amd import tools
+    lv = [torch.from_numpy(np.random.default_rng(1234).random((gs, gs, 255), dtype=np.float32)).cuda() for gs in (13, 26, 52)]
+    rows = tools.decode_device(*lv, class_num=80, threshold=0.5, version=3)
+    want = 0
+    for a in lv:
+        v = a.reshape(a.shape[0], a.shape[1], 3, 85)
+        want += int(((v[..., 4:5] * v[..., 5:]) >= 0.5).sum().item())
+    assert rows.shape[0] == want
+    joint = (rows[:, 4].float() * rows[:, 6].float())
+    assert bool((joint >= 0.5).all())
+    kept = tools.nms(rows, 80, 0.5)
+    assert 0 < kept.shape[0] < rows.shape[0]
+    cls = kept[:, 5]
+    assert bool((cls[1:] >= cls[:-1]).all())                       # classes ascending (utils/tools.py:730-732)
+    again = tools.nms(kept, 80, 0.5)
+    assert torch.equal(again, kept)                                  # idempotent
+    soft = tools.soft_nms(rows, 80, 0.5, 0.5, 0.5)
+    assert soft.shape[0] <= rows.shape[0]
