@@ -197,7 +197,8 @@ int yolo_bn_act_bwd_apply(const float* x, const float* dout, long long P, int C,
  *  - backward: yolo_bn_act_bwd_reduce_bound leaves in bound_aux[0..2] max|dz|, max_c|scale_c| and
  *    max_c |scale_c| (|mean(dz xhat)_c| sqrt(P) + |mean(dz)_c|), which bound dx; bound_aux holds 68 uint32,
  *    all zeroed by the caller ([3] unused, [4..67] are replica slots of max|dz|).
- * yolo_bn_act_bwd_apply_planes: dx may be NULL when only the planes are wanted. */
+ * yolo_bn_act_fwd_planes: out may be NULL, yolo_bn_act_bwd_apply_planes: dx may be NULL, when only the planes
+ * are wanted. */
 int yolo_bn_finalize_bound(double* stats, long long P, int C, const float* gamma, const float* beta, float eps,
                            float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
                            float* scale, float* shift, float* save_mean, float* save_invstd,

@@ -381,8 +381,10 @@ __global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restric
         o0 += *reinterpret_cast<const f32x4*>(res + e);
         o1 += *reinterpret_cast<const f32x4*>(res + e + 4);
       }
-      *reinterpret_cast<f32x4*>(out + e) = o0;
-      *reinterpret_cast<f32x4*>(out + e + 4) = o1;
+      if (out != nullptr) {   // (nullptr: every consumer reads the planes, the fp32 copy is not needed)
+        *reinterpret_cast<f32x4*>(out + e) = o0;
+        *reinterpret_cast<f32x4*>(out + e + 4) = o1;
+      }
     }
     if (PLANES) store_planes8(planes, p, g8, C, o0, o1, psc);
   }
@@ -594,7 +596,7 @@ extern "C" int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const 
                                       int act, const float* residual, float* out, void* planes,
                                       const unsigned* bn_bound, const float* residual_bound, float* out_bound,
                                       void* stream) {
-  YOLO_REQUIRE(x && scale && shift && out && P > 0 && C > 0, "bn_act_fwd: bad args");
+  YOLO_REQUIRE(x && scale && shift && (out || (planes && C % 8 == 0)) && P > 0 && C > 0, "bn_act_fwd: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_fwd: C=%d must be a multiple of 4", C);
   YOLO_REQUIRE(act >= 0 && act <= 2, "bn_act_fwd: bad activation %d", act);
   YOLO_REQUIRE(planes == nullptr || C % 16 == 0, "bn_act_fwd: planes output needs C %% 16 == 0 (C=%d)", C);

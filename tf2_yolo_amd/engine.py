@@ -339,6 +339,19 @@ class Network:
                 u.wTp_off, u.wTp_bytes = wp, ops.planes_bytes(u.src.c, k * k * cout)
                 wp += (u.wTp_bytes + 255) // 256 * 256
         self._wplanes = torch.empty(wp, device=self.device, dtype=torch.uint8) if wp else None
+        # fp32 copy of a BN/activation output is skipped (training) when every consumer is a conv that reads the
+        # planes for both its forward and its filter gradient
+        consumers = {}
+        for u in self.units:
+            for t in u.inputs:
+                consumers.setdefault(t.tid, []).append(u)
+        out_tids = {t.tid for t in self.outputs}
+        for u in self.units:
+            if u.kind == "conv":
+                cs = consumers.get(u.out.tid, [])
+                u.a_needed = (not cs) or (u.out.tid in out_tids) or u.cout % 16 != 0 or any(
+                    not (c.kind in ("conv", "head") and c.src.tid == u.out.tid and getattr(c, "residual", None) is not u.out
+                         and c.planes_fwd and c.planes_wgrad) for c in cs)
         self._wp_valid = False
         self._wTp_valid = False
         self._jobs_wp = self._jobs_wTp = self._jobs_wT = None
@@ -594,6 +607,7 @@ class Network:
                         self._tbound_set.add(u.out.tid)
                     tb = self._tbound
                     ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a, planes=pl,
+                                   want_out=not (training and pl is not None and not u.a_needed),
                                    bn_bound=self._aux[u.aux_off:u.aux_off + 1],
                                    residual_bound=tb[u.residual.tid:u.residual.tid + 1] if u.residual is not None else None,
                                    out_bound=tb[u.out.tid:u.out.tid + 1])

@@ -342,11 +342,16 @@ def bn_fold_inference(C, gamma, beta, moving_mean, moving_var, scale, shift, eps
 
 
 def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None, planes=None, bn_bound=None, residual_bound=None,
-               out_bound=None):
+               out_bound=None, want_out=True):
     """planes: optional uint8 buffer (planes_bytes(P, C)) that also receives the result in the conv operand format;
     it needs bn_bound (from bn_finalize) and, with a residual, residual_bound (1 float: bound of the residual
-    tensor). out_bound (1 float, optional) receives the bound of the result."""
-    if out is None:
+    tensor). out_bound (1 float, optional) receives the bound of the result. want_out=False (with planes): only the
+    planes are written."""
+    if not want_out:
+        if planes is None:
+            raise YoloHipError("bn_act_fwd: nothing to produce")
+        out = None
+    elif out is None:
         out = torch.empty_like(x)
     P = x.numel() // C
     if planes is not None and planes.numel() < planes_bytes(P, C):
