@@ -195,6 +195,37 @@ def main():
         model.net._overlap_wgrad = True
         iso = iso_timer.summary()
 
+    # Outside the timed region (rank 0, informational): BASELINE.json's second figure, the MFMA rate of the
+    # Darknet-53 training-mode FORWARD alone (convs + batch-stat BN + activations + heads, no loss / backward).
+    # conv rate = algorithmic conv FLOPs / summed conv-launch time (HIP events); whole = same FLOPs / wall time.
+    fwd = None
+    if timer is not None and rank == 0 and world == 1:
+        nf = 5
+        model.net.forward(x, training=True)
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        for _ in range(nf):
+            model.net.forward(x, training=True)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
+        f_timer = ops.KernelTimer()
+        ops.TIMER = f_timer
+        for _ in range(2):
+            model.net.forward(x, training=True)
+        torch.cuda.synchronize()
+        ops.TIMER = None
+        fa = f_timer.summary()
+        fl = sum(v["flops"] for v in fa.values()) / 2
+        kms = sum(v["ms"] for v in fa.values()) / 2
+        pk = sum(v["flops"] / 2 / kernel_peak(k) for k, v in fa.items())   # time at peak, summed per kernel
+        fwd = {"what": "training-mode forward only (batch-stat BN), bs %d, after the timed region" % args.batch,
+               "ms": round(fwd_ms, 3), "conv_gflop": round(fl / 1e9, 1), "conv_kernel_ms": round(kms, 3),
+               "conv_tflops": round(fl / kms / 1e9, 1), "conv_frac_of_peak": round(pk / 1e9 / kms, 4),
+               "whole_forward_tflops": round(fl / fwd_ms / 1e9, 1),
+               "whole_forward_frac_of_peak": round(pk / 1e9 / fwd_ms, 4),
+               "raw_fp16_mfma_tflops_conv": round(PLANES_PASSES * sum(v["flops"] for k, v in fa.items() if "planes" in k)
+                                                  / 2 / kms / 1e9, 1)}
+
     t = torch.tensor([dt], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -249,7 +280,7 @@ def main():
                                       "gradient all-reduce + Adam",
                           "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                           "parallelism": f"dp{world}", "loss": round(loss_val, 4), "replicas_in_sync": dp_in_sync},
-               "roofline": roof}
+               "roofline": roof, "forward": fwd}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (bounded sample) ...")
             try:

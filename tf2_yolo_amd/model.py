@@ -333,18 +333,57 @@ class Model:
             yb = [a[sel] for a in ys]
             yield x[sel], (yb if isinstance(y, (list, tuple)) else yb[0])
 
+    def _host_source(self, x, y, batch_size, shuffle, rng):
+        """Feeder source for host-resident data, or None when the data already lives on the device."""
+        if y is None:
+            def batches():
+                for i in range(len(x)):
+                    yield x[int(i)]
+                if hasattr(x, "on_epoch_end"):
+                    x.on_epoch_end()
+            return ("batches", batches())
+        ys = list(y) if isinstance(y, (list, tuple)) else [y]
+        if any(torch.is_tensor(a) and a.is_cuda for a in [x] + ys):
+            return None
+        n = len(x)
+        order = rng.permutation(n) if shuffle else np.arange(n)
+        return ("arrays", [x] + ys, order, batch_size)
+
     def fit(self, x=None, y=None, batch_size=None, epochs=1, verbose=1, validation_data=None, shuffle=True,
             initial_epoch=0, callbacks=None, **_):
+        """Keras-style training loop (README.md:241-297). Host arrays / Sequences are streamed through
+        `feeder.HostFeeder` (pinned staging, copy stream) and the per-batch losses stay on the device until
+        the epoch ends, so the loop never waits for the GPU; YOLO_FIT_PIPELINE=0 keeps the plain
+        batch-by-batch loop (`train_on_batch` per batch)."""
+        import os
+        from .feeder import FeederBuffers, HostFeeder
         batch_size = batch_size or 32
         rng = np.random.default_rng(0)
         hist = {"loss": []}
+        pipelined = os.environ.get("YOLO_FIT_PIPELINE", "1") != "0"
         for ep in range(initial_epoch, epochs):
             t0 = time.time()
             tot, nb = 0.0, 0
-            for xb, yb in self._iter_batches(x, y, batch_size, shuffle, rng):
-                r = self.train_on_batch(xb, yb)
-                tot += r[0] if isinstance(r, list) else r
-                nb += 1
+            src = self._host_source(x, y, batch_size, shuffle, rng) if pipelined else None
+            if src is not None:
+                if getattr(self, "_feed_bufs", None) is None:
+                    self._feed_bufs = FeederBuffers()
+                feeder = HostFeeder(src, self._feed_bufs)
+                tot_dev = torch.zeros((), dtype=torch.float64, device="cuda")
+                try:
+                    for xb, ys in feeder:
+                        bufs, _m = self.train_step_device(xb, ys)
+                        for b in bufs:
+                            tot_dev += b[0]
+                        nb += 1
+                finally:
+                    feeder.close()
+                tot = float(tot_dev.item())
+            else:
+                for xb, yb in self._iter_batches(x, y, batch_size, shuffle, rng):
+                    r = self.train_on_batch(xb, yb)
+                    tot += r[0] if isinstance(r, list) else r
+                    nb += 1
             hist["loss"].append(tot / max(nb, 1))
             msg = f"Epoch {ep + 1}/{epochs} - {time.time() - t0:.1f}s - loss: {hist['loss'][-1]:.4f}"
             if validation_data is not None:
