@@ -130,8 +130,12 @@ def main():
     dev_index = 0 if single_dev else local_rank
     torch.cuda.set_device(dev_index)
     import torch.distributed as dist
-    if world > 1:
+    # YOLO_DP_FORCE=1: initialise RCCL and run the gradient exchange in a world of ONE rank too
+    # (tests/test_gpu_dp.py: the RCCL calls, side stream and bucket views on a single GPU)
+    force_dp = os.environ.get("YOLO_DP_FORCE") == "1"
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
@@ -144,7 +148,7 @@ def main():
     yolo.create_model(pretrained_body=None, seed=1234)            # same weights on every rank
     model = yolo.model
     model.compile(optimizer=optimizers.Adam(learning_rate=1e-4), loss=yolo.loss())   # README.md:241
-    if world > 1:
+    if world > 1 or force_dp:
         model.enable_data_parallel()
 
     rng = np.random.default_rng(1234 + rank)                     # seed = 1234 + rank
@@ -232,7 +236,7 @@ def main():
     dt = float(t.item())
 
     dp_in_sync = None
-    if world > 1:   # outside the timed region: every replica must hold bit-identical weights after K steps
+    if world > 1 or force_dp:   # outside the timed region: every replica must hold bit-identical weights after K steps
         chk = model.net.params.data.double().sum().reshape(1)
         lo, hi = chk.clone(), chk.clone()
         if backend != "nccl":
@@ -289,7 +293,7 @@ def main():
                 cores = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(min(cores, 16))   # the GPU box's CPU share is 16 cores
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

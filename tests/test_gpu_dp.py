@@ -1,0 +1,53 @@
+"""The data-parallel step on the one GPU a test box has (the driver runs the real 2/4/8-GPU jobs):
+(1) RCCL in a world of ONE rank, YOLO_DP_FORCE=1: process-group init with a device id, parameter broadcast, the
+    bucketed async all-reduces on the side stream over views of the flat gradient buffer, the wait of the
+    optimizer - every RCCL call of the N > 1 job, with a loss equal to the plain single-process step;
+(2) two ranks sharing the GPU over gloo (RCCL refuses two ranks on one device): different data per rank, the
+    1/world mean, replicas bit-identical after the steps.
+bench.py is the program under test, launched the way the driver launches it."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ARGS = ["--steps", "2", "--warmup", "1", "--batch", "4", "--no-cpu-baseline", "--no-kernel-timer"]
+
+
+def _json_line(out):
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def _env(**kw):
+    env = dict(os.environ)
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", **kw)
+    return env
+
+
+def test_rccl_single_rank_runs_every_collective_of_the_dp_step():
+    plain = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, cwd=ROOT, env=_env(),
+                           capture_output=True, text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    forced = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, cwd=ROOT,
+                            env=_env(YOLO_DP_FORCE="1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"),
+                            capture_output=True, text=True, timeout=600)
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    a, b = _json_line(plain.stdout), _json_line(forced.stdout)
+    assert b["config"]["replicas_in_sync"] is True and b["n_gpus"] == 1
+    assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-3 * abs(a["config"]["loss"])
+
+
+def test_two_ranks_on_one_gpu_stay_in_sync_over_gloo():
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29543", "bench.py", "--gpus", "2"] + ARGS
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(YOLO_BENCH_SINGLE_DEVICE="1", YOLO_DIST_BACKEND="gloo"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["scaling"] == "weak"
+    assert j["config"]["replicas_in_sync"] is True

@@ -14,8 +14,16 @@ latency-bound, and the first bucket (heads + FPN) is launched within the first f
 backward. BatchNormalization statistics stay per-replica (what "bs=32/GPU" with the
 reference's plain BN means); moving statistics are not reduced.
 """
+import os
+
 import torch
 import torch.distributed as dist
+
+
+def _forced():
+    """YOLO_DP_FORCE=1: run the collectives even in a world of one rank (exercises the RCCL calls, the side
+    stream and the bucket views on a single GPU; tests/test_gpu_dp.py)."""
+    return os.environ.get("YOLO_DP_FORCE") == "1"
 
 
 def plan_buckets(segments, total, bucket_elems):
@@ -44,6 +52,7 @@ class GradReducer:
         self.flat = flat_grads
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (dist.is_initialized() and _forced())
         self.buckets, self.closes = plan_buckets(segments, flat_grads.numel(), max(bucket_bytes // 4, 1))
         self.on_gpu = flat_grads.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
@@ -53,7 +62,7 @@ class GradReducer:
         self.extra_streams = None
 
     def segment_done(self, i):
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.closes[i]:
             lo, hi = self.buckets[b]
@@ -73,7 +82,7 @@ class GradReducer:
 
     def finish(self):
         """Make the compute stream wait for every outstanding bucket. Returns 1/world."""
-        if self.world == 1:
+        if not self.active:
             return 1.0
         for w in self._works:
             w.wait()           # on GPU: stream-level wait, does not block the host
@@ -84,7 +93,7 @@ class GradReducer:
 
 
 def broadcast_parameters(tensors, src=0, process_group=None):
-    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(process_group) == 1 and not _forced()):
         return
     for t in tensors:
         dist.broadcast(t, src=src, group=process_group)
