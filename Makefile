@@ -8,6 +8,9 @@ SRCS  := $(CSRC)/runtime.hip $(CSRC)/conv.hip $(CSRC)/conv_split.hip $(CSRC)/con
 OBJS  := $(SRCS:.hip=.o)
 LIB   := tf2_yolo_amd/libyolo_hip.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -munsafe-fp-atomics -Wall -Wno-unused-function
+ifdef KNOCKOUTS   # diagnostic build: YOLO_PLANES_DBG=<bits> selects compile-time knock-outs of the planes conv loop
+HIPFLAGS += -DYOLO_PLANES_KNOCKOUTS
+endif
 
 all: $(LIB)
 

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 //   read fragments of stage kt+1 into the other register set
 //   3 MFMA passes per fragment pair on stage kt's registers, with the 2 DMAs of stage kt+3 (into stage
 //   kt's buffer) issued between them
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int DBG = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(const GatherConvArgs a) {
   constexpr int NW = WGM * WGN;
   constexpr int NT = 64 * NW;
@@ -213,13 +213,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
+          if constexpr (!(DBG & 8)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
           const int idx = (q * TM + i) * TN + j;
 #pragma unroll
           for (int d = 0; d < ND; ++d)
             if (idx == (((d + 1) * NM) / (ND + 1) > 0 ? ((d + 1) * NM) / (ND + 1) - 1 : 0)) {
               __builtin_amdgcn_sched_barrier(0);
-              issue_plane(d, wbuf);
+              if constexpr (!(DBG & 1)) issue_plane(d, wbuf);
               __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -248,8 +248,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
     if (LPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage kt's buffer are done
-    __builtin_amdgcn_s_barrier();
-    read_frags(rbuf, NXT);
+    if constexpr (!(DBG & 4)) __builtin_amdgcn_s_barrier();
+    if constexpr (!(DBG & 2)) read_frags(rbuf, NXT);
     __builtin_amdgcn_sched_barrier(0);
     mfma_stage(CUR, wbuf);
   };
@@ -307,7 +307,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
         if (cok && off >= 0) {
           float v = fmaf(acc[i][j][q], unscale, bv);
           if (a.accumulate) v += a.dst[off + col];
-          if (a.nt_store) __builtin_nontemporal_store(v, &a.dst[off + col]); else a.dst[off + col] = v;
+          if constexpr ((DBG & 16) != 0) { if (v == 1234.5678f) a.dst[off + col] = v; }
+          else if (a.nt_store) __builtin_nontemporal_store(v, &a.dst[off + col]); else a.dst[off + col] = v;
           s1 += v;
           s2 += v * v;
           mx = fmaxf(mx, fabsf(v));
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int DBG = 0>
 static int launch_planes(GatherConvArgs& a, hipStream_t st) {
   const long long tiles_m = (a.M + BM - 1) / BM;
   a.tiles_n = (a.Cout + BN - 1) / BN;
@@ -368,11 +369,11 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
   constexpr size_t lds = 3 * (BM / 32 + BN / 32) * PL_PLANES * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN, DBG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN>), dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
+  hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN, DBG>), dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
   return check_launch("gather_conv_planes_kernel");
 }
 
@@ -393,6 +394,9 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   a.zero_blk_wgt = (a.Cout + 15) / 16;
   static const int nt = [] { const char* e = getenv("YOLO_NT_STORE"); return e ? atoi(e) : 1; }();
   a.nt_store = nt;
+  // diagnostic knock-outs of the main loop (wrong results): 1 no DMA, 2 no fragment reads, 4 no barrier, 8 no MFMA, 16 no output stores
+  static const int dbg = [] { const char* e = getenv("YOLO_PLANES_DBG"); return e ? atoi(e) : 0; }();
+  a.dbg = dbg;
   // channel-block chunk of the stage order (see the kernel): YOLO_PLANES_KC overrides
   static const int kc_env = [] { const char* e = getenv("YOLO_PLANES_KC"); return e ? atoi(e) : 0; }();
   a.kc = kc_env > 0 ? kc_env : (a.Cs >> 4);
@@ -403,6 +407,21 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   if (a.Cout <= 32) return launch_planes<128, 32, 4, 1>(a, st);
   if (a.Cout <= 64) return launch_planes<128, 64, 4, 2>(a, st);
   static const int waves = [] { const char* e = getenv("YOLO_PLANES_WAVES"); return e ? atoi(e) : 4; }();
+#ifdef YOLO_PLANES_KNOCKOUTS   // diagnostic build (make KNOCKOUTS=1): compile-time knock-outs of the 128x128 4-wave kernel
+  switch (a.dbg) {
+    case 1: return launch_planes<128, 128, 2, 2, 1>(a, st);
+    case 2: return launch_planes<128, 128, 2, 2, 2>(a, st);
+    case 3: return launch_planes<128, 128, 2, 2, 3>(a, st);
+    case 7: return launch_planes<128, 128, 2, 2, 7>(a, st);
+    case 8: return launch_planes<128, 128, 2, 2, 8>(a, st);
+    case 11: return launch_planes<128, 128, 2, 2, 11>(a, st);
+    case 15: return launch_planes<128, 128, 2, 2, 15>(a, st);
+    case 16: return launch_planes<128, 128, 2, 2, 16>(a, st);
+    case 23: return launch_planes<128, 128, 2, 2, 23>(a, st);
+    case 31: return launch_planes<128, 128, 2, 2, 31>(a, st);
+    default: break;
+  }
+#endif
   if (waves == 4) return launch_planes<128, 128, 2, 2>(a, st);
   return launch_planes<128, 128, 4, 2>(a, st);
 }
