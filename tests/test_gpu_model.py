@@ -172,7 +172,7 @@ def test_model_parity(version):
     sum(ref_losses).backward()
     # float32 CPU execution of the same oracle (same forced branches): the error floor of ANY fp32
     # implementation on this instance (random-weight BN chains amplify rounding with depth: ~1e-4 for the
-    # 72-layer v3 graph, ~1e-3 for the 107-layer v4 CSP/PAN graph; scripts/debug_act_profile.py)
+    # 72-layer v3 graph, ~1e-3 for the 107-layer v4 CSP/PAN graph; scripts/act_error_profile.py)
     w32 = {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
     out32, _ = fwd(w32, torch.tensor(x), True, masks)
     losses32 = [lf(torch.tensor(yt), o) for lf, yt, o in zip(loss_o, ys, out32)]

@@ -406,6 +406,10 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   if (shape == 16 && a.Cout > 32) return launch_gather_planes16(a, st);
   if (a.Cout <= 32) return launch_planes<128, 32, 4, 1>(a, st);
   if (a.Cout <= 64) return launch_planes<128, 64, 4, 2>(a, st);
+  // few row tiles (13x13 layers at bs 32: 43): 128x128 tiles leave CUs idle (172 tiles for a 512-channel data
+  // gradient); the 128x64 tile doubles the workgroups. YOLO_PLANES_NARROW_BELOW = tile count under which it is used
+  static const int narrow_below = [] { const char* e = getenv("YOLO_PLANES_NARROW_BELOW"); return e ? atoi(e) : 0; }();
+  if (((a.M + 127) / 128) * ((a.Cout + 127) / 128) < narrow_below) return launch_planes<128, 64, 4, 2>(a, st);
   static const int waves = [] { const char* e = getenv("YOLO_PLANES_WAVES"); return e ? atoi(e) : 4; }();
 #ifdef YOLO_PLANES_KNOCKOUTS   // diagnostic build (make KNOCKOUTS=1): compile-time knock-outs of the 128x128 4-wave kernel
   switch (a.dbg) {
