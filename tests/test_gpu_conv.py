@@ -269,3 +269,42 @@ def test_conv_wgrad_planes(case):
     ops.conv2d_wgrad_planes(d, xp, dyp, dw)       # accumulates: dw += ...
     torch.cuda.synchronize()
     assert _relerr(dw.double().cpu(), 2 * _krsc(wk.grad)) < TOL
+
+
+def test_batched_filter_split_equals_per_tensor_split():
+    """yolo_split_planes_batch / yolo_filter_transpose_batch (one launch for every filter of a network) against the
+    per-tensor entry points, byte for byte: ragged row counts, a job smaller than one workgroup, and a transposed
+    filter that takes its bound from the planes of the untransposed one (same values -> same scale -> same bytes)."""
+    from tf2_yolo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    shapes = [(255, 1, 512), (64, 9, 32), (16, 1, 16), (1024, 9, 512), (33, 9, 48)]   # (cout, taps, cin)
+    ws = [torch.randn(co, t, ci, device="cuda", generator=g) * (0.01 + i) for i, (co, t, ci) in enumerate(shapes)]
+    wTs = [torch.empty(ci * t * co, device="cuda") for (co, t, ci) in shapes]
+    jt = ops.BatchJobs("transpose", "cuda")
+    for w, wT, (co, t, ci) in zip(ws, wTs, shapes):
+        jt.add_transpose(w, wT, co, t, ci)
+    jt.run()
+    for w, wT, (co, t, ci) in zip(ws, wTs, shapes):
+        assert torch.equal(wT.view(ci, t, co), w.permute(2, 1, 0).contiguous())
+    fwd = [torch.zeros(ops.planes_bytes(co, t * ci), dtype=torch.uint8, device="cuda") for (co, t, ci) in shapes]
+    js = ops.BatchJobs("split", "cuda")
+    for w, p, (co, t, ci) in zip(ws, fwd, shapes):
+        js.add_split(w, p, co, t * ci)
+    js.run()
+    def same(a, b):   # body + {bound, scale, 1/scale}; the rest of the 256-byte header is unused
+        n = a.numel() - 256 + 12
+        return torch.equal(a[:n], b[:n])
+    for w, p, (co, t, ci) in zip(ws, fwd, shapes):
+        assert same(p, ops.split_planes(w, co, t * ci)), (co, t, ci)
+    # transposed filters [cin][taps*cout] need taps*cout % 16 == 0: skip the 255- and 33-filter layers
+    sel = [i for i, (co, t, ci) in enumerate(shapes) if (t * co) % 16 == 0]
+    bwd = {i: torch.zeros(ops.planes_bytes(shapes[i][2], shapes[i][1] * shapes[i][0]), dtype=torch.uint8, device="cuda")
+           for i in sel}
+    jb = ops.BatchJobs("split", "cuda")
+    for n, i in enumerate(sel):
+        co, t, ci = shapes[i]
+        jb.add_split(wTs[i], bwd[i], ci, t * co, bound_from=fwd[i] if n % 2 == 0 else None)
+    jb.run()
+    for i in sel:
+        co, t, ci = shapes[i]
+        assert same(bwd[i], ops.split_planes(wTs[i], ci, t * co)), shapes[i]

@@ -447,7 +447,8 @@ __device__ __forceinline__ int find_job(const BatchJob* jobs, int njobs, long lo
   return lo;
 }
 
-// split job: a = rows, b = C. Three launches over the same job table: clear the bound, max |x|, split.
+// split job: a = rows, b = C, c = 0 or the header address of planes holding the same values (bound donor).
+// Three launches over the same job table: clear the bound, max |x|, split.
 __global__ void planes_header_clear_batch_kernel(const BatchJob* __restrict__ jobs, int njobs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= njobs) return;
@@ -455,17 +456,29 @@ __global__ void planes_header_clear_batch_kernel(const BatchJob* __restrict__ jo
                                                  planes_body_bytes(jobs[i].a, (int)jobs[i].b));
   header[0] = 0u;
 }
+constexpr int BATCH_UNITS = YOLO_SPLIT_BATCH_UNITS;   // 8-float units per thread of the batched amax / split kernels
 __global__ __launch_bounds__(256) void planes_amax_batch_kernel(const BatchJob* __restrict__ jobs, int njobs) {
   const BatchJob j = jobs[find_job(jobs, njobs, blockIdx.x)];
+  if (j.c != 0) return;   // the bound comes from another planes buffer of the same values (split kernel)
   const float* x = reinterpret_cast<const float*>(j.src);
-  const long long n8 = j.a * (j.b >> 3);   // the job's workgroups cover rows_padded * C/8 >= n8 threads
-  const long long t = ((long long)blockIdx.x - j.first_block) * 256 + threadIdx.x;
-  float m = 0.f;
-  if (t < n8) {
-    const f32x4 v0 = reinterpret_cast<const f32x4*>(x)[2 * t], v1 = reinterpret_cast<const f32x4*>(x)[2 * t + 1];
-    m = fmaxf(fmaxf(fmaxf(fabsf(v0[0]), fabsf(v0[1])), fmaxf(fabsf(v0[2]), fabsf(v0[3]))),
-              fmaxf(fmaxf(fabsf(v1[0]), fabsf(v1[1])), fmaxf(fabsf(v1[2]), fabsf(v1[3]))));
+  const long long n8 = j.a * (j.b >> 3);   // the job's workgroups cover rows_padded * C/8 >= n8 units
+  const long long t0 = ((long long)blockIdx.x - j.first_block) * (256 * BATCH_UNITS) + threadIdx.x;
+  f32x4 v[BATCH_UNITS][2];
+#pragma unroll
+  for (int u = 0; u < BATCH_UNITS; ++u) {
+    const long long t = t0 + u * 256;
+    v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t < n8) {
+      v[u][0] = reinterpret_cast<const f32x4*>(x)[2 * t];
+      v[u][1] = reinterpret_cast<const f32x4*>(x)[2 * t + 1];
+    }
   }
+  float m = 0.f;
+#pragma unroll
+  for (int u = 0; u < BATCH_UNITS; ++u)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+      m = fmaxf(m, fmaxf(fmaxf(fabsf(v[u][h][0]), fabsf(v[u][h][1])), fmaxf(fabsf(v[u][h][2]), fabsf(v[u][h][3]))));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0 && m > 0.f) {
@@ -482,27 +495,40 @@ __global__ __launch_bounds__(256) void split_planes_batch_kernel(const BatchJob*
   const long long rows = j.a;
   const int C = (int)j.b;
   unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
-  const float sc = planes_scale_from_bound(header[0]);
+  // c != 0: header of a planes buffer holding the same values in another order (a filter and its transpose)
+  const unsigned bound = j.c != 0 ? *reinterpret_cast<const unsigned*>(j.c) : header[0];
+  const float sc = planes_scale_from_bound(bound);
   const long long rows_padded = ((rows + 15) / 16 + 1) * 16;
   const int G = C >> 3;
-  const long long t = ((long long)blockIdx.x - j.first_block) * 256 + threadIdx.x;
-  if (t == 0) {
+  const long long t0 = ((long long)blockIdx.x - j.first_block) * (256 * BATCH_UNITS) + threadIdx.x;
+  if (t0 == 0) {
+    header[0] = bound;
     reinterpret_cast<float*>(header)[1] = sc;
     reinterpret_cast<float*>(header)[2] = 1.f / sc;
   }
-  if (t >= rows_padded * G) return;
-  const long long row = t / G;
-  const int g = (int)(t - row * G);
-  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-  if (row < rows) {
-    const float* p = x + row * C + g * 8;
-    v0 = *reinterpret_cast<const f32x4*>(p);
-    v1 = *reinterpret_cast<const f32x4*>(p + 4);
+  f32x4 v[BATCH_UNITS][2];
+  long long row[BATCH_UNITS];
+  int g[BATCH_UNITS];
+#pragma unroll
+  for (int u = 0; u < BATCH_UNITS; ++u) {
+    const long long t = t0 + u * 256;
+    row[u] = t / G;
+    g[u] = (int)(t - row[u] * G);
+    v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row[u] < rows) {
+      const float* p = x + row[u] * C + g[u] * 8;
+      v[u][0] = *reinterpret_cast<const f32x4*>(p);
+      v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
   }
-  const Planes8 s = split8(v0, v1, sc);
-  unsigned char* o = out + planes_unit_offset(row, g, C);
-  *reinterpret_cast<u32x4*>(o) = s.h;
-  *reinterpret_cast<u32x4*>(o + 512) = s.l;
+#pragma unroll
+  for (int u = 0; u < BATCH_UNITS; ++u) {
+    if (row[u] >= rows_padded) continue;
+    const Planes8 s = split8(v[u][0], v[u][1], sc);
+    unsigned char* o = out + planes_unit_offset(row[u], g[u], C);
+    *reinterpret_cast<u32x4*>(o) = s.h;
+    *reinterpret_cast<u32x4*>(o + 512) = s.l;
+  }
 }
 
 // transpose job: a = Cout, b = taps, c = Cin;  wT[ci][t][co] = w[co][t][ci]

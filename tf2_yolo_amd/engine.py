@@ -490,6 +490,7 @@ class Network:
     def _refresh_wTplanes(self):
         if self._wTp_valid or self._wplanes is None:
             return
+        self._refresh_wplanes()   # bound donors of the transposed filters
         if self._jobs_wTp is None:
             self._jobs_wTp = ops.BatchJobs("split", self.device)
             for u in self.units:
@@ -497,8 +498,10 @@ class Network:
                     cout = u.cout if u.kind == "conv" else u.out.c
                     k = u.k if u.kind == "conv" else 1
                     n = cout * k * k * u.src.c
+                    donor = self._wplanes[u.wp_off:u.wp_off + u.wp_bytes] if u.planes_fwd else None
                     self._jobs_wTp.add_split(self._wT[u.wT_off:u.wT_off + n],
-                                             self._wplanes[u.wTp_off:u.wTp_off + u.wTp_bytes], u.src.c, k * k * cout)
+                                             self._wplanes[u.wTp_off:u.wTp_off + u.wTp_bytes], u.src.c, k * k * cout,
+                                             bound_from=donor)
         self._jobs_wTp.run()
         self._wTp_valid = True
 

@@ -15,7 +15,8 @@ from ._lib import ConvDesc, LossCfg, YoloHipError, check
 BN_EPS = 1e-3       # Keras BatchNormalization default
 BN_MOMENTUM = 0.99
 BN_STAT_SLOTS = 64  # YOLO_BN_STAT_SLOTS in include/yolo_hip.h
-BN_RED_SLOTS = 512  # YOLO_BN_RED_SLOTS
+BN_RED_SLOTS = 512
+SPLIT_BATCH_UNITS = 4   # include/yolo_hip.h YOLO_SPLIT_BATCH_UNITS
 
 
 class KernelTimer:
@@ -190,9 +191,12 @@ class BatchJobs:
         self.kind, self.device = kind, device
         self.rows, self.blocks, self.table = [], 0, None
 
-    def add_split(self, src, dst, rows, c):
-        nb = -(-(((rows + 15) // 16 + 1) * 16 * (c // 8)) // 256)
-        self.rows.append([src.data_ptr(), dst.data_ptr(), rows, c, 0, self.blocks])
+    def add_split(self, src, dst, rows, c, bound_from=None):
+        """bound_from: an already split planes buffer (uint8 tensor, exact size) holding the same values in
+        another order - its bound is reused instead of a max|x| pass over `src`."""
+        nb = -(-(((rows + 15) // 16 + 1) * 16 * (c // 8)) // (256 * SPLIT_BATCH_UNITS))
+        donor = 0 if bound_from is None else bound_from.data_ptr() + bound_from.numel() - 256
+        self.rows.append([src.data_ptr(), dst.data_ptr(), rows, c, donor, self.blocks])
         self.blocks += nb
 
     def add_transpose(self, src, dst, cout, taps, cin):
