@@ -115,6 +115,11 @@ int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin
  * convolutions (forward, filter gradient) is split once. */
 size_t yolo_planes_bytes(long long rows, int C);
 int yolo_split_planes(const float* x, long long rows, int C, void* planes, void* stream);
+/* Same for a dense [rows][C_src] source whose channel count is not a multiple of 16 (the 3*(5+classes) = 255
+ * channels of a YOLOv3 head, yolov3/models/__init__.py: the gradient of the head conv's output): planes of
+ * [rows][C], C = C_src rounded up to 16, the columns past C_src are zero. The conv kernels then run with a
+ * descriptor of Cout = C and filters padded with zero rows. */
+int yolo_split_planes_padded(const float* x, long long rows, int C_src, int C, void* planes, void* stream);
 
 /* Batched forms for the filters of a whole network: ONE launch instead of one per layer. `jobs` is a device
  * array of njobs records of six int64: {source pointer, destination pointer, a, b, c, first_block};

@@ -308,3 +308,18 @@ def test_batched_filter_split_equals_per_tensor_split():
     for i in sel:
         co, t, ci = shapes[i]
         assert same(bwd[i], ops.split_planes(wTs[i], ci, t * co)), shapes[i]
+
+
+def test_split_planes_padded_equals_split_of_the_zero_padded_tensor():
+    from tf2_yolo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    for rows, c in [(5408, 255), (37, 125), (16, 1), (1000, 250)]:
+        x = torch.randn(rows, c, device="cuda", generator=g) * 3.0
+        cp = (c + 15) // 16 * 16
+        xz = torch.zeros(rows, cp, device="cuda")
+        xz[:, :c] = x
+        a, b = ops.split_planes_padded(x, rows, c), ops.split_planes(xz, rows, cp)
+        n = a.numel() - 256 + 12
+        assert a.numel() == b.numel() and torch.equal(a[:n], b[:n]), (rows, c)
+    with pytest.raises(Exception):
+        ops.split_planes_padded(torch.zeros(4, 256, device="cuda"), 4, 250)

@@ -48,6 +48,7 @@ SIGNATURES = {
     "yolo_filter_transpose": (c_int, [_P, _P, c_int, c_int, c_int, _P]),
     "yolo_planes_bytes": (c_size_t, [_LL, c_int]),
     "yolo_split_planes": (c_int, [_P, _LL, c_int, _P, _P]),
+    "yolo_split_planes_padded": (c_int, [_P, _LL, c_int, c_int, _P, _P]),
     "yolo_split_planes_batch": (c_int, [_P, c_int, _LL, _P]),
     "yolo_filter_transpose_batch": (c_int, [_P, c_int, _LL, _P]),
     "yolo_conv2d_fwd_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),

@@ -800,6 +800,11 @@ extern "C" int yolo_split_planes(const float* x, long long rows, int C, void* pl
   return launch_split_planes(x, rows, C, planes, as_stream(stream));
 }
 
+extern "C" int yolo_split_planes_padded(const float* x, long long rows, int C_src, int C, void* planes, void* stream) {
+  YOLO_REQUIRE(x && planes, "split_planes_padded: null pointer");
+  return launch_split_planes_padded(x, rows, C_src, C, planes, as_stream(stream));
+}
+
 static int dgrad_impl(const yolo_conv_desc* d, const float* dy, const float* wT, float* dx, int accumulate,
                       void* stream, bool planes) {
   if (int rc = validate_desc(d)) return rc;

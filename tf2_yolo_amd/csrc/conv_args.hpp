@@ -73,6 +73,7 @@ bool gather_split_supported(const GatherConvArgs& a);
 // conv_planes.hip
 long long planes_bytes(long long rows, int C);
 int launch_split_planes(const float* x, long long rows, int C, void* planes, hipStream_t st);
+int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, void* planes, hipStream_t st);
 int launch_split_planes_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st);

@@ -51,6 +51,47 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   *reinterpret_cast<u32x4*>(o + 512) = s.l;
 }
 
+// Dense [rows][Csrc] source with Csrc < C = Csrc rounded up to 16 (the 255-channel head gradients): scalar loads,
+// columns >= Csrc of the planes are zero.
+__global__ __launch_bounds__(256) void planes_amax_scalar_kernel(const float* __restrict__ x, long long n,
+                                                                unsigned* __restrict__ header) {
+  float m = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && __builtin_bit_cast(unsigned, m) > *reinterpret_cast<volatile unsigned*>(header))
+    atomicMax(header, __builtin_bit_cast(unsigned, m));
+}
+__global__ __launch_bounds__(256) void split_planes_padded_kernel(const float* __restrict__ x, long long rows, int Csrc,
+                                                                 int C, unsigned char* __restrict__ out,
+                                                                 long long rows_padded) {
+  unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
+  const float sc = planes_scale_from_bound(header[0]);
+  const int G = C >> 3;
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) {
+    reinterpret_cast<float*>(header)[1] = sc;
+    reinterpret_cast<float*>(header)[2] = 1.f / sc;
+  }
+  if (t >= rows_padded * G) return;
+  const long long row = t / G;
+  const int g = (int)(t - row * G);
+  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+  if (row < rows) {
+    const float* p = x + row * Csrc;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (g * 8 + j < Csrc) v0[j] = p[g * 8 + j];
+      if (g * 8 + 4 + j < Csrc) v1[j] = p[g * 8 + 4 + j];
+    }
+  }
+  const Planes8 s = split8(v0, v1, sc);
+  unsigned char* o = out + planes_unit_offset(row, g, C);
+  *reinterpret_cast<u32x4*>(o) = s.h;
+  *reinterpret_cast<u32x4*>(o + 512) = s.l;
+}
+
 // Workgroup tile BM x BN, NW = WGM*WGN waves; every wave is also the loader of ONE 32-row block of
 // A (waves 0 .. BM/32-1) or B (the rest): two DMA instructions (planes h, l) per 16-k stage.
 // Ring of 3 stage buffers in LDS + 2 fragment register sets, one barrier per stage. Iteration kt:
@@ -575,6 +616,30 @@ int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_b
   hipLaunchKernelGGL(filter_transpose_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, st,
                      reinterpret_cast<const BatchJob*>(jobs), njobs);
   return check_launch("filter_transpose_batch_kernel");
+}
+
+int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, void* planes, hipStream_t st) {
+  if (C % 16 != 0 || rows <= 0 || Csrc <= 0 || Csrc > C || C - Csrc >= 16) {
+    set_error("split_planes_padded: need 0 < Csrc <= C < Csrc + 16, C %% 16 == 0, rows > 0");
+    return YOLO_ERR_INVALID_ARG;
+  }
+  const long long rows_padded = ((rows + 15) / 16 + 1) * 16;
+  const long long blocks = (rows_padded * (C / 8) + 255) / 256;
+  if (blocks > 0x7fffffffLL) {
+    set_error("split_planes_padded: tensor too large");
+    return YOLO_ERR_INVALID_ARG;
+  }
+  unsigned char* out = reinterpret_cast<unsigned char*>(planes);
+  unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
+  if (hipMemsetAsync(header, 0, 16, st) != hipSuccess) {
+    set_error("split_planes_padded: hipMemsetAsync failed");
+    return YOLO_ERR_LAUNCH;
+  }
+  const long long n = rows * Csrc;
+  hipLaunchKernelGGL(planes_amax_scalar_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, st, x, n, header);
+  hipLaunchKernelGGL(split_planes_padded_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, rows, Csrc, C, out,
+                     rows_padded);
+  return check_launch("split_planes_padded_kernel");
 }
 
 int launch_split_planes(const float* x, long long rows, int C, void* planes, hipStream_t st) {

@@ -332,6 +332,16 @@ class Network:
             u.planes_dgrad = ops.planes_dgrad_ok(u.src.c, cout) and self._needs_grad[u.src.tid]
             u.planes_wgrad = u.planes_fwd and ops.planes_wgrad_ok(u.src.c, cout, k * k, u.stride if u.kind == "conv" else 1)
             u.wp_off = u.wTp_off = -1
+            # heads whose channel count is not a multiple of 16 (YOLOv3: 255): the backward kernels run on the
+            # channel count rounded up to 16 - head gradient planes with zero columns, filters with zero rows
+            u.cpad = 0
+            if (u.kind == "head" and cout % 16 != 0 and not u.planes_dgrad
+                    and os.environ.get("YOLO_HEAD_PAD", "1") != "0"):
+                cp = (cout + 15) // 16 * 16
+                if u.planes_fwd and ops.planes_wgrad_ok(u.src.c, cp, 1) and ops.planes_dgrad_ok(u.src.c, cp):
+                    u.cpad = cp
+                    u.wTp_pad_off, u.wTp_pad_bytes = wp, ops.planes_bytes(u.src.c, cp)
+                    wp += (u.wTp_pad_bytes + 255) // 256 * 256
             if u.planes_fwd:
                 u.wp_off, u.wp_bytes = wp, ops.planes_bytes(cout, k * k * u.src.c)
                 wp += (u.wp_bytes + 255) // 256 * 256
@@ -339,6 +349,12 @@ class Network:
                 u.wTp_off, u.wTp_bytes = wp, ops.planes_bytes(u.src.c, k * k * cout)
                 wp += (u.wTp_bytes + 255) // 256 * 256
         self._wplanes = torch.empty(wp, device=self.device, dtype=torch.uint8) if wp else None
+        for u in self.units:
+            if u.kind == "head" and u.cpad:
+                n = u.cpad * u.src.c
+                u.w_pad = torch.zeros(n, device=self.device, dtype=torch.float32)    # [cpad][cin], zero rows past out.c
+                u.wT_pad = torch.empty(n, device=self.device, dtype=torch.float32)   # [cin][cpad]
+                u.dw_pad = torch.empty(n, device=self.device, dtype=torch.float32)   # filter-gradient scratch
         # fp32 copy of a BN/activation output is skipped (training) when every consumer is a conv that reads the
         # planes for both its forward and its filter gradient
         consumers = {}
@@ -456,7 +472,10 @@ class Network:
             if u.planes_fwd and u.src.tid not in self._xplanes:
                 self._xplanes[u.src.tid] = torch.zeros(ops.planes_bytes(N * u.src.h * u.src.w, u.src.c), device=dev,
                                                        dtype=torch.uint8)
-            if u.planes_dgrad or u.planes_wgrad:
+            if u.kind == "head" and u.cpad:
+                dyp = max(dyp, ops.planes_bytes(N * u.out.h * u.out.w, u.cpad))
+                u.desc_pad = ops.conv_desc((N, u.src.h, u.src.w, u.src.c), u.cpad, 1, 1, 1, "same")
+            elif u.planes_dgrad or u.planes_wgrad:
                 dyp = max(dyp, ops.planes_bytes(N * u.out.h * u.out.w, u.cout if u.kind == "conv" else u.out.c))
         # (two scratch buffers, used alternately: the filter gradient of layer L may still be reading its dy
         # planes on the second stream while layer L-1 produces its own)
@@ -494,7 +513,10 @@ class Network:
         if self._jobs_wTp is None:
             self._jobs_wTp = ops.BatchJobs("split", self.device)
             for u in self.units:
-                if u.kind in ("conv", "head") and u.planes_dgrad:
+                if u.kind == "head" and u.cpad:
+                    self._jobs_wTp.add_split(u.wT_pad, self._wplanes[u.wTp_pad_off:u.wTp_pad_off + u.wTp_pad_bytes],
+                                             u.src.c, u.cpad)
+                elif u.kind in ("conv", "head") and u.planes_dgrad:
                     cout = u.cout if u.kind == "conv" else u.out.c
                     k = u.k if u.kind == "conv" else 1
                     n = cout * k * k * u.src.c
@@ -661,12 +683,17 @@ class Network:
         if self._jobs_wT is None:
             self._jobs_wT = ops.BatchJobs("transpose", self.device)
             for u in self.units:
-                if u.kind in ("conv", "head"):
+                if u.kind == "head" and u.cpad:
+                    self._jobs_wT.add_transpose(u.w_pad, u.wT_pad, u.cpad, 1, u.src.c)
+                elif u.kind in ("conv", "head"):
                     cout = u.cout if u.kind == "conv" else u.out.c
                     taps = u.k * u.k if u.kind == "conv" else 1
                     n = cout * taps * u.src.c
                     self._jobs_wT.add_transpose(self.params.view(u.p_kernel.name), self._wT[u.wT_off:u.wT_off + n],
                                                 cout, taps, u.src.c)
+        for u in self.units:
+            if u.kind == "head" and u.cpad:
+                u.w_pad[:u.out.c * u.src.c].copy_(self.params.view(u.p_kernel.name).reshape(-1))
         self._jobs_wT.run()
         self._wT_valid = True
 
@@ -719,6 +746,24 @@ class Network:
                 xin = self.act[u.src.tid]
                 dt = ops.head_act_bwd(u.yact, dout, u.A, u.C, u.version, self._anchors_dev.get(u.name),
                                       danchors=self._anchor_grad_views.get(u.name) if self.anchors_trainable else None)
+                if u.cpad:
+                    rows = N * u.out.h * u.out.w
+                    dtp = ops.split_planes_padded(dt, rows, u.out.c, out=self._next_dyp_buffer())
+                    with self._beside_backward(dt):
+                        u.dw_pad.zero_()
+                        ops.conv2d_wgrad_planes(u.desc_pad, self._xplanes[u.src.tid], dtp, u.dw_pad)
+                        self._gview(u.p_kernel).add_(u.dw_pad[:u.out.c * u.src.c])
+                        ops.conv2d_wgrad_bias(dt, rows, u.out.c, self._gview(u.p_bias))
+                    if self._needs_grad[u.src.tid]:
+                        wTp = self._wplanes[u.wTp_pad_off:u.wTp_pad_off + u.wTp_pad_bytes]
+                        cur = grads.get(u.src.tid)
+                        if cur is None:
+                            grads[u.src.tid] = ops.conv2d_dgrad_planes(u.desc_pad, dtp, wTp)
+                        else:
+                            ops.conv2d_dgrad_planes(u.desc_pad, dtp, wTp, dx=cur, accumulate=True)
+                    if self.grad_ready_hook is not None:
+                        self.grad_ready_hook(u)
+                    continue
                 dtp = self._dyp(u, dt)
                 with self._beside_backward(dt):
                     if u.planes_wgrad:

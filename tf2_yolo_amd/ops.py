@@ -184,6 +184,23 @@ def split_planes(x, rows, c, out=None):
     return out
 
 
+def split_planes_padded(x, rows, c_src, out=None):
+    """fp32 [rows][c_src], c_src % 16 != 0 -> planes of [rows][ceil16(c_src)], zero columns past c_src
+    (include/yolo_hip.h: yolo_split_planes_padded)"""
+    _chk_f32(x)
+    c = (c_src + 15) // 16 * 16
+    if x.numel() != rows * c_src:
+        raise YoloHipError("split_planes_padded: tensor size does not match rows x C_src")
+    n = planes_bytes(rows, c)
+    if out is None:
+        out = torch.empty(n, device=x.device, dtype=torch.uint8)
+    elif out.numel() < n or out.dtype != torch.uint8:
+        raise YoloHipError("split_planes_padded: output buffer too small")
+    check(_lib.load().yolo_split_planes_padded(_p(x), int(rows), int(c_src), int(c), _p(out), _stream()),
+          "yolo_split_planes_padded")
+    return out
+
+
 class BatchJobs:
     """Device job table for yolo_split_planes_batch / yolo_filter_transpose_batch (built once, re-run every step)."""
 
@@ -270,6 +287,15 @@ def conv2d_wgrad_planes(d, xp, dyp, dw, dy=None, dbias=None):
         check(_lib.load().yolo_conv2d_wgrad_bias(_p(dy), d.N * d.Ho * d.Wo, d.Cout, _p(dbias), _stream()),
               "yolo_conv2d_wgrad_bias")
     return dw
+
+
+def conv2d_wgrad_bias(dy, rows, c, dbias):
+    """dbias += column sums of the fp32 dy [rows][c] (include/yolo_hip.h: yolo_conv2d_wgrad_bias)"""
+    _chk_f32(dy, dbias)
+    if dy.numel() != rows * c or dbias.numel() != c:
+        raise YoloHipError("conv2d_wgrad_bias: sizes do not match")
+    check(_lib.load().yolo_conv2d_wgrad_bias(_p(dy), int(rows), int(c), _p(dbias), _stream()), "yolo_conv2d_wgrad_bias")
+    return dbias
 
 
 def filter_transpose(w, cout, taps, cin, out=None):
