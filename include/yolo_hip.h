@@ -74,7 +74,7 @@ typedef struct yolo_conv_desc {
  * results of [2*C] doubles (every workgroup stores its own slot: no atomics, no zeroing needed) followed by
  * the final [2*C] sums: (YOLO_BN_RED_SLOTS + 1) * 2 * C doubles. */
 #define YOLO_BN_RED_SLOTS 512
-#define YOLO_SPLIT_BATCH_UNITS 4   /* 8-float units per thread of yolo_split_planes_batch */
+#define YOLO_SPLIT_BATCH_UNITS 4   /* 16-row blocks per workgroup of yolo_split_planes_batch */
 
 /* y = conv(x, w) (+ bias if bias != NULL). If stats != NULL (double[YOLO_BN_STAT_SLOTS][2*Cout],
  * zeroed by the caller) the epilogue also accumulates per-channel sum / sum-of-squares of y for
@@ -127,7 +127,8 @@ int yolo_split_planes_padded(const float* x, long long rows, int C_src, int C, v
  * split job:     a = rows, b = C, c = 0, or the address of the HEADER (buffer + yolo_planes_bytes - 256) of an
  *                already split planes buffer holding the same values in another order (a filter and its
  *                transpose): its bound is reused and the max|x| pass skipped;
- *                workgroups = ceil(((ceil(rows/16)+1)*16 * C/8) / (256 * YOLO_SPLIT_BATCH_UNITS))
+ *                workgroups = ceil((ceil(rows/16)+1) / YOLO_SPLIT_BATCH_UNITS) * ceil(C / 128)
+ *                (a workgroup covers YOLO_SPLIT_BATCH_UNITS 16-row blocks x 128 channels)
  * transpose job: a = Cout, b = taps, c = Cin;  workgroups = ceil(Cin/32) * ceil(Cout/32) * taps */
 int yolo_split_planes_batch(const void* jobs, int njobs, long long total_blocks, void* stream);
 int yolo_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, void* stream);

@@ -497,21 +497,42 @@ __global__ void planes_header_clear_batch_kernel(const BatchJob* __restrict__ jo
                                                  planes_body_bytes(jobs[i].a, (int)jobs[i].b));
   header[0] = 0u;
 }
-constexpr int BATCH_UNITS = YOLO_SPLIT_BATCH_UNITS;   // 8-float units per thread of the batched amax / split kernels
+// Workgroup = YOLO_SPLIT_BATCH_UNITS consecutive 16-row blocks x 16 channel groups (128 channels): thread
+// (r = tid & 15, gg = tid >> 4) reads 32 B of row r next to its neighbour groups' (128-B lines per row) and
+// writes its two 16-B units next to the other 15 rows' (256-B sub-blocks): both sides move whole lines.
+constexpr int BATCH_UNITS = YOLO_SPLIT_BATCH_UNITS;
+struct BatchPos {
+  long long row0;   // first row of this thread (+16 per unit)
+  int g;            // 8-channel group
+  bool live;
+};
+__device__ __forceinline__ BatchPos batch_pos(const BatchJob& j) {
+  const int G = (int)j.b >> 3;
+  const int gbn = (G + 15) >> 4;
+  const long long lb = (long long)blockIdx.x - j.first_block;
+  const long long rb = lb / gbn;
+  const int gb = (int)(lb - rb * gbn);
+  BatchPos p;
+  p.g = gb * 16 + (threadIdx.x >> 4);
+  p.row0 = rb * (16 * BATCH_UNITS) + (threadIdx.x & 15);
+  p.live = p.g < G;
+  return p;
+}
 __global__ __launch_bounds__(256) void planes_amax_batch_kernel(const BatchJob* __restrict__ jobs, int njobs) {
   const BatchJob j = jobs[find_job(jobs, njobs, blockIdx.x)];
   if (j.c != 0) return;   // the bound comes from another planes buffer of the same values (split kernel)
   const float* x = reinterpret_cast<const float*>(j.src);
-  const long long n8 = j.a * (j.b >> 3);   // the job's workgroups cover rows_padded * C/8 >= n8 units
-  const long long t0 = ((long long)blockIdx.x - j.first_block) * (256 * BATCH_UNITS) + threadIdx.x;
+  const BatchPos p = batch_pos(j);
+  const int C = (int)j.b;
   f32x4 v[BATCH_UNITS][2];
 #pragma unroll
   for (int u = 0; u < BATCH_UNITS; ++u) {
-    const long long t = t0 + u * 256;
+    const long long row = p.row0 + 16 * u;
     v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (t < n8) {
-      v[u][0] = reinterpret_cast<const f32x4*>(x)[2 * t];
-      v[u][1] = reinterpret_cast<const f32x4*>(x)[2 * t + 1];
+    if (p.live && row < j.a) {
+      const float* q = x + row * C + p.g * 8;
+      v[u][0] = *reinterpret_cast<const f32x4*>(q);
+      v[u][1] = *reinterpret_cast<const f32x4*>(q + 4);
     }
   }
   float m = 0.f;
@@ -540,35 +561,32 @@ __global__ __launch_bounds__(256) void split_planes_batch_kernel(const BatchJob*
   const unsigned bound = j.c != 0 ? *reinterpret_cast<const unsigned*>(j.c) : header[0];
   const float sc = planes_scale_from_bound(bound);
   const long long rows_padded = ((rows + 15) / 16 + 1) * 16;
-  const int G = C >> 3;
-  const long long t0 = ((long long)blockIdx.x - j.first_block) * (256 * BATCH_UNITS) + threadIdx.x;
-  if (t0 == 0) {
+  if ((long long)blockIdx.x == j.first_block && threadIdx.x == 0) {
     header[0] = bound;
     reinterpret_cast<float*>(header)[1] = sc;
     reinterpret_cast<float*>(header)[2] = 1.f / sc;
   }
+  const BatchPos p = batch_pos(j);
+  if (!p.live) return;
   f32x4 v[BATCH_UNITS][2];
-  long long row[BATCH_UNITS];
-  int g[BATCH_UNITS];
 #pragma unroll
   for (int u = 0; u < BATCH_UNITS; ++u) {
-    const long long t = t0 + u * 256;
-    row[u] = t / G;
-    g[u] = (int)(t - row[u] * G);
+    const long long row = p.row0 + 16 * u;
     v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row[u] < rows) {
-      const float* p = x + row[u] * C + g[u] * 8;
-      v[u][0] = *reinterpret_cast<const f32x4*>(p);
-      v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    if (row < rows) {
+      const float* q = x + row * C + p.g * 8;
+      v[u][0] = *reinterpret_cast<const f32x4*>(q);
+      v[u][1] = *reinterpret_cast<const f32x4*>(q + 4);
     }
   }
 #pragma unroll
   for (int u = 0; u < BATCH_UNITS; ++u) {
-    if (row[u] >= rows_padded) continue;
-    const Planes8 s = split8(v[u][0], v[u][1], sc);
-    unsigned char* o = out + planes_unit_offset(row[u], g[u], C);
-    *reinterpret_cast<u32x4*>(o) = s.h;
-    *reinterpret_cast<u32x4*>(o + 512) = s.l;
+    const long long row = p.row0 + 16 * u;
+    if (row >= rows_padded) continue;
+    const Planes8 s8 = split8(v[u][0], v[u][1], sc);
+    unsigned char* o = out + planes_unit_offset(row, p.g, C);
+    *reinterpret_cast<u32x4*>(o) = s8.h;
+    *reinterpret_cast<u32x4*>(o + 512) = s8.l;
   }
 }
 
@@ -635,8 +653,10 @@ int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, 
     set_error("split_planes_padded: hipMemsetAsync failed");
     return YOLO_ERR_LAUNCH;
   }
-  const long long n = rows * Csrc;
-  hipLaunchKernelGGL(planes_amax_scalar_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, st, x, n, header);
+  const long long n = rows * Csrc, n4 = n / 4;   // the dense source is read as float4 up to its last 0-3 values
+  if (n4 > 0) hipLaunchKernelGGL(planes_amax_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, st, x, n4, header);
+  if (n > 4 * n4)
+    hipLaunchKernelGGL(planes_amax_scalar_kernel, dim3(1), dim3(256), 0, st, x + 4 * n4, n - 4 * n4, header);
   hipLaunchKernelGGL(split_planes_padded_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, rows, Csrc, C, out,
                      rows_padded);
   return check_launch("split_planes_padded_kernel");

@@ -211,7 +211,7 @@ class BatchJobs:
     def add_split(self, src, dst, rows, c, bound_from=None):
         """bound_from: an already split planes buffer (uint8 tensor, exact size) holding the same values in
         another order - its bound is reused instead of a max|x| pass over `src`."""
-        nb = -(-(((rows + 15) // 16 + 1) * 16 * (c // 8)) // (256 * SPLIT_BATCH_UNITS))
+        nb = -(-((rows + 15) // 16 + 1) // SPLIT_BATCH_UNITS) * -(-c // 128)
         donor = 0 if bound_from is None else bound_from.data_ptr() + bound_from.numel() - 256
         self.rows.append([src.data_ptr(), dst.data_ptr(), rows, c, donor, self.blocks])
         self.blocks += nb
