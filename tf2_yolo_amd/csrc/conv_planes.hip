@@ -26,29 +26,42 @@ __global__ __launch_bounds__(256) void planes_amax_kernel(const float* __restric
 
 // pass 2: one thread = (row, 8-channel group); adjacent lanes read adjacent 32-byte pieces of a row.
 // Also zero-fills the rows past the end + the zero block and completes the header (scale, 1/scale).
+// Workgroup = 4 consecutive 16-row blocks x 16 channel groups (see the batched form below for why).
+constexpr int SPLIT_BLOCKS_PER_WG = 4;
 __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, long long rows, int C,
                                                           unsigned char* __restrict__ out, long long rows_padded) {
   unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
   const float sc = planes_scale_from_bound(header[0]);
   const int G = C >> 3;
-  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (t == 0) {
+  const int gbn = (G + 15) >> 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     reinterpret_cast<float*>(header)[1] = sc;
     reinterpret_cast<float*>(header)[2] = 1.f / sc;
   }
-  if (t >= rows_padded * G) return;
-  const long long row = t / G;
-  const int g = (int)(t - row * G);
-  f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
-  if (row < rows) {
-    const float* p = x + row * C + g * 8;
-    v0 = *reinterpret_cast<const f32x4*>(p);
-    v1 = *reinterpret_cast<const f32x4*>(p + 4);
+  const long long rb = blockIdx.x / gbn;
+  const int g = (int)(blockIdx.x - rb * gbn) * 16 + (threadIdx.x >> 4);
+  if (g >= G) return;
+  const long long row0 = rb * (16 * SPLIT_BLOCKS_PER_WG) + (threadIdx.x & 15);
+  f32x4 v[SPLIT_BLOCKS_PER_WG][2];
+#pragma unroll
+  for (int u = 0; u < SPLIT_BLOCKS_PER_WG; ++u) {
+    const long long row = row0 + 16 * u;
+    v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+      const float* p = x + row * C + g * 8;
+      v[u][0] = *reinterpret_cast<const f32x4*>(p);
+      v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
   }
-  const Planes8 s = split8(v0, v1, sc);
-  unsigned char* o = out + planes_unit_offset(row, g, C);
-  *reinterpret_cast<u32x4*>(o) = s.h;
-  *reinterpret_cast<u32x4*>(o + 512) = s.l;
+#pragma unroll
+  for (int u = 0; u < SPLIT_BLOCKS_PER_WG; ++u) {
+    const long long row = row0 + 16 * u;
+    if (row >= rows_padded) continue;
+    const Planes8 s = split8(v[u][0], v[u][1], sc);
+    unsigned char* o = out + planes_unit_offset(row, g, C);
+    *reinterpret_cast<u32x4*>(o) = s.h;
+    *reinterpret_cast<u32x4*>(o + 512) = s.l;
+  }
 }
 
 // Dense [rows][Csrc] source with Csrc < C = Csrc rounded up to 16 (the 255-channel head gradients): scalar loads,
@@ -668,8 +681,7 @@ int launch_split_planes(const float* x, long long rows, int C, void* planes, hip
     return YOLO_ERR_INVALID_ARG;
   }
   const long long rows_padded = ((rows + 15) / 16 + 1) * 16;
-  const long long threads = rows_padded * (C / 8);
-  const long long blocks = (threads + 255) / 256;
+  const long long blocks = ((rows_padded / 16 + SPLIT_BLOCKS_PER_WG - 1) / SPLIT_BLOCKS_PER_WG) * ((C / 8 + 15) / 16);
   if (blocks > 0x7fffffffLL) {
     set_error("split_planes: tensor too large");
     return YOLO_ERR_INVALID_ARG;
