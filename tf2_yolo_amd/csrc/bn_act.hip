@@ -417,7 +417,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
                                                             const float* __restrict__ sinv, int act,
                                                             const double* __restrict__ red, float* __restrict__ dx,
                                                             unsigned char* __restrict__ planes,
-                                                            const unsigned* __restrict__ aux) {
+                                                            const unsigned* __restrict__ aux,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // |dx| <= max_c|scale_c| * max|dz| + max_c |scale_c| (|mean(dz xhat)| sqrt(P) + |mean(dz)|): aux = {max|dz|,
   // max|scale|, max of the second term} from the reduce / sum kernels
@@ -441,6 +442,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
     const float mdzx = (float)(red[C + c] * invP);
     cb[k] = -sc[k] * sinv[c] * mdzx;
     ck[k] = -sc[k] * mdz;
+    // the parameter gradients are the channel sums themselves (dbeta = sum dz, dgamma = sum dz xhat): the first
+    // row-slot of the first workgroup along the rows adds them (one lane per 8-channel group) - no extra launch
+    if (blockIdx.x == 0 && wave / wpr == 0 && (lane & 15) == 0) {
+      if (dbeta != nullptr) dbeta[c] += (float)red[c];
+      if (dgamma != nullptr) dgamma[c] += (float)red[C + c];
+    }
   }
   const long long rb_lo = (long long)blockIdx.x * blocks_per_wg;
   long long p_hi = (rb_lo + blocks_per_wg) * 16;
@@ -686,11 +693,12 @@ extern "C" int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, l
 #define YOLO_BWD8(PL, DX)                                                                                            \
   hipLaunchKernelGGL((bn_bwd_apply8_kernel<PL, DX>), dim3(g.gx, g.gy), dim3(256), 0, st, x, dout, P, C, g.wpr,       \
                      g.blocks_per_wg, rows, 1.0 / (double)P, scale, shift, save_mean, save_invstd, act, redsum, dx, pl,  \
-                     bound_aux)
+                     bound_aux, dgamma, dbeta)
     if (planes && dx) YOLO_BWD8(true, true);
     else if (planes) YOLO_BWD8(true, false);
     else YOLO_BWD8(false, true);
 #undef YOLO_BWD8
+    return check_launch("bn_bwd_apply8_kernel");   // (dgamma / dbeta are added by the kernel itself)
   } else {
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(stream_grid(n4, 256)), dim3(256), 0, st, x, dout, n4, C / 4,
                        1.0 / (double)P, scale, shift, save_mean, save_invstd, act, redsum, dx);
