@@ -24,6 +24,7 @@ CASES = [
     (3, 9, 11, 256, 128, 1, 1, "valid", False),
     (1, 13, 13, 64, 125, 1, 1, "same", True),       # v2 head width
     (1, 5, 5, 1024, 11, 1, 1, "same", True),        # v1 head (tiny Cout)
+    (3, 21, 19, 3, 32, 3, 1, "same", True),         # stem (direct kernel, csrc/stem.hip): odd sizes, batch, bias
 ]
 
 
@@ -104,7 +105,7 @@ def test_conv_rejects_bad_descriptor():
         ops.conv2d_fwd(d, x, w)
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[4], CASES[5], CASES[8]])
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[4], CASES[5], CASES[8], CASES[12]])
 def test_conv_fused_bn_statistics(case):
     """epilogue-fused per-channel sum / sum of squares (training-mode BN) vs the oracle's conv output"""
     from tf2_yolo_amd import ops

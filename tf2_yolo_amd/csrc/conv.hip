@@ -747,6 +747,7 @@ extern "C" int yolo_conv2d_fwd_absmax(const yolo_conv_desc* d, const float* x, c
                                       float* y, double* stats, unsigned* absmax, void* stream) {
   if (int rc = validate_desc(d)) return rc;
   YOLO_REQUIRE(x && w && y, "conv_fwd: null pointer");
+  if (g_conv_mode == 1 && stem_fwd_supported(d)) return launch_stem_fwd(d, x, w, bias, y, stats, absmax, as_stream(stream));
   GatherConvArgs a{};
   a.src = x;
   a.wgt = w;

@@ -82,6 +82,10 @@ bool gather_planes_supported(const GatherConvArgs& a);
 // conv_wgrad_planes.hip
 int launch_wgrad_planes(WgradArgs& a, hipStream_t st);
 bool wgrad_planes_supported(const WgradArgs& a);
+// stem.hip (direct fp32 kernel for the 3-channel 3x3 stem)
+bool stem_fwd_supported(const yolo_conv_desc* d);
+int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y, double* stats,
+                    unsigned* absmax, hipStream_t st);
 // conv_wgrad_split.hip
 int launch_wgrad_split(WgradArgs& a, hipStream_t st);
 bool wgrad_split_supported(const WgradArgs& a);

@@ -1,0 +1,177 @@
+// The RGB stem: Conv2D(32, 3, padding="same") on the 3-channel image, the first layer of every Darknet body
+// (yolov3/models/backbone.py:60, yolov4/models/backbone.py:127, yolov2/models/backbone.py:44).
+// K = 27 and a 32-channel output at full resolution make it a WRITE-bound layer (bs 32 at 416x416: 66 MB in,
+// 709 MB out, 9.6 GFLOP): the implicit-GEMM kernels spend their time on 27-wide gathers, so the stem gets a
+// direct fp32 kernel - one pixel per lane, the 27 x 32 filter broadcast from LDS, exact fp32 FMA chains, the
+// BatchNorm statistics of the output accumulated on the way.
+#include "common.hpp"
+#include "conv_args.hpp"
+
+namespace yolo {
+
+constexpr int STEM_CO = 32;
+constexpr int STEM_K = 27;
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ y,
+                                                          double* __restrict__ stats, unsigned* __restrict__ absmax,
+                                                          int H, int W, int pad_t, int pad_l, int M) {
+  __shared__ __attribute__((aligned(16))) float w_s[STEM_K + 1][STEM_CO];   // [j = (r*3+s)*3+ci][co]; row 27 = bias
+  for (int i = threadIdx.x; i < STEM_K * STEM_CO; i += 256) w_s[i % STEM_K][i / STEM_K] = w[i];   // w: [co][j]
+  if (threadIdx.x < STEM_CO) w_s[STEM_K][threadIdx.x] = bias != nullptr ? bias[threadIdx.x] : 0.f;
+  __shared__ __attribute__((aligned(16))) float t_s[4][64 * STEM_CO];   // per-wave output staging (8 KB each)
+  __syncthreads();
+  float s1[STATS ? STEM_CO : 1], s2[STATS ? STEM_CO : 1], mx[STATS ? STEM_CO : 1];
+  if (STATS) {
+#pragma unroll
+    for (int c = 0; c < STEM_CO; ++c) s1[c] = s2[c] = mx[c] = 0.f;
+  }
+  const int HW = H * W;
+  const int stride = gridDim.x * 256;
+  // whole waves iterate together (the output staging is per wave): lanes past the end compute pixel M-1 again
+  // and are masked at the store / statistics
+  for (int pb = blockIdx.x * 256 + (threadIdx.x & ~63); pb < M; pb += stride) {
+    const int p_raw = pb + (threadIdx.x & 63);
+    const bool live = p_raw < M;
+    const int p = p_raw;
+    const int pc = live ? p_raw : M - 1;
+    const int n = pc / HW;
+    const int rem = pc - n * HW;
+    const int yy = rem / W;
+    const int xx = rem - yy * W;
+    float patch[STEM_K];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const int iy = yy + r - pad_t, ix = xx + s - pad_l;
+        const bool ok = ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+        const float* q = x + ((long long)(n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float v = q[c];
+          patch[(r * 3 + s) * 3 + c] = ok ? v : 0.f;
+        }
+      }
+    // (the filter is re-read from LDS for every pixel: without the clobber hipcc hoists all 864 values out of
+    // the pixel loop and spills them)
+    asm volatile("" ::: "memory");
+    // packed fp32 FMAs (v_pk_fma_f32: two channels per lane and instruction): the 864 FMAs per pixel are the
+    // kernel's critical resource
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc2[STEM_CO / 2];
+#pragma unroll
+    for (int c4 = 0; c4 < STEM_CO / 4; ++c4) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(&w_s[STEM_K][c4 * 4]);
+      acc2[2 * c4] = f32x2{bv[0], bv[1]};
+      acc2[2 * c4 + 1] = f32x2{bv[2], bv[3]};
+    }
+#pragma unroll
+    for (int j = 0; j < STEM_K; ++j) {
+      const f32x2 pj = {patch[j], patch[j]};
+#pragma unroll
+      for (int c4 = 0; c4 < STEM_CO / 4; ++c4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(&w_s[j][c4 * 4]);   // same address in every lane: broadcast
+        acc2[2 * c4] = __builtin_elementwise_fma(pj, f32x2{wv[0], wv[1]}, acc2[2 * c4]);
+        acc2[2 * c4 + 1] = __builtin_elementwise_fma(pj, f32x2{wv[2], wv[3]}, acc2[2 * c4 + 1]);
+      }
+    }
+    float acc[STEM_CO];
+#pragma unroll
+    for (int c = 0; c < STEM_CO; ++c) acc[c] = acc2[c >> 1][c & 1];
+    // transpose through LDS so that one store instruction writes 1 KB of consecutive output (8 pixels x 128 B):
+    // a lane writing its own pixel's 128 B would issue 64 partial lines per instruction
+    {
+      float* t = &t_s[threadIdx.x >> 6][0];
+      const int lane = threadIdx.x & 63;
+#pragma unroll
+      for (int c4 = 0; c4 < STEM_CO / 4; ++c4) {
+        const f32x4 v = {acc[c4 * 4], acc[c4 * 4 + 1], acc[c4 * 4 + 2], acc[c4 * 4 + 3]};
+        // pixel-major rows of 32 floats, 16-byte units rotated by the pixel so that the 64 lanes' writes spread over the banks
+        *reinterpret_cast<f32x4*>(t + lane * STEM_CO + (((c4 + lane) & 7) << 2)) = v;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its own LDS writes are visible to itself)
+      const int p0 = p - lane;                    // first pixel of this wave's 64 (consecutive: p = base + lane)
+      const int valid = M - p0 < 64 ? M - p0 : 64;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int px = i * 8 + (lane >> 3), c4 = lane & 7;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(t + px * STEM_CO + (((c4 + px) & 7) << 2));
+        if (px < valid)
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(y + (long long)(p0 + px) * STEM_CO + c4 * 4));
+      }
+    }
+    if (STATS && live) {
+#pragma unroll
+      for (int c = 0; c < STEM_CO; ++c) {
+        s1[c] += acc[c];
+        s2[c] = fmaf(acc[c], acc[c], s2[c]);
+        mx[c] = fmaxf(mx[c], fabsf(acc[c]));
+      }
+    }
+  }
+  if (STATS) {
+    // per-wave totals of this wave's pixels (~40 per lane), then one fp64 atomic per channel and wave into the
+    // replica slot of the workgroup (YOLO_BN_STAT_SLOTS, as the implicit-GEMM epilogues do)
+    const int lane = threadIdx.x & 63;
+    double* slot = stats != nullptr ? stats + (long long)(blockIdx.x & (YOLO_BN_STAT_SLOTS - 1)) * 2 * STEM_CO : nullptr;
+#pragma unroll
+    for (int c = 0; c < STEM_CO; ++c) {
+      float a1 = s1[c], a2 = s2[c], am = mx[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        a1 += __shfl_xor(a1, o, 64);
+        a2 += __shfl_xor(a2, o, 64);
+        am = fmaxf(am, __shfl_xor(am, o, 64));
+      }
+      if (lane == 0) {
+        if (slot != nullptr) {
+          atomicAdd(&slot[c], (double)a1);
+          atomicAdd(&slot[STEM_CO + c], (double)a2);
+        }
+        if (absmax != nullptr && __builtin_bit_cast(unsigned, am) > absmax[c])
+          atomicMax(&absmax[c], __builtin_bit_cast(unsigned, am));
+      }
+    }
+  }
+}
+
+bool stem_fwd_supported(const yolo_conv_desc* d) {
+  static const bool on = [] { const char* e = getenv("YOLO_STEM_DIRECT"); return !(e && atoi(e) == 0); }();
+  return on && d->Cin == 3 && d->Cout == STEM_CO && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 &&
+         d->Ho == d->H && d->Wo == d->W && (long long)d->N * d->H * d->W < (1LL << 31) - (1 << 20);
+}
+
+int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y, double* stats,
+                    unsigned* absmax, hipStream_t st) {
+  const int M = d->N * d->H * d->W;
+  const bool st_on = stats != nullptr || absmax != nullptr;
+  // one resident round: every lane walks M / (grid * 256) pixels (a second, partial round would idle most CUs)
+  static int per_cu[2] = {0, 0};
+  if (per_cu[st_on] == 0) {
+    int n = 0;
+    const void* fn = st_on ? reinterpret_cast<const void*>(&stem_conv3x3_kernel<true>)
+                           : reinterpret_cast<const void*>(&stem_conv3x3_kernel<false>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, 0) != hipSuccess || n < 1) n = 2;
+    per_cu[st_on] = n;
+  }
+  int cus = 256;
+  {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+      cus = prop.multiProcessorCount;
+  }
+  int grid = (M + 255) / 256;
+  if (grid > per_cu[st_on] * cus) grid = per_cu[st_on] * cus;
+  if (st_on)
+    hipLaunchKernelGGL(stem_conv3x3_kernel<true>, dim3(grid), dim3(256), 0, st, x, w, bias, y, stats, absmax, d->H, d->W,
+                       d->pad_t, d->pad_l, M);
+  else
+    hipLaunchKernelGGL(stem_conv3x3_kernel<false>, dim3(grid), dim3(256), 0, st, x, w, bias, y, stats, absmax, d->H,
+                       d->W, d->pad_t, d->pad_l, M);
+  return check_launch("stem_conv3x3_kernel");
+}
+
+}  // namespace yolo
