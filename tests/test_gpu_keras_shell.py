@@ -186,31 +186,28 @@ def test_graph_inference_matches_eager_and_tracks_weight_updates():
 
 def test_fit_streams_host_batches_like_the_plain_loop(monkeypatch):
     """fit() on host arrays goes through pinned staging + a copy stream (feeder.HostFeeder) without per-batch
-    synchronisation; the plain train_on_batch loop (YOLO_FIT_PIPELINE=0) is the reference behaviour: same
-    shuffled order, same ragged last batch (10 images, batches of 4), same loss history and weights."""
+    synchronisation; the plain train_on_batch loop (YOLO_FIT_PIPELINE=0) is the reference behaviour. With a
+    learning rate of 0 the weights stay put, so every epoch's mean loss is a pure function of WHICH rows formed
+    WHICH batch (10 images in shuffled batches of 4, 4, 2: batch-statistics BN makes the grouping matter) and must
+    agree between the two loops to rounding. (With lr > 0 this tiny net - BatchNorm over 8-16 samples - amplifies
+    the rounding noise of the filter-gradient atomics to 1e-3 within three steps, in either loop alike.)"""
     import yolov3
     from tf2_yolo_amd import labels
     from tf2_yolo_amd.optimizers import SGD
     rng = np.random.default_rng(3)
     x, ys = labels.synthetic_batch(rng, 10, (64, 64), 2)
-    hist, weights = {}, {}
+    hist = {}
     for mode in ("1", "0"):
         monkeypatch.setenv("YOLO_FIT_PIPELINE", mode)
         yolo = yolov3.Yolo((64, 64, 3), ["a", "b"])
         yolo.create_model(anchors=A9, pretrained_body=None, seed=7)
-        # (plain SGD: Adam's sign-like first steps amplify the rounding noise of the atomics in the filter
-        # gradients into visibly different trajectories, which would hide a real difference in the batches)
-        yolo.model.compile(optimizer=SGD(learning_rate=1e-5), loss=yolo.loss())
+        yolo.model.compile(optimizer=SGD(learning_rate=0.0), loss=yolo.loss())
         h = yolo.model.fit(x, ys, batch_size=4, epochs=3, verbose=0)
         h2 = yolo.model.fit(_Seq(x, ys, 5), epochs=1, verbose=0)
         hist[mode] = np.array(h.history["loss"] + h2.history["loss"])
-        weights[mode] = yolo.model.net.params.data.clone()
     assert np.isfinite(hist["1"]).all()
-    # the first epoch (3 dependent steps) agrees to rounding; after that this tiny net (BatchNorm over 8-16
-    # samples) amplifies the atomics' rounding noise by orders of magnitude per step, in either loop alike
-    # (two runs of the SAME loop differ by 1 % in epoch 2), so later epochs are only checked loosely
-    np.testing.assert_allclose(hist["1"][0], hist["0"][0], rtol=1e-4)
-    np.testing.assert_allclose(hist["1"], hist["0"], rtol=5e-2)
+    assert len(set(np.round(hist["1"][:3], 3))) == 3      # the three shuffles group the rows differently
+    np.testing.assert_allclose(hist["1"], hist["0"], rtol=1e-6)
 
 
 def test_feeder_delivers_every_row_once_in_order():

@@ -399,8 +399,8 @@ class Network:
                     u.s_var = self.state.add(f"{u.name}_bn/moving_variance", (u.cout,), init_ones)
                     u.bn_f32_off = f32
                     f32 += 4 * u.cout            # scale, shift, save_mean, save_invstd
-                    u.bn_f64_off = f64
-                    f64 += (ops.BN_STAT_SLOTS + ops.BN_RED_SLOTS + 1) * 2 * u.cout   # stats[SLOTS][2C], red[RED_SLOTS+1][2C]
+                    u.bn_f64_off = f64           # stats[SLOTS][2C]; all layers' statistics are contiguous: they are
+                    f64 += ops.BN_STAT_SLOTS * 2 * u.cout   # the part of the fp64 buffer that is zeroed every step
                 u.wT_off = wT
                 wT += u.cout * u.k * u.k * cin
             elif u.kind == "head":
@@ -410,6 +410,11 @@ class Network:
                 u.p_bias = self.params.add(f"{u.name}/bias", (cout,), init_zeros)
                 u.wT_off = wT
                 wT += cout * cin
+        self._bn_stats_total = f64
+        for u in self.units:              # red[RED_SLOTS+1][2C]: every slot is written before it is read, never zeroed
+            if u.kind == "conv" and u.bn:
+                u.bn_red_off = f64
+                f64 += (ops.BN_RED_SLOTS + 1) * 2 * u.cout
         self._wT_total = wT
         self._bn_f32_total = f32
         self._bn_f64_total = f64
@@ -539,8 +544,8 @@ class Network:
         b = self._bn_f32[u.bn_f32_off:u.bn_f32_off + 4 * c]
         ns = ops.BN_STAT_SLOTS * 2 * c
         nr = (ops.BN_RED_SLOTS + 1) * 2 * c
-        d = self._bn_f64[u.bn_f64_off:u.bn_f64_off + ns + nr]
-        return b[0:c], b[c:2 * c], b[2 * c:3 * c], b[3 * c:4 * c], d[0:ns], d[ns:ns + nr]
+        return (b[0:c], b[c:2 * c], b[2 * c:3 * c], b[3 * c:4 * c], self._bn_f64[u.bn_f64_off:u.bn_f64_off + ns],
+                self._bn_f64[u.bn_red_off:u.bn_red_off + nr])
 
     # ---- inference through a captured HIP graph ------------------------------------------------------------
     def infer(self, x):
@@ -592,7 +597,7 @@ class Network:
         self._refresh_wplanes()
         self._aux.zero_()   # bounds / per-channel maxima of this pass
         if training:
-            self._bn_f64.zero_()
+            self._bn_f64[:self._bn_stats_total].zero_()
             self._infer_scale_valid = False  # moving statistics (and the shared scale/shift) change
         P = self.params
         for u in self.units:
