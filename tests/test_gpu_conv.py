@@ -24,7 +24,8 @@ CASES = [
     (3, 9, 11, 256, 128, 1, 1, "valid", False),
     (1, 13, 13, 64, 125, 1, 1, "same", True),       # v2 head width
     (1, 5, 5, 1024, 11, 1, 1, "same", True),        # v1 head (tiny Cout)
-    (3, 21, 19, 3, 32, 3, 1, "same", True),         # stem (direct kernel, csrc/stem.hip): odd sizes, batch, bias
+    (3, 21, 19, 3, 32, 3, 1, "same", True),         # stem, small: implicit-GEMM path
+    (2, 733, 717, 3, 32, 3, 1, "same", True),       # stem >= 2^20 pixels: direct kernel (csrc/stem.hip), odd sizes
 ]
 
 
@@ -105,7 +106,7 @@ def test_conv_rejects_bad_descriptor():
         ops.conv2d_fwd(d, x, w)
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[4], CASES[5], CASES[8], CASES[12]])
+@pytest.mark.parametrize("case", [CASES[0], CASES[2], CASES[4], CASES[5], CASES[8], CASES[13]])
 def test_conv_fused_bn_statistics(case):
     """epilogue-fused per-channel sum / sum of squares (training-mode BN) vs the oracle's conv output"""
     from tf2_yolo_amd import ops

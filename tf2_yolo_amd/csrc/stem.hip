@@ -139,8 +139,11 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
 
 bool stem_fwd_supported(const yolo_conv_desc* d) {
   static const bool on = [] { const char* e = getenv("YOLO_STEM_DIRECT"); return !(e && atoi(e) == 0); }();
+  // (below ~1 M pixels - bs 1 inference - a lane gets a single pixel and the kernel is bound by the latency of its
+  // 216 LDS filter reads: the implicit-GEMM kernel is faster there, 3.76 vs 4.0 ms for the whole bs-1 forward)
+  const long long M = (long long)d->N * d->H * d->W;
   return on && d->Cin == 3 && d->Cout == STEM_CO && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 &&
-         d->Ho == d->H && d->Wo == d->W && (long long)d->N * d->H * d->W < (1LL << 31) - (1 << 20);
+         d->Ho == d->H && d->Wo == d->W && M >= (1LL << 20) && M < (1LL << 31) - (1 << 20);
 }
 
 int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y, double* stats,
