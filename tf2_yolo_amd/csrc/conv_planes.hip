@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void split_planes_padded_kernel(const float* _
 //   3 MFMA passes per fragment pair on stage kt's registers, with the 2 DMAs of stage kt+3 (into stage
 //   kt's buffer) issued between them
 template <int BM, int BN, int WGM, int WGN, int DBG = 0>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(const GatherConvArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gather_conv_planes_kernel(const GatherConvArgs a) {
   constexpr int NW = WGM * WGN;
   constexpr int NT = 64 * NW;
   constexpr int TM = BM / WGM / 32;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   // RBA + RBB blocks repeat a B block -- identical bytes to the same LDS address -- so that every wave has
   // the same number of DMAs on its counter
   constexpr int LPW = (RBA + RBB + NW - 1) / NW;
-  static_assert(LPW <= 2 && RBA <= NW, "loader layout: slot s = wave + i*NW loads A block s, or B block (s - RBA) % RBB");
+  static_assert(LPW <= 4, "loader layout: slot s = wave + i*NW loads A block s, or B block (s - RBA) % RBB");
   constexpr int ND = PL_PLANES * LPW;   // DMA instructions per wave per stage
   constexpr int STAGE_BYTES = (RBA + RBB) * PL_PLANES * 1024;
   constexpr int NBUF = 3;
@@ -290,8 +290,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   issue_stage(0);
   issue_stage(1);
   issue_stage(2);
-  if (LPW == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ND) : "memory");   // stages 1 and 2 may still fly
   __builtin_amdgcn_s_barrier();
   read_frags(0, S0{});
 
@@ -299,8 +298,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gather_conv_planes_kernel(c
   // (into stage kt's buffer: everybody finished reading it before this iteration's barrier)
   auto step = [&](int rbuf, int wbuf, auto CUR, auto NXT) {
     // my pieces of stage kt+1 have landed (those of kt+2 may still fly)
-    if (LPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage kt's buffer are done
     if constexpr (!(DBG & 4)) __builtin_amdgcn_s_barrier();
     if constexpr (!(DBG & 2)) read_frags(rbuf, NXT);
@@ -480,6 +478,7 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
     default: break;
   }
 #endif
+  if (waves == 2) return launch_planes<128, 128, 2, 1>(a, st);   // 2 waves x (64 x 128): one wave per SIMD, 512 registers
   if (waves == 4) return launch_planes<128, 128, 2, 2>(a, st);
   return launch_planes<128, 128, 4, 2>(a, st);
 }
