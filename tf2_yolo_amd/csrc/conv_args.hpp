@@ -33,6 +33,7 @@ struct GatherConvArgs {
   unsigned src_bytes, wgt_bytes;
   int zero_blk_src, zero_blk_wgt;
   int nt_store;  // planes kernels: non-temporal stores of the output (it is not re-read by this kernel)
+  int vec_store; // planes kernels, 128x128 tiles: output through LDS as dwordx4 rows (YOLO_VEC_STORE, default 1)
   int kc;        // planes kernels: 16-channel blocks per chunk of the stage order
   int dbg;       // planes kernels: diagnostic knock-outs (YOLO_PLANES_DBG), 0 in production
   Tap taps[MAX_TAPS];

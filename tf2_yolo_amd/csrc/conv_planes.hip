@@ -344,6 +344,63 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
       reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wgt) + a.wgt_bytes - PL_HEADER)[2];
   float* sred = smf + 2 * BM;
   float csum[TN], csq[TN], cmx[TN];
+  // 128x128 tiles store through LDS: the C/D layout gives a lane one column and 16 scattered rows (64 dword stores
+  // per lane, two 128-B row pieces per instruction); transposed in two 64-row halves, every store instruction
+  // writes 1 KB = two full 512-B rows of the tile as dwordx4 (the store tail is issue-bound, not bandwidth-bound)
+  constexpr bool VEC_TILE = (BM == 128 && (BN % 32) == 0);
+  const bool vec = VEC_TILE && a.vec_store && (a.Cout & 3) == 0 && (a.Cd & 3) == 0 && !(a.accumulate && a.stats != nullptr) &&
+                   (DBG & 16) == 0;
+  if (vec) {
+    constexpr int TLD = BN + 4;                    // floats per staged row (16-B aligned, rows 4 banks apart)
+    constexpr int C4 = BN / 4;                     // dwordx4 pieces per row
+    float* tile = smf + 2 * BM + WGM * BN * 3;     // after rowoff and sred; 64 x (BN+4) x 4 B, inside the stage ring
+    static_assert((2 * BM + WGM * BN * 3 + 64 * TLD) * 4 <= 3 * STAGE_BYTES, "epilogue staging exceeds the stage ring");
+    float bvj[TN];
+    bool cokj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
+      cokj[j] = col < a.Cout;
+      bvj[j] = (a.bias != nullptr && cokj[j]) ? a.bias[col] : 0.f;
+      csum[j] = csq[j] = cmx[j] = 0.f;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int rbk = wm * TM + i;               // 32-row block of the tile (0..3): wave-uniform
+        if ((rbk >> 1) != h) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int cl = (wn * TN + j) * 32 + (lane & 31);
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const int rl = (rbk & 1) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            const float v = fmaf(acc[i][j][q], unscale, bvj[j]);
+            tile[rl * TLD + cl] = v;
+            if (cokj[j] && rowoff[h * 64 + rl] >= 0) {
+              csum[j] += v;
+              csq[j] = fmaf(v, v, csq[j]);
+              cmx[j] = fmaxf(cmx[j], fabsf(v));
+            }
+          }
+        }
+      }
+      __syncthreads();
+      for (int idx = tid; idx < 64 * C4; idx += NT) {
+        const int rl = idx / C4, c4 = idx - rl * C4;
+        const long long off = rowoff[h * 64 + rl];
+        const int col = n0 + c4 * 4;
+        if (off >= 0 && col < a.Cout) {
+          f32x4 v = *reinterpret_cast<const f32x4*>(tile + rl * TLD + c4 * 4);
+          f32x4* p = reinterpret_cast<f32x4*>(a.dst + off + col);
+          if (a.accumulate) v += *p;
+          if (a.nt_store) __builtin_nontemporal_store(v, p); else *p = v;
+        }
+      }
+      __syncthreads();
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
@@ -370,6 +427,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
     csum[j] = s1;
     csq[j] = s2;
     cmx[j] = mx;
+  }
   }
   if (a.stats != nullptr || a.absmax != nullptr) {
 #pragma unroll
@@ -446,6 +504,8 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   a.zero_blk_wgt = (a.Cout + 15) / 16;
   static const int nt = [] { const char* e = getenv("YOLO_NT_STORE"); return e ? atoi(e) : 1; }();
   a.nt_store = nt;
+  static const int vecst = [] { const char* e = getenv("YOLO_VEC_STORE"); return e ? atoi(e) : 1; }();
+  a.vec_store = vecst;
   // diagnostic knock-outs of the main loop (wrong results): 1 no DMA, 2 no fragment reads, 4 no barrier, 8 no MFMA, 16 no output stores
   static const int dbg = [] { const char* e = getenv("YOLO_PLANES_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;
