@@ -141,6 +141,11 @@ PLANES_CASES = [
     (1, 13, 13, 64, 125, 1, 1, "same", True),
     (2, 16, 16, 64, 32, 1, 1, "same", False),        # Cout = 32: 128x32 tile (B block loaded by all four waves)
     (2, 15, 17, 32, 64, 3, 2, "darknet_s2", False),   # dgrad with 32 output columns (Cin = 32), 4 parity launches
+    # >= 5000 output rows: the epilogue stages the tile in LDS and stores dwordx4 rows (also the accumulate form)
+    (2, 51, 53, 32, 160, 3, 1, "same", True),         # 128x128 tiles, partial column tile, partial last row tile
+    (2, 51, 53, 160, 32, 1, 1, "same", False),        # 128x32 tile forward; its dgrad: 160 columns
+    (3, 60, 60, 64, 64, 3, 2, "darknet_s2", False),   # dgrad: 4 parity classes of 2700 rows (scalar) / fwd 2700 rows
+    (2, 72, 72, 48, 64, 3, 1, "same", True),          # 128x64 tile, 10368 rows
 ]
 
 
