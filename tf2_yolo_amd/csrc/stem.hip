@@ -159,12 +159,12 @@ int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, con
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, 0) != hipSuccess || n < 1) n = 2;
     per_cu[st_on] = n;
   }
-  int cus = 256;
-  {
+  static int cus = 0;   // (all devices of a node are the same part; queried once: the call is slow)
+  if (cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-      cus = prop.multiProcessorCount;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+           prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
   int grid = (M + 255) / 256;
   if (grid > per_cu[st_on] * cus) grid = per_cu[st_on] * cus;
