@@ -48,6 +48,22 @@ const char* yolo_last_error(void);
 int yolo_abi_version(void);
 /* 1 if a HIP device is visible to the calling process, 0 otherwise (never throws) */
 int yolo_device_available(void);
+/* Run-time tuning / diagnostic switches of the library (no reference counterpart). key 0 = YOLO_OPT_CONV_WIN:
+ * kernel used by yolo_conv2d_fwd_planes / _dgrad_planes for 3x3 stride-1 layers: 0 = per-tap streaming kernel,
+ * 1 = input-window kernel with automatic tile choice, 2 / 4 = window kernel with 128x128 / 256x128 tiles.
+ * Results are identical up to fp32 summation order. Defaults come from the environment (YOLO_CONV_WIN). */
+enum { YOLO_OPT_CONV_WIN = 0, YOLO_OPT_STAMPS = 1, YOLO_OPT_CONV_SK = 2 };
+int yolo_set_option(int key, int value);
+/* Scratch for the persistent ("stream-K") form of the 3x3 window kernel (key 2 = YOLO_OPT_CONV_SK != 0): tile
+ * tickets + the accumulator slabs of tiles shared by several workgroups. The caller owns the memory
+ * (yolo_conv_workspace_bytes() bytes, device); the call zeroes the ticket area on `stream`. Every
+ * yolo_conv2d_fwd_planes / _dgrad_planes call must then be ordered after it on ONE stream (the kernels leave the
+ * tickets zero again). p == NULL unregisters (the kernels fall back to one workgroup per tile). */
+size_t yolo_conv_workspace_bytes(void);
+int yolo_set_conv_workspace(void* p, size_t bytes, void* stream);
+/* Diagnostic builds only (key 1 = YOLO_OPT_STAMPS != 0): device buffer that receives 8 x uint64 clock stamps per
+ * workgroup of the stamped kernel variants; never read by any kernel. */
+int yolo_set_debug_buffer(void* p, size_t bytes);
 
 /* ------------------------------------------------------------------------------------
  * Convolution (replaces tf.keras Conv2D at yolov3/models/backbone.py:27-36,

@@ -224,6 +224,72 @@ def test_conv_dgrad_planes(case):
     assert _relerr(dx2.double().cpu(), 2 * x.grad) < TOL
 
 
+# ---- 3x3 stride-1 kernel that keeps the input window in LDS (csrc/conv_win.hip; yolo_set_option key 0) ----
+WIN_CASES = [
+    (2, 7, 7, 96, 160, 3, 1, "same", False),       # M tail (98 pixels), N tail, 6 channel blocks
+    (1, 2, 2, 1024, 512, 3, 1, "same", False),     # 4 pixels, 64 channel blocks
+    (3, 13, 13, 32, 128, 3, 1, "same", True),      # tiles cross image boundaries (169 pixels per image)
+    (2, 26, 26, 48, 128, 3, 1, "same", False),     # odd number of channel blocks (3)
+    (2, 51, 53, 16, 256, 3, 1, "same", True),      # one channel block, two column tiles, odd row length
+    (5, 5, 9, 64, 128, 3, 1, "same", False),       # tiny images: a tile spans three of them
+    (1, 104, 104, 32, 128, 3, 1, "same", False),   # long rows: wide window
+    (2, 20, 17, 128, 256, 3, 1, "same", False),    # data gradient with 128 columns: window kernel both ways
+]
+
+
+@pytest.mark.parametrize("sk", [0, 1])
+@pytest.mark.parametrize("win", [2, 4])
+@pytest.mark.parametrize("case", WIN_CASES)
+def test_conv_window_kernel_fwd_dgrad(case, win, sk):
+    """sk = 1: the persistent stream-K form; at these sizes every workgroup gets ONE (tile, channel block) unit, so
+    every tile with more than one channel block is combined from as many parts as it has blocks"""
+    from tf2_yolo_amd import ops
+    ops.ensure_conv_workspace()
+    ops.set_option(ops.OPT_CONV_SK, sk)
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=21)
+    x.requires_grad_(True)
+    ref = L.conv2d(x, wk, b, stride=s, padding=pad)
+    g = torch.Generator().manual_seed(22)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    xd, wd = x.detach().float().cuda(), _krsc(wk).float().cuda()
+    bd = None if b is None else b.float().cuda()
+    xp = ops.split_planes(xd, n * h * w, cin)
+    wp = ops.split_planes(wd, cout, k * k * cin)
+    stats = torch.zeros(ops.BN_STAT_SLOTS * 2 * cout, device="cuda", dtype=torch.float64)
+    amax = torch.zeros(cout, device="cuda", dtype=torch.int32)
+    ops.set_option(ops.OPT_CONV_WIN, 0)
+    y0 = ops.conv2d_fwd_planes(d, xp, wp, bd)
+    ops.set_option(ops.OPT_CONV_WIN, win)
+    try:
+        y = ops.conv2d_fwd_planes(d, xp, wp, bd, stats=stats, absmax=amax)
+        torch.cuda.synchronize()
+        assert _relerr(y.double().cpu(), ref.detach()) < TOL
+        assert _relerr(y.double(), y0.double()) < 1e-5      # same arithmetic as the per-tap kernel, other summation order
+        assert torch.equal(amax.view(torch.float32), y.reshape(-1, cout).abs().max(0).values)
+        got = stats.cpu().reshape(ops.BN_STAT_SLOTS, 2, cout).sum(0)
+        r2 = ref.detach().reshape(-1, cout)
+        assert _relerr(got[1], (r2 * r2).sum(0)) < 1e-5
+        if cin >= 32:
+            # data gradient = the same kernel on dy with the transposed filter (needs Cin >= 128 columns for the
+            # window kernel; narrower ones fall through to the per-tap kernel and must still be right)
+            wT = ops.filter_transpose(wd, cout, k * k, cin)
+            dyp = ops.split_planes(dy.float().cuda(), n * d.Ho * d.Wo, cout)
+            wTp = ops.split_planes(wT, cin, k * k * cout)
+            dx = ops.conv2d_dgrad_planes(d, dyp, wTp)
+            torch.cuda.synchronize()
+            assert _relerr(dx.double().cpu(), x.grad) < TOL
+            dx2 = dx.clone()
+            ops.conv2d_dgrad_planes(d, dyp, wTp, dx=dx2, accumulate=True)
+            torch.cuda.synchronize()
+            assert _relerr(dx2.double().cpu(), 2 * x.grad) < TOL
+    finally:
+        ops.set_option(ops.OPT_CONV_WIN, 0)
+        ops.set_option(ops.OPT_CONV_SK, 0)
+
+
 def test_conv_planes_rejects_unsupported_shapes():
     from tf2_yolo_amd import ops
     from tf2_yolo_amd._lib import YoloHipError

@@ -41,6 +41,10 @@ SIGNATURES = {
     "yolo_last_error": (c_char_p, []),
     "yolo_abi_version": (c_int, []),
     "yolo_device_available": (c_int, []),
+    "yolo_set_option": (c_int, [c_int, c_int]),
+    "yolo_set_debug_buffer": (c_int, [_P, c_size_t]),
+    "yolo_conv_workspace_bytes": (c_size_t, []),
+    "yolo_set_conv_workspace": (c_int, [_P, c_size_t, _P]),
     "yolo_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),
     "yolo_conv2d_dgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P]),
     "yolo_conv2d_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P]),

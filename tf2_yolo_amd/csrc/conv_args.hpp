@@ -36,6 +36,11 @@ struct GatherConvArgs {
   int vec_store; // planes kernels, 128x128 tiles: output through LDS as dwordx4 rows (YOLO_VEC_STORE, default 1)
   int kc;        // planes kernels: 16-channel blocks per chunk of the stage order
   int dbg;       // planes kernels: diagnostic knock-outs (YOLO_PLANES_DBG), 0 in production
+  // conv_win.hip, stream-K form: workgroups of the launch (0 = one tile per workgroup), part slabs, tile tickets
+  int sk_grid;
+  float* sk_slabs;
+  unsigned* sk_tickets;
+  unsigned long long* stamps;  // diagnostic builds of conv_win.hip: 8 x u64 per workgroup (s_memtime / s_memrealtime)
   Tap taps[MAX_TAPS];
 };
 
@@ -80,6 +85,16 @@ int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_b
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st);
 int launch_gather_planes16(GatherConvArgs& a, hipStream_t st);   // conv_planes16.hip (16x16x32 MFMA shape)
 bool gather_planes_supported(const GatherConvArgs& a);
+// conv_win.hip (3x3 stride-1 forward / data gradient with the input window kept in LDS); returns 1 = not covered
+int launch_conv_win(GatherConvArgs& a, int variant, hipStream_t st);
+bool conv_win_supported(const GatherConvArgs& a);
+// run-time options (yolo_set_option; defaults from the environment): see runtime.hip
+enum { OPT_CONV_WIN = 0, OPT_STAMPS = 1, OPT_CONV_SK = 2, OPT_DBG = 3, OPT_COUNT = 16 };
+int set_conv_workspace(void* p, size_t bytes, hipStream_t st);   // conv_win.hip
+extern void* g_dbg_buf;        // yolo_set_debug_buffer
+extern size_t g_dbg_bytes;
+extern int g_opt[OPT_COUNT];
+void init_options();
 // conv_wgrad_planes.hip
 int launch_wgrad_planes(WgradArgs& a, hipStream_t st);
 bool wgrad_planes_supported(const WgradArgs& a);

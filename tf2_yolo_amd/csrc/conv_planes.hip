@@ -2,7 +2,7 @@
 // format, planes.hpp) and that reach LDS by LDS-DMA (buffer_load ... lds): the main loop has no VALU split
 // arithmetic, no ds_write and no VGPR staging -- only DMA issue, fragment reads and the 3 fp16 MFMA passes
 // (l*h, h*l, h*h) per 32x32 fragment pair; the epilogue undoes the two power-of-two operand scales.
-#include "planes.hpp"
+#include "planes_epilogue.hpp"
 #include <cstdlib>
 #include <type_traits>
 
@@ -116,7 +116,6 @@ __global__ __launch_bounds__(256) void split_planes_padded_kernel(const float* _
 template <int BM, int BN, int WGM, int WGN, int DBG = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gather_conv_planes_kernel(const GatherConvArgs a) {
   constexpr int NW = WGM * WGN;
-  constexpr int NT = 64 * NW;
   constexpr int TM = BM / WGM / 32;
   constexpr int TN = BN / WGN / 32;
   constexpr int RBA = BM / 32, RBB = BN / 32;
@@ -321,149 +320,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy tail DMAs too
   __syncthreads();  // every wave is done with the stage buffers: the epilogue reuses them
 
-  // ---- epilogue: identical to gather_conv_kernel (C/D layout is dtype-independent) ----
-  float* smf = reinterpret_cast<float*>(smem);
-  long long* rowoff = reinterpret_cast<long long*>(smf);
-  for (int rr = tid; rr < BM; rr += NT) {
-    const long long m = m0 + rr;
-    long long off = -1;
-    if (m < a.M) {
-      const int n = (int)(m / HgWg);
-      const int rem = (int)(m - (long long)n * HgWg);
-      const int y = rem / a.Wg;
-      const int x = rem - y * a.Wg;
-      off = (((long long)n * a.Hd + (y * a.osy + a.ooy)) * a.Wd + (x * a.osx + a.oox)) * a.Cd;
-    }
-    rowoff[rr] = off;
-  }
-  __syncthreads();
-
-  // 1 / (scale of A * scale of B): both powers of two (planes headers)
-  const float unscale =
-      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2] *
-      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wgt) + a.wgt_bytes - PL_HEADER)[2];
-  float* sred = smf + 2 * BM;
-  float csum[TN], csq[TN], cmx[TN];
-  // 128x128 tiles store through LDS: the C/D layout gives a lane one column and 16 scattered rows (64 dword stores
-  // per lane, two 128-B row pieces per instruction); transposed in two 64-row halves, every store instruction
-  // writes 1 KB = two full 512-B rows of the tile as dwordx4 (the store tail is issue-bound, not bandwidth-bound)
-  constexpr bool VEC_TILE = (BM == 128 && (BN % 32) == 0);
-  const bool vec = VEC_TILE && a.vec_store && (a.Cout & 3) == 0 && (a.Cd & 3) == 0 && !(a.accumulate && a.stats != nullptr) &&
-                   (DBG & 16) == 0;
-  if (vec) {
-    constexpr int TLD = BN + 4;                    // floats per staged row (16-B aligned, rows 4 banks apart)
-    constexpr int C4 = BN / 4;                     // dwordx4 pieces per row
-    float* tile = smf + 2 * BM + WGM * BN * 3;     // after rowoff and sred; 64 x (BN+4) x 4 B, inside the stage ring
-    static_assert((2 * BM + WGM * BN * 3 + 64 * TLD) * 4 <= 3 * STAGE_BYTES, "epilogue staging exceeds the stage ring");
-    float bvj[TN];
-    bool cokj[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-      cokj[j] = col < a.Cout;
-      bvj[j] = (a.bias != nullptr && cokj[j]) ? a.bias[col] : 0.f;
-      csum[j] = csq[j] = cmx[j] = 0.f;
-    }
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int rbk = wm * TM + i;               // 32-row block of the tile (0..3): wave-uniform
-        if ((rbk >> 1) != h) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int cl = (wn * TN + j) * 32 + (lane & 31);
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int rl = (rbk & 1) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-            const float v = fmaf(acc[i][j][q], unscale, bvj[j]);
-            tile[rl * TLD + cl] = v;
-            if (cokj[j] && rowoff[h * 64 + rl] >= 0) {
-              csum[j] += v;
-              csq[j] = fmaf(v, v, csq[j]);
-              cmx[j] = fmaxf(cmx[j], fabsf(v));
-            }
-          }
-        }
-      }
-      __syncthreads();
-      for (int idx = tid; idx < 64 * C4; idx += NT) {
-        const int rl = idx / C4, c4 = idx - rl * C4;
-        const long long off = rowoff[h * 64 + rl];
-        const int col = n0 + c4 * 4;
-        if (off >= 0 && col < a.Cout) {
-          f32x4 v = *reinterpret_cast<const f32x4*>(tile + rl * TLD + c4 * 4);
-          f32x4* p = reinterpret_cast<f32x4*>(a.dst + off + col);
-          if (a.accumulate) v += *p;
-          if (a.nt_store) __builtin_nontemporal_store(v, p); else *p = v;
-        }
-      }
-      __syncthreads();
-    }
-  } else {
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
-    const bool cok = col < a.Cout;
-    const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
-    float s1 = 0.f, s2 = 0.f, mx = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (wm * TM + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
-        const long long off = rowoff[row];
-        if (cok && off >= 0) {
-          float v = fmaf(acc[i][j][q], unscale, bv);
-          if (a.accumulate) v += a.dst[off + col];
-          if constexpr ((DBG & 16) != 0) { if (v == 1234.5678f) a.dst[off + col] = v; }
-          else if (a.nt_store) __builtin_nontemporal_store(v, &a.dst[off + col]); else a.dst[off + col] = v;
-          s1 += v;
-          s2 += v * v;
-          mx = fmaxf(mx, fabsf(v));
-        }
-      }
-    }
-    csum[j] = s1;
-    csq[j] = s2;
-    cmx[j] = mx;
-  }
-  }
-  if (a.stats != nullptr || a.absmax != nullptr) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const float s1 = csum[j] + __shfl_xor(csum[j], 32, 64);
-      const float s2 = csq[j] + __shfl_xor(csq[j], 32, 64);
-      const float mx = fmaxf(cmx[j], __shfl_xor(cmx[j], 32, 64));
-      if (lane < 32) {
-        const int c = (wn * TN + j) * 32 + lane;
-        sred[(wm * BN + c) * 3 + 0] = s1;
-        sred[(wm * BN + c) * 3 + 1] = s2;
-        sred[(wm * BN + c) * 3 + 2] = mx;
-      }
-    }
-    __syncthreads();
-    for (int c = tid; c < BN; c += NT) {
-      const int col = n0 + c;
-      if (col < a.Cout) {
-        float s1 = 0.f, s2 = 0.f, mx = 0.f;
-#pragma unroll
-        for (int w = 0; w < WGM; ++w) {
-          s1 += sred[(w * BN + c) * 3 + 0];
-          s2 += sred[(w * BN + c) * 3 + 1];
-          mx = fmaxf(mx, sred[(w * BN + c) * 3 + 2]);
-        }
-        if (a.stats != nullptr) {
-          double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
-          atomicAdd(&slot[col], (double)s1);
-          atomicAdd(&slot[a.Cout + col], (double)s2);
-        }
-        // per-channel max|y| (bit patterns of non-negative floats order like integers); most tiles skip the atomic
-        if (a.absmax != nullptr && __builtin_bit_cast(unsigned, mx) > a.absmax[col])
-          atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, mx));
-      }
-    }
-  }
+  planes_epilogue<BM, BN, WGM, WGN, 3 * STAGE_BYTES, DBG>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
 }
 
 template <int BM, int BN, int WGM, int WGN, int DBG = 0>
@@ -518,6 +375,12 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   // YOLO_PLANES_MFMA=16 selects the 16x16x32-MFMA build of the kernel (conv_planes16.hip): measured equal
   static const int shape = [] { const char* e = getenv("YOLO_PLANES_MFMA"); return e ? atoi(e) : 32; }();
   if (shape == 16 && a.Cout > 32) return launch_gather_planes16(a, st);
+  // 3x3 stride-1 forward / data gradient: the kernel that keeps the input window in LDS (conv_win.hip)
+  init_options();
+  if (g_opt[OPT_CONV_WIN] != 0) {
+    const int rc = launch_conv_win(a, g_opt[OPT_CONV_WIN], st);
+    if (rc <= 0) return rc;
+  }
   if (a.Cout <= 32) return launch_planes<128, 32, 4, 1>(a, st);
   if (a.Cout <= 64) return launch_planes<128, 64, 4, 2>(a, st);
   // few row tiles (13x13 layers at bs 32: 43): 128x128 tiles leave CUs idle (172 tiles for a 512-channel data

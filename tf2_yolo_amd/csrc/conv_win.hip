@@ -1,0 +1,554 @@
+// 3x3 stride-1 convolution forward / data gradient on "planes" operands with the INPUT WINDOW KEPT IN LDS.
+//
+// conv_planes.hip streams, for every filter tap, the 128 shifted pixels of the tile from L2 into LDS again: nine
+// times the same bytes (plus the halo), 341 B of operands per MFMA, and with 40+ workgroups per XCD the window has
+// left the 4 MB L2 by the time the next tap wants it (254 MB beyond-L2 traffic per launch against ~70 MB of
+// compulsory bytes). Here a workgroup loads, per 16-channel block, ONE window of the input -- every pixel any tap of
+// any pixel of the tile touches -- and takes the nine shifted A fragments from it; only the filter tile (B) is
+// streamed per tap.
+//
+// Window coordinates. Pixel (n, y, x) of the [N][H][W] source gets the "padded linear" index
+//     u(n, y, x) = (n (H+1) + y + 1) (W+1) + x + 1
+// i.e. rows of pitch W+1 whose column 0 is a zero column (the right neighbour of x = W-1 is column 0 of the next
+// row, the left neighbour of x = 0 is column 0 of the same row) and one zero row between consecutive images (and
+// above the first): tap (dy, dx) of a pixel is at u + dy (W+1) + dx for EVERY pixel, borders included. The tile's
+// BM consecutive output pixels m0 .. m0+BM-1 need the contiguous range u(m0) - (W+1) - 1 .. u(m_last) + (W+1) + 1;
+// it is loaded in chunks of 64 window pixels (one LDS-DMA instruction = 64 lanes x 16 B = one (plane, k-half) of
+// 64 pixels; zero columns / rows / images past the end fetch the planes' all-zero block). LDS image of a window:
+// [plane][k-half][NCH*64 pixels][16 B], so the A fragment of tap t for lane (r, hf) is ONE ds_read_b128 at
+// base(r, hf) + tapoff_t * 16: 16 consecutive pixels = 16 distinct 16-byte slots, conflict-free up to the +1 jump
+// where the tile crosses an image row.
+//
+// Schedule (per wave; NB = 2 filter DMAs per stage with 4 waves, 1 with 8): stages in (channel block c, tap t)
+// order; B ring of 3 stage buffers (9 taps = 3 turns of the ring, so the buffer of a stage is a compile-time
+// constant), two window buffers (block c reads one while block c+1's chunks land in the other, ONE chunk DMA per
+// wave and stage during taps 0 .. NWS-1), two fragment register sets. Iteration (c, t):
+//     wait vmcnt(NB + [a window DMA was issued in the previous stage])  -> my filter DMAs of the next stage landed
+//     barrier
+//     fragment reads of the next stage (A from the window at the next tap's offset, B from the ring)
+//     12 MFMAs of this stage, with the window chunk DMA (t < NWS) and the filter DMAs of stage +3 between them
+// DMAs are issued from inline asm and counted by hand, window chunk before filter pieces in every stage, so that
+// "all but the youngest NB (+1)" is exactly "everything up to the next stage's filter pieces"; the window of block
+// c+1 is complete two stages before its first read for the same reason (NWS <= 7).
+//
+// Persistent "stream-K" form (a.sk_grid > 0). With one workgroup per tile every workgroup of a round reaches its
+// epilogue at the same time: the chip alternates between rounds of MFMA work and bursts of output stores in which
+// the matrix pipes idle (measured on the 52x52x128->256 layer: 29 k of a tile's 80 k cycles in the epilogue,
+// 6 k in the prologue). Here sk_grid resident workgroups each take an equal, contiguous share of the
+// (tile, channel block) units; a workgroup's tile boundaries fall at a different point of its life than its
+// neighbours', so the epilogues and prologues of some overlap the main loops of the others, and the last round is
+// as full as the first. A tile whose channel blocks are shared by several workgroups is combined without any
+// waiting: every part owner writes its accumulators to its slab in the workspace with write-through (sc1) stores,
+// drains them, and draws a ticket (agent-scope atomic); whoever draws the last ticket acquires, adds the other
+// parts IN PART ORDER (bitwise reproducible whatever the arrival order), resets the ticket and runs the epilogue.
+// No workgroup ever waits for another one, so the result does not depend on residency, dispatch order or placement
+// (cdna_hip_programming.md, Guideline 16 and "In-launch split-K reduction").
+#include "planes_epilogue.hpp"
+#include <cstdlib>
+#include <type_traits>
+
+namespace yolo {
+
+// WGM x 2 waves of 64x64: tile (64*WGM) x 128. NCH = window chunks of 64 pixels (LDS: 2 x NCH x 4 KB + 24 KB).
+template <int WGM, int NCH, bool STAMPS = false>
+__global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConvArgs a) {
+  constexpr int WGN = 2;
+  constexpr int BM = 64 * WGM, BN = 128;
+  constexpr int NW = WGM * WGN;
+  constexpr int TM = 2, TN = 2;
+  constexpr int NB = 8 / NW;                       // filter DMAs per wave and stage (8 x 1 KB per stage)
+  constexpr int NWS = (NCH * 4) / NW;              // window DMAs per wave and channel block, one per stage
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert((NCH * 4) % NW == 0 && NWS <= 7, "window chunks: NCH*4 DMAs spread evenly, at most 7 stages");
+  constexpr int WIN_BYTES = NCH * 4096;            // one window buffer: 2 planes x 2 halves x NCH*64 px x 16 B
+  constexpr int PLANE_STRIDE = 2 * NCH * 1024;
+  constexpr int BSTAGE = 8192;                     // 4 blocks of 32 filters x 2 planes x 1 KB
+  constexpr int BRING = 2 * WIN_BYTES;
+  constexpr int LDS_TOTAL = 2 * WIN_BYTES + 3 * BSTAGE;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds_base = (unsigned)(size_t)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  // diagnostic build: shader-clock stamps of wave 0 around the phases of every part (summed per phase), and the
+  // constant 100 MHz clock at both ends
+  [[maybe_unused]] unsigned long long stamp[4] = {0, 0, 0, 0}, phase_sum[3] = {0, 0, 0};
+  auto take_stamp = [&](int i) {
+    if constexpr (STAMPS) {
+      __builtin_amdgcn_sched_barrier(0);
+      stamp[i] = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  [[maybe_unused]] unsigned long long rt0 = 0, t_start = 0;
+  [[maybe_unused]] int nparts_done = 0, epi_count = 0;
+  [[maybe_unused]] unsigned long long epi_sum[6] = {0, 0, 0, 0, 0, 0};
+  if constexpr (STAMPS) {
+    rt0 = __builtin_amdgcn_s_memrealtime();
+    t_start = __builtin_amdgcn_s_memtime();
+  }
+
+  const int H = a.Hs, W = a.Ws, P1 = W + 1;
+  const int HW = H * W;
+  const int cpt = a.Cs >> 4;                       // 16-channel blocks
+
+  const i32x4 rsrcA = planes_rsrc(a.src, a.src_bytes), rsrcB = planes_rsrc(a.wgt, a.wgt_bytes);
+  const unsigned blkstrideA = (unsigned)(cpt * PL_RECORD);
+  const unsigned blkstrideB = (unsigned)((a.ldw >> 4) * PL_RECORD);
+  // tap offsets in the window (bytes): ((oy+1)(W+1) + ox+1) * 16
+  int tapoff[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) tapoff[t] = ((a.taps[t].oy + 1) * P1 + a.taps[t].ox + 1) * 16;
+
+  // ---- my share of the (tile, channel block) units: [u_begin, u_end) ----
+  // sk_grid == 0: one whole tile per workgroup. Otherwise the units are dealt out evenly to sk_grid workgroups,
+  // logical workgroup wl = XCD-aware remap of blockIdx (neighbours in unit space share an L2).
+  const int G = a.sk_grid;
+  const int wl = xcd_remap(blockIdx.x, G > 0 ? G : a.nblocks);
+  const int sk_q = G > 0 ? (a.nblocks * cpt) / G : 0, sk_r = G > 0 ? (a.nblocks * cpt) % G : 0;
+  auto first_unit = [&](int w) { return w * sk_q + (w < sk_r ? w : sk_r); };
+  auto owner_of = [&](int u) { return u < sk_r * (sk_q + 1) ? u / (sk_q + 1) : sk_r + (u - sk_r * (sk_q + 1)) / sk_q; };
+  const int u_begin = G > 0 ? first_unit(wl) : wl * cpt;
+  const int u_end = G > 0 ? first_unit(wl + 1) : (wl + 1) * cpt;
+
+  for (int u_cur = u_begin; u_cur < u_end;) {
+  take_stamp(0);
+  const int tile = u_cur / cpt;
+  const int cb0 = u_cur - tile * cpt;                                   // first channel block of this part
+  const int cb1 = (cpt - cb0 < u_end - u_cur) ? cpt : cb0 + (u_end - u_cur);   // one past the last
+  u_cur += cb1 - cb0;
+  const int tile_n = tile % a.tiles_n;
+  const int tile_m = tile / a.tiles_n;
+  const long long m0 = (long long)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  // padded linear index of a pixel m
+  auto u_of = [&](long long m) -> int {
+    const int n = (int)(m / HW);
+    const int rem = (int)(m - (long long)n * HW);
+    const int y = rem / W;
+    return (n * (H + 1) + y + 1) * P1 + (rem - y * W) + 1;
+  };
+  const int u_m0 = __builtin_amdgcn_readfirstlane(u_of(m0));
+  const int u_lo = u_m0 - P1 - 1;
+
+  // ---- window loader role: (plane, k-half) of this wave, NWS chunks; voffW = source unit of my pixel ----
+  const int wplane = (wave >> 1) & 1, whf = wave & 1;
+  unsigned voffW[NWS];
+  int chunkW[NWS];
+#pragma unroll
+  for (int s = 0; s < NWS; ++s) {
+    chunkW[s] = (NW == 4) ? s : 2 * s + (wave >> 2);
+    const int u = u_lo + chunkW[s] * 64 + lane;
+    unsigned v = (unsigned)a.zero_blk_src * blkstrideA;
+    if (u >= 0) {
+      const int vrow = u / P1, xc = u - vrow * P1;
+      const int n = vrow / (H + 1), vr = vrow - n * (H + 1);
+      if (xc >= 1 && vr >= 1 && n < a.N) {
+        const int pix = (n * H + vr - 1) * W + xc - 1;
+        v = ((unsigned)pix >> 4) * blkstrideA + (unsigned)(pix & 15) * 16;
+      }
+    }
+    voffW[s] = v;
+  }
+  const unsigned soffW0 = (unsigned)(wplane * 512 + whf * 256);
+  const unsigned ldsW0 = lds_base + (unsigned)((wplane * 2 + whf) * NCH * 1024);
+
+  // ---- filter loader role: 32-filter block rb, plane(s) ----
+  const int r = lane & 31, hf = lane >> 5;
+  const int rbB = (NW == 4) ? wave : (wave >> 1);
+  unsigned voffB;
+  {
+    const int co = n0 + rbB * 32 + r;
+    const unsigned blk = co < a.Cout ? (unsigned)(co >> 4) : (unsigned)a.zero_blk_wgt;
+    voffB = blk * blkstrideB + (co < a.Cout ? (unsigned)(co & 15) * 16 : 0u) + (unsigned)hf * 256;
+  }
+
+  // ---- A fragment bases: lane (r, hf) of 32-row block (wm*TM + i) ----
+  unsigned abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const long long m = m0 + (wm * TM + i) * 32 + r;
+    const int wi = (m < a.M) ? (u_of(m) - u_m0) : 0;
+    abase[i] = (unsigned)(hf * NCH * 1024 + wi * 16);
+  }
+
+  // window chunk DMA number s (0..NWS-1) of channel block cb into window buffer wb
+  auto issue_window = [&](int s, int cb, int wb) {
+    const int cbe = cb < cpt ? cb : cpt - 1;       // past the end: reload the last block (never read)
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)cbe * PL_RECORD + soffW0);
+    const unsigned l = __builtin_amdgcn_readfirstlane(ldsW0 + (unsigned)(wb * WIN_BYTES + chunkW[s] * 1024));
+    dma16(rsrcA, voffW[s], so, l);
+  };
+  // filter DMA number d (0..NB-1) of stage (cb, t) into ring buffer rb3
+  auto issue_filter = [&](int d, int cb, int t, int rb3) {
+    const int cbe = cb < cpt ? cb : cpt - 1;
+    const int plane = (NW == 4) ? d : (wave & 1);
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(t * cpt + cbe) * PL_RECORD + (unsigned)plane * 512);
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(BRING + rb3 * BSTAGE + (rbB * 2 + plane) * 1024));
+    dma16(rsrcB, voffB, so, l);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+  f16x8 fa[2][PL_PLANES][TM], fb[2][PL_PLANES][TN];
+  // fragments of stage (cb, t) into register set S
+  auto read_frags = [&](int cb, auto T, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    constexpr int t = decltype(T)::value;
+    const unsigned so = (unsigned)((cb & 1) * WIN_BYTES + tapoff[t]);
+    const unsigned char* sbB = smem + BRING + (t % 3) * BSTAGE + lane * 16;
+#pragma unroll
+    for (int p = 0; p < PL_PLANES; ++p) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[S][p][i] = *reinterpret_cast<const f16x8*>(smem + (abase[i] + so) + p * PLANE_STRIDE);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[S][p][j] = *reinterpret_cast<const f16x8*>(sbB + ((wn * TN + j) * PL_PLANES + p) * 1024);
+    }
+  };
+
+  // the 12 MFMAs of a stage (l*h, h*l, h*h; planes 0 = h, 1 = l) on register set S, with this stage's DMA issue
+  // (window chunk t of block c+1 first, then the filter pieces of stage +3) spread between them
+  auto mfma_stage = [&](int c, auto T, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    constexpr int t = decltype(T)::value;
+    constexpr int ND = NB + (t < NWS ? 1 : 0);
+    constexpr int NM = TM * TN * 3;
+    constexpr int t3 = (t + 3) % 9;
+    const int c3 = c + (t + 3) / 9;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int pa = (q == 0) ? 1 : 0;
+      const int pb = (q == 1) ? 1 : 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
+          const int idx = (q * TM + i) * TN + j;
+#pragma unroll
+          for (int d = 0; d < ND; ++d)
+            if (idx == (((d + 1) * NM) / (ND + 1) > 0 ? ((d + 1) * NM) / (ND + 1) - 1 : 0)) {
+              __builtin_amdgcn_sched_barrier(0);
+              if (t < NWS && d == 0) issue_window(t, c + 1, (c + 1) & 1);
+              else issue_filter(d - (t < NWS ? 1 : 0), c3, t3, t % 3);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+  };
+
+  // ---- prologue: window of the first block, filter stages (cb0,0) (cb0,1) (cb0,2); fragments of (cb0,0) in set 0 ----
+#pragma unroll
+  for (int s = 0; s < NWS; ++s) issue_window(s, cb0, cb0 & 1);
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int d = 0; d < NB; ++d) issue_filter(d, cb0, t, t);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NB) : "memory");   // filter stages 1 and 2 may still fly
+  __builtin_amdgcn_s_barrier();
+  read_frags(cb0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+  take_stamp(1);
+
+  // one stage: S = register set of this stage, the next stage's fragments go into the other one
+  auto stage = [&](int c, auto T, auto SET) {
+    constexpr int t = decltype(T)::value;
+    constexpr int S = decltype(SET)::value;
+    constexpr int wprev = (t >= 1 && t - 1 < NWS) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NB + wprev) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    constexpr int tn = (t + 1) % 9;
+    read_frags(c + (t + 1) / 9, std::integral_constant<int, tn>{}, std::integral_constant<int, 1 - S>{});
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_stage(c, T, SET);
+  };
+  auto block = [&](int c, auto P) {
+    constexpr int p = decltype(P)::value;
+    stage(c, std::integral_constant<int, 0>{}, std::integral_constant<int, (p + 0) & 1>{});
+    stage(c, std::integral_constant<int, 1>{}, std::integral_constant<int, (p + 1) & 1>{});
+    stage(c, std::integral_constant<int, 2>{}, std::integral_constant<int, (p + 2) & 1>{});
+    stage(c, std::integral_constant<int, 3>{}, std::integral_constant<int, (p + 3) & 1>{});
+    stage(c, std::integral_constant<int, 4>{}, std::integral_constant<int, (p + 4) & 1>{});
+    stage(c, std::integral_constant<int, 5>{}, std::integral_constant<int, (p + 5) & 1>{});
+    stage(c, std::integral_constant<int, 6>{}, std::integral_constant<int, (p + 6) & 1>{});
+    stage(c, std::integral_constant<int, 7>{}, std::integral_constant<int, (p + 7) & 1>{});
+    stage(c, std::integral_constant<int, 8>{}, std::integral_constant<int, (p + 8) & 1>{});
+  };
+  {
+    int c = cb0;
+    for (; c + 1 < cb1; c += 2) {
+      block(c, std::integral_constant<int, 0>{});
+      block(c + 1, std::integral_constant<int, 1>{});
+    }
+    if (c < cb1) block(c, std::integral_constant<int, 0>{});
+  }
+  take_stamp(2);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail DMAs too
+  __syncthreads();  // every wave is done with the LDS: the epilogue reuses it
+
+  bool finish = true;
+  if (cb1 - cb0 < cpt) {
+    // ---- part of a tile: publish my accumulators, draw a ticket; the last arriver combines ----
+    constexpr int SLAB_BYTES = BM * BN * 4;
+    const int w_first = owner_of(tile * cpt), w_last = owner_of(tile * cpt + cpt - 1);
+    const int nparts = w_last - w_first + 1;
+    auto slab_of = [&](int w) {   // a workgroup's head part (its first tile) is slot 0, its tail part slot 1
+      const int slot = (first_unit(w) / cpt == tile) ? 0 : 1;
+      return reinterpret_cast<unsigned char*>(a.sk_slabs) + (size_t)(w * 2 + slot) * SLAB_BYTES;
+    };
+    {
+      unsigned char* mine = slab_of(wl);
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, SLAB_BYTES, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            // (bit_cast of the whole vector: hipcc 7.2 miscompiles __builtin_bit_cast applied to an ext-vector ELEMENT)
+            const f32x4 f = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+            const u32x4 v = __builtin_bit_cast(u32x4, f);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, (((wave * TM + i) * TN + j) * 4 + q4) * 1024 + lane * 16, 0, 16 /* sc1 */);
+          }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+    __syncthreads();
+    unsigned* lds_word = reinterpret_cast<unsigned*>(smem);
+    if (tid == 0)
+      *lds_word = __hip_atomic_fetch_add(&a.sk_tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = *lds_word;
+    finish = (ticket == (unsigned)(nparts - 1));
+    if (finish) {
+      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      const int own = wl - w_first;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q4 = 0; q4 < 4; ++q4) {
+            const size_t off = (size_t)((((wave * TM + i) * TN + j) * 4 + q4) * 1024 + lane * 16);
+            f32x4 mine4 = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            for (int p = 0; p < nparts; ++p) {   // fixed order: part 0 + part 1 + ... (mine from registers)
+              f32x4 v = mine4;
+              if (a.dbg == 1 && p != own) { v = f32x4{0.f, 0.f, 0.f, 0.f}; }            // diagnostic: own part only
+              else if (a.dbg == 2 && p == own) { v = f32x4{0.f, 0.f, 0.f, 0.f}; }       // diagnostic: the other parts only
+              else if (p != own) {   // sc1 load: served by L2 / memory, never by this CU's L1
+                const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(slab_of(w_first + p), 0, SLAB_BYTES, 0x00020000);
+                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (unsigned)off, 0, 16));
+              }
+              t = (p == 0) ? v : t + v;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q4 + e] = t[e];
+          }
+      if (tid == 0) __hip_atomic_store(&a.sk_tickets[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();   // (lds_word is reused by the epilogue)
+    }
+  }
+  if constexpr (STAMPS) {
+    if (finish) {
+      unsigned long long es[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      auto sf = [&](int i) {
+        __builtin_amdgcn_sched_barrier(0);
+        es[i] = __builtin_amdgcn_s_memtime();
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long e_begin = __builtin_amdgcn_s_memtime();
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL, 0>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid, sf);
+      // per-workgroup sums of the epilogue sections -> second record (offset 8 x gridDim.x)
+      epi_sum[0] += es[0] - e_begin;   // row offsets + barrier
+      epi_sum[1] += es[1] - es[0];     // scale loads
+      epi_sum[2] += es[2] - es[1];     // LDS staging, half 0
+      epi_sum[3] += es[3] - es[2];     // stores, half 0
+      epi_sum[4] += es[4] - es[3];     // LDS staging, half 1
+      epi_sum[5] += es[5] - es[4];     // stores, half 1
+      ++epi_count;
+    }
+  } else
+  if (finish) planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
+  __syncthreads();   // the next part's DMAs overwrite the LDS the epilogue used
+  if constexpr (STAMPS) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the diagnostic build waits for its output stores)
+    take_stamp(3);
+    phase_sum[0] += stamp[1] - stamp[0];
+    phase_sum[1] += stamp[2] - stamp[1];
+    phase_sum[2] += stamp[3] - stamp[2];
+    ++nparts_done;
+  }
+  }  // parts of this workgroup
+  if constexpr (STAMPS) {
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    const unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();
+    if (tid == 0 && a.stamps != nullptr) {
+      unsigned long long* o = a.stamps + (size_t)blockIdx.x * 8;
+      o[0] = t_start;
+      o[1] = phase_sum[0];   // prologues
+      o[2] = phase_sum[1];   // main loops
+      o[3] = phase_sum[2];   // drains, combines, epilogues
+      o[4] = t_end;
+      o[5] = rt0;
+      o[6] = rt1;
+      o[7] = (unsigned long long)__builtin_amdgcn_s_getreg(((4 - 1) << 11) | (0 << 6) | 20) |   // HW_REG_XCC_ID
+             ((unsigned long long)nparts_done << 8) | ((unsigned long long)gridDim.x << 32);
+      unsigned long long* o2 = a.stamps + ((size_t)gridDim.x + blockIdx.x) * 8;
+      for (int i = 0; i < 6; ++i) o2[i] = epi_sum[i];
+      o2[6] = (unsigned long long)epi_count;
+      o2[7] = 0;
+    }
+  }
+}
+
+// largest window (in pixels) any tile of BM consecutive output pixels needs
+static int win_pixels_needed(const GatherConvArgs& a, int BM) {
+  const long long HW = (long long)a.Hs * a.Ws;
+  const int P1 = a.Ws + 1;
+  auto u_of = [&](long long m) -> long long {
+    const long long n = m / HW, rem = m - n * HW;
+    const long long y = rem / a.Ws;
+    return (n * (a.Hs + 1) + y + 1) * P1 + (rem - y * a.Ws) + 1;
+  };
+  long long worst = 0;
+  for (long long m0 = 0; m0 < a.M; m0 += BM) {
+    const long long ml = (m0 + BM - 1 < a.M) ? m0 + BM - 1 : a.M - 1;
+    const long long need = u_of(ml) - u_of(m0) + 2 * P1 + 3;
+    if (need > worst) worst = need;
+  }
+  return (int)worst;
+}
+
+bool conv_win_supported(const GatherConvArgs& a) {
+  if (a.ntaps != 9 || a.sy != 1 || a.sx != 1 || a.Hg != a.Hs || a.Wg != a.Ws) return false;
+  if ((a.Cs % 16) != 0 || a.Cout < 128 || a.ldw != 9 * a.Cs) return false;
+  for (int t = 0; t < 9; ++t)
+    if (a.taps[t].oy < -1 || a.taps[t].oy > 1 || a.taps[t].ox < -1 || a.taps[t].ox > 1 || a.taps[t].woff != t * a.Cs)
+      return false;
+  if ((long long)a.N * (a.Hs + 1) * (a.Ws + 1) + 2LL * a.Ws + 8 > 0x3fffffffLL) return false;
+  return true;
+}
+
+// Workspace of the stream-K form (yolo_set_conv_workspace): [tickets: SK_TICKETS x u32, zero between launches]
+// [slabs: 2 per workgroup]. Calls that use it must be ordered on one stream.
+constexpr size_t SK_TICKETS = 1 << 18;
+static void* g_sk_ws = nullptr;
+static size_t g_sk_bytes = 0;
+int set_conv_workspace(void* p, size_t bytes, hipStream_t st) {
+  g_sk_ws = nullptr;
+  g_sk_bytes = 0;
+  if (p == nullptr || bytes <= SK_TICKETS * 4) return YOLO_OK;
+  if (hipMemsetAsync(p, 0, SK_TICKETS * 4, st) != hipSuccess) {
+    set_error("set_conv_workspace: hipMemsetAsync failed");
+    return YOLO_ERR_LAUNCH;
+  }
+  g_sk_ws = p;
+  g_sk_bytes = bytes;
+  return YOLO_OK;
+}
+
+template <int WGM, int NCH>
+static int launch_win(GatherConvArgs& a, hipStream_t st) {
+  constexpr int BM = 64 * WGM;
+  const long long tiles_m = (a.M + BM - 1) / BM;
+  a.tiles_n = (a.Cout + 127) / 128;
+  const long long nb = tiles_m * a.tiles_n;
+  if (nb <= 0 || nb * (a.Cs >> 4) > 0x7fffffffLL) {
+    set_error("conv(window): bad grid %lld", nb);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  a.nblocks = (int)nb;
+  constexpr size_t lds = 2 * NCH * 4096 + 3 * 8192;
+  static bool attr_set = false;
+  static int resident = 0;   // workgroups the chip holds at once (occupancy x CUs)
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<WGM, NCH>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&conv_win_kernel<WGM, NCH>),
+                                                     128 * WGM, lds) == hipSuccess &&
+        hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      resident = per_cu * cus;
+  }
+  // stream-K: as many workgroups as the chip holds, each an equal share of the (tile, channel block) units
+  a.sk_grid = 0;
+  a.dbg = g_opt[OPT_DBG];
+  unsigned grid = (unsigned)nb;
+  if (g_opt[OPT_CONV_SK] != 0 && resident > 0 && g_sk_ws != nullptr && nb <= (long long)SK_TICKETS) {
+    long long G = g_opt[OPT_CONV_SK] > 1 ? g_opt[OPT_CONV_SK] : resident;
+    const long long units = nb * (a.Cs >> 4);
+    if (G > units) G = units;
+    if (SK_TICKETS * 4 + (size_t)G * 2 * BM * 128 * 4 <= g_sk_bytes && G >= 1) {
+      a.sk_grid = (int)G;
+      a.sk_tickets = reinterpret_cast<unsigned*>(g_sk_ws);
+      a.sk_slabs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(g_sk_ws) + SK_TICKETS * 4);
+      grid = (unsigned)G;
+    }
+  }
+  if constexpr (WGM == 2 && NCH == 5) {   // the one stamped instantiation (diagnostics on the 52x52 layers)
+    if (g_opt[OPT_STAMPS] != 0 && g_dbg_buf != nullptr && g_dbg_bytes >= (size_t)nb * 128) {
+      static bool attr2 = false;
+      if (!attr2) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<WGM, NCH, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr2 = true;
+      }
+      a.stamps = reinterpret_cast<unsigned long long*>(g_dbg_buf);
+      hipLaunchKernelGGL((conv_win_kernel<WGM, NCH, true>), dim3(grid), dim3(128 * WGM), lds, st, a);
+      return check_launch("conv_win_kernel(stamps)");
+    }
+  }
+  hipLaunchKernelGGL((conv_win_kernel<WGM, NCH>), dim3(grid), dim3(128 * WGM), lds, st, a);
+  return check_launch("conv_win_kernel");
+}
+
+// variant: 0 = automatic, 2 = 128x128 tiles (4 waves), 4 = 256x128 tiles (8 waves). Returns 1 when no window
+// kernel covers the shape (the caller then uses the per-tap streaming kernel), 0 on success, < 0 on error.
+int launch_conv_win(GatherConvArgs& a, int variant, hipStream_t st) {
+  if (!conv_win_supported(a)) return 1;
+  int wgm = variant;
+  if (wgm != 2 && wgm != 4) wgm = 2;
+  const int need = win_pixels_needed(a, 64 * wgm);
+  const int nch = (need + 63) / 64;
+  if (wgm == 2) {
+    switch (nch) {
+      case 1: case 2: case 3: return launch_win<2, 3>(a, st);
+      case 4: return launch_win<2, 4>(a, st);
+      case 5: return launch_win<2, 5>(a, st);
+      case 6: return launch_win<2, 6>(a, st);
+      case 7: return launch_win<2, 7>(a, st);
+      default: return 1;
+    }
+  }
+  switch ((nch + 1) / 2) {
+    case 1: case 2: return launch_win<4, 4>(a, st);
+    case 3: return launch_win<4, 6>(a, st);
+    case 4: return launch_win<4, 8>(a, st);
+    case 5: return launch_win<4, 10>(a, st);
+    case 6: return launch_win<4, 12>(a, st);
+    case 7: return launch_win<4, 14>(a, st);
+    default: return 1;
+  }
+}
+
+}  // namespace yolo

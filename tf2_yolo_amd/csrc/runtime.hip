@@ -1,5 +1,6 @@
 // Error reporting and device probe for the C-ABI (include/yolo_hip.h).
-#include "common.hpp"
+#include "conv_args.hpp"
+#include <cstdlib>
 #include <cstring>
 
 namespace yolo {
@@ -13,7 +14,46 @@ void set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Run-time options. Index = OPT_* (conv_args.hpp); defaults come from the environment once, yolo_set_option
+// overrides them (benchmarks switch kernel variants inside one process: rule "A/B in one process").
+int g_opt[OPT_COUNT];
+void* g_dbg_buf = nullptr;
+size_t g_dbg_bytes = 0;
+void init_options() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  for (int i = 0; i < OPT_COUNT; ++i) g_opt[i] = 0;
+  const char* e = getenv("YOLO_CONV_WIN");       // 0 off, 1 automatic, 2 force 128x128 tiles, 4 force 256x128 tiles
+  g_opt[OPT_CONV_WIN] = e ? atoi(e) : 0;
+  e = getenv("YOLO_CONV_SK");                    // stream-K form of the window kernel: 0 off, 1 on (needs a workspace)
+  g_opt[OPT_CONV_SK] = e ? atoi(e) : 0;
+}
+
 }  // namespace yolo
+
+extern "C" int yolo_set_option(int key, int value) {
+  yolo::init_options();
+  if (key < 0 || key >= yolo::OPT_COUNT) {
+    yolo::set_error("yolo_set_option: unknown key %d", key);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  yolo::g_opt[key] = value;
+  return YOLO_OK;
+}
+
+extern "C" size_t yolo_conv_workspace_bytes(void) { return (size_t)(1 << 20) + (size_t)1024 * 2 * 256 * 128 * 4; }
+
+extern "C" int yolo_set_conv_workspace(void* p, size_t bytes, void* stream) {
+  yolo::init_options();
+  return yolo::set_conv_workspace(p, bytes, yolo::as_stream(stream));
+}
+
+extern "C" int yolo_set_debug_buffer(void* p, size_t bytes) {
+  yolo::g_dbg_buf = p;
+  yolo::g_dbg_bytes = bytes;
+  return YOLO_OK;
+}
 
 extern "C" const char* yolo_last_error(void) { return yolo::g_err; }
 

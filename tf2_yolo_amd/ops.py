@@ -102,6 +102,27 @@ def _gather_variant(cout, flat, m=None):
     return f"gather_conv_kernel<{bm},{bn}{',flat' if flat else ''}>"
 
 
+OPT_CONV_WIN = 0   # include/yolo_hip.h YOLO_OPT_CONV_WIN
+OPT_CONV_SK = 2
+_CONV_WS = None
+
+
+def ensure_conv_workspace():
+    """scratch of the persistent (stream-K) window kernel: allocated once per process, registered with the library"""
+    global _CONV_WS
+    if _CONV_WS is None:
+        lib = _lib.load()
+        n = int(lib.yolo_conv_workspace_bytes())
+        _CONV_WS = torch.empty(n, dtype=torch.uint8, device="cuda")
+        check(lib.yolo_set_conv_workspace(_p(_CONV_WS), n, _stream()), "yolo_set_conv_workspace")
+    return _CONV_WS
+
+
+def set_option(key, value):
+    """yolo_set_option: run-time kernel-variant switches of the library (benchmarks, tests)"""
+    check(_lib.load().yolo_set_option(int(key), int(value)), "yolo_set_option")
+
+
 def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
