@@ -34,7 +34,7 @@ def kernel_peak(name):
     """Peak of ALGORITHMIC (fp32-equivalent) TFLOP/s for a kernel: the fp32-MFMA peak for the fp32-MFMA kernels,
     the 16-bit MFMA peak / 6 for the bf16x6 split kernels, / 3 for the fp16x3 planes kernels (each algorithmic
     FLOP costs that many 16-bit MFMA FLOPs)."""
-    if "planes" in name:
+    if "planes" in name:     # (also conv_win_planes_kernel: the 3x3 window kernel, same 3 passes)
         return BF16_MFMA_PEAK_TFLOPS / PLANES_PASSES
     return BF16_MFMA_PEAK_TFLOPS / SPLIT_PASSES if "split" in name else FP32_MFMA_PEAK_TFLOPS
 BATCH = 32

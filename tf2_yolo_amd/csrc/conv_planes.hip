@@ -362,9 +362,8 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   static const int nt = [] { const char* e = getenv("YOLO_NT_STORE"); return e ? atoi(e) : 1; }();
   a.nt_store = nt;
   static const int vecst = [] { const char* e = getenv("YOLO_VEC_STORE"); return e ? atoi(e) : 1; }();
-  // (latency-bound launches - a bs-1 forward with tens of tiles per layer - lose 0.1 ms per forward to the two extra
-  // barrier phases: dwordx4 rows from 5000 output rows up)
-  a.vec_store = vecst && a.M >= 5000;
+  // (the wave-private staging of planes_epilogue.hpp has no workgroup barriers: used at every size)
+  a.vec_store = vecst;
   // diagnostic knock-outs of the main loop (wrong results): 1 no DMA, 2 no fragment reads, 4 no barrier, 8 no MFMA, 16 no output stores
   static const int dbg = [] { const char* e = getenv("YOLO_PLANES_DBG"); return e ? atoi(e) : 0; }();
   a.dbg = dbg;

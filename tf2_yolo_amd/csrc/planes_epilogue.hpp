@@ -18,22 +18,33 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
                                                 const int wm, const int wn, const int lane, const int tid,
                                                 const STAMP& stampf = STAMP()) {
   constexpr int NT = 64 * WGM * WGN;
+  constexpr int NW = WGM * WGN;
   constexpr int TM = BM / WGM / 32;
   constexpr int TN = BN / WGN / 32;
-  const int HgWg = a.Hg * a.Wg;
+  const int wave = wm * WGN + wn;
   float* smf = reinterpret_cast<float*>(smem);
   long long* rowoff = reinterpret_cast<long long*>(smf);
-  for (int rr = tid; rr < BM; rr += NT) {
-    const long long m = m0 + rr;
-    long long off = -1;
-    if (m < a.M) {
-      const int n = (int)(m / HgWg);
-      const int rem = (int)(m - (long long)n * HgWg);
-      const int y = rem / a.Wg;
-      const int x = rem - y * a.Wg;
-      off = (((long long)n * a.Hd + (y * a.osy + a.ooy)) * a.Wd + (x * a.osx + a.oox)) * a.Cd;
+  // offset (in floats) of every tile row in dst (-1: the row does not exist). Dense outputs (the forward pass and
+  // stride-1 data gradients: output pixel m IS row m of dst) need no divisions.
+  const bool dense = a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Hd == a.Hg && a.Wd == a.Wg;
+  {
+    const int HgWg = a.Hg * a.Wg;
+    for (int rr = tid; rr < BM; rr += NT) {
+      const long long m = m0 + rr;
+      long long off = -1;
+      if (m < a.M) {
+        if (dense) {
+          off = m * a.Cd;
+        } else {
+          const int n = (int)(m / HgWg);
+          const int rem = (int)(m - (long long)n * HgWg);
+          const int y = rem / a.Wg;
+          const int x = rem - y * a.Wg;
+          off = (((long long)n * a.Hd + (y * a.osy + a.ooy)) * a.Wd + (x * a.osx + a.oox)) * a.Cd;
+        }
+      }
+      rowoff[rr] = off;
     }
-    rowoff[rr] = off;
   }
   __syncthreads();
   stampf(0);
@@ -44,71 +55,73 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
       reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wgt) + a.wgt_bytes - PL_HEADER)[2];
   float* sred = smf + 2 * BM;
   float csum[TN], csq[TN], cmx[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) csum[j] = csq[j] = cmx[j] = 0.f;
   asm volatile("" ::"v"(unscale));
   stampf(1);
   // rows of this tile that exist (the last row tile of a tensor is partial): row r of the tile is real iff r < rows_valid
   const int rows_valid = (a.M - m0 < (long long)BM) ? (int)(a.M - m0) : BM;
-  // 128-row-multiple tiles store through LDS: the C/D layout gives a lane one column and 16 scattered rows (64 dword
-  // stores per lane, two 128-B row pieces per instruction); transposed in 64-row passes, every store instruction
-  // writes 1 KB = two full 512-B rows of the tile as dwordx4 (the store tail is issue-bound, not bandwidth-bound).
-  // The statistics are accumulated with selects, no LDS reads and no branches inside the 64-value loops (the first
-  // version re-read the row offset from LDS and branched per value: 10 k cycles per pass, 21 k of a 128x128 tile's 80 k).
-  constexpr bool VEC_TILE = ((BM % 128) == 0 && (BN % 32) == 0);
-  const bool vec = VEC_TILE && a.vec_store && (a.Cout & 3) == 0 && (a.Cd & 3) == 0 && !(a.accumulate && a.stats != nullptr) &&
+  const bool want_stats = a.stats != nullptr || a.absmax != nullptr;   // (data gradients, inference: none)
+  // Vector path. The C/D layout of the 32x32 MFMA leaves a lane with ONE column and 16 scattered rows of its
+  // sub-tile (64 dword stores per lane, 128-B row pieces); every wave instead transposes its own sub-tile through a
+  // PRIVATE strip of LDS, RP rows at a time, and stores dwordx4 (whole 128..512-B row pieces per lane group): no
+  // workgroup barrier, all waves at once, and the stores of one pass fly while the next pass is staged. The
+  // statistics are accumulated with selects -- no LDS reads, no branches inside the value loops. (History: the first
+  // version staged 64-row halves of the whole tile between workgroup barriers, two waves at a time, and re-read the
+  // row offset from LDS with a branch per value: 21 k of a 128x128 tile's 80 k cycles.)
+  constexpr int WCOLS = TN * 32;                   // columns of a wave's sub-tile
+  constexpr int TLD = WCOLS + 4;                   // floats per staged row (16-B aligned, rows 4 banks apart)
+  constexpr int FIXED = 2 * BM + WGM * BN * 3;     // floats: row offsets + statistics scratch
+  constexpr int RP = ((FIXED + NW * 32 * TLD) * 4 <= LDS_BYTES) ? 32 : 16;   // rows per pass
+  constexpr bool VEC_OK = (FIXED + NW * RP * TLD) * 4 <= LDS_BYTES && (RP * WCOLS / 4) % 64 == 0;
+  const bool vec = VEC_OK && a.vec_store && (a.Cout & 3) == 0 && (a.Cd & 3) == 0 && !(a.accumulate && a.stats != nullptr) &&
                    (DBG & 16) == 0;
+  if constexpr (VEC_OK) {
   if (vec) {
-    constexpr int TLD = BN + 4;                    // floats per staged row (16-B aligned, rows 4 banks apart)
-    constexpr int C4 = BN / 4;                     // dwordx4 pieces per row
-    float* tile = smf + 2 * BM + WGM * BN * 3;     // after rowoff and sred; 64 x (BN+4) x 4 B
-    static_assert((2 * BM + WGM * BN * 3 + 64 * TLD) * 4 <= LDS_BYTES, "epilogue staging exceeds the LDS it may reuse");
-    static_assert((64 * C4) % NT == 0, "copy-out: whole iterations");
+    float* strip = smf + FIXED + wave * (RP * TLD);
+    constexpr int C4 = WCOLS / 4;                  // dwordx4 pieces per row of the sub-tile
+    constexpr int ITER = RP * C4 / 64;
     float bvj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
       bvj[j] = (a.bias != nullptr && col < a.Cout) ? a.bias[col] : 0.f;
-      csum[j] = csq[j] = cmx[j] = 0.f;
     }
 #pragma unroll
-    for (int h = 0; h < BM / 64; ++h) {
+    for (int i = 0; i < TM; ++i) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int rbk = wm * TM + i;               // 32-row block of the tile: wave-uniform
-        if ((rbk >> 1) != h) continue;
-        const int rl0 = (rbk & 1) * 32 + 4 * (lane >> 5);
+      for (int hp = 0; hp < 32 / RP; ++hp) {       // RP = 16: registers 0..7 (rows 0..15), then 8..15 (rows 16..31)
+        const int row0 = (wm * TM + i) * 32 + hp * RP;          // first tile row of this pass (wave-uniform)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int cl = (wn * TN + j) * 32 + (lane & 31);
 #pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const int rl = rl0 + (q & 3) + 8 * (q >> 2);
+          for (int q = hp * (RP / 2); q < (hp + 1) * (RP / 2); ++q) {
+            const int rl = (q & 3) + 8 * ((q >> 2) - hp * (RP / 8)) + 4 * (lane >> 5);   // row inside the pass
             const float v = fmaf(acc[i][j][q], unscale, bvj[j]);
-            tile[rl * TLD + cl] = v;
-            const float vm = (h * 64 + rl < rows_valid) ? v : 0.f;
-            csum[j] += vm;
-            csq[j] = fmaf(vm, vm, csq[j]);
-            cmx[j] = fmaxf(cmx[j], fabsf(vm));
+            strip[rl * TLD + j * 32 + (lane & 31)] = v;
+            if (want_stats) {
+              const float vm = (row0 + rl < rows_valid) ? v : 0.f;
+              csum[j] += vm;
+              csq[j] = fmaf(vm, vm, csq[j]);
+              cmx[j] = fmaxf(cmx[j], fabsf(vm));
+            }
           }
         }
-      }
-      __syncthreads();
-      stampf(2 + 2 * h);
-      {
-        constexpr int ITER = 64 * C4 / NT;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my strip is written (wave-private: no barrier)
         long long offs[ITER];
         f32x4 vv[ITER];
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-          const int idx = tid + it * NT;
+          const int idx = lane + it * 64;
           const int rl = idx / C4, c4 = idx - rl * C4;
-          offs[it] = rowoff[h * 64 + rl];
-          vv[it] = *reinterpret_cast<const f32x4*>(tile + rl * TLD + c4 * 4);
+          offs[it] = rowoff[row0 + rl];
+          vv[it] = *reinterpret_cast<const f32x4*>(strip + rl * TLD + c4 * 4);
         }
 #pragma unroll
         for (int it = 0; it < ITER; ++it) {
-          const int idx = tid + it * NT;
+          const int idx = lane + it * 64;
           const int c4 = idx % C4;
-          const int col = n0 + c4 * 4;
+          const int col = n0 + wn * WCOLS + c4 * 4;
           if (offs[it] >= 0 && col < a.Cout) {
             f32x4* p = reinterpret_cast<f32x4*>(a.dst + offs[it] + col);
             f32x4 v = vv[it];
@@ -116,13 +129,13 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
             if (a.nt_store) __builtin_nontemporal_store(v, p); else *p = v;
           }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the strip is read before the next pass rewrites it
       }
-      __syncthreads();
-      stampf(3 + 2 * h);
     }
-  } else {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) csum[j] = csq[j] = cmx[j] = 0.f;
+    stampf(2);
+  }
+  }
+  if (!vec) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       long long offs[16];   // the 16 rows of this lane in the 32-row block: one batch of LDS reads

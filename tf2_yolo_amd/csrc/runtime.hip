@@ -25,7 +25,7 @@ void init_options() {
   done = true;
   for (int i = 0; i < OPT_COUNT; ++i) g_opt[i] = 0;
   const char* e = getenv("YOLO_CONV_WIN");       // 0 off, 1 automatic, 2 force 128x128 tiles, 4 force 256x128 tiles
-  g_opt[OPT_CONV_WIN] = e ? atoi(e) : 0;
+  g_opt[OPT_CONV_WIN] = e ? atoi(e) : 1;
   e = getenv("YOLO_CONV_SK");                    // stream-K form of the window kernel: 0 off, 1 on (needs a workspace)
   g_opt[OPT_CONV_SK] = e ? atoi(e) : 0;
 }

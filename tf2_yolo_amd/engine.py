@@ -599,6 +599,9 @@ class Network:
         if training:
             self._bn_f64[:self._bn_stats_total].zero_()
             self._infer_scale_valid = False  # moving statistics (and the shared scale/shift) change
+            # captured inference graphs were recorded with the folded scale/shift valid (no bn_fold_inference
+            # inside): a training-mode forward overwrites those buffers with batch statistics, so drop them
+            self._infer_graphs = {}
         P = self.params
         for u in self.units:
             if u.kind == "conv":

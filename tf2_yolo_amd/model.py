@@ -204,28 +204,56 @@ class Model:
         self.net.anchors_trainable = bool(trainable)
         self.net.anchor_grads.zero_()
 
+    @staticmethod
+    def _npz_path(path):
+        p = str(path)
+        if p.endswith((".h5", ".hdf5")):
+            raise YoloHipError("HDF5 weights need h5py, which is not available here; use .npz "
+                               "(keys '<layer name>/<index>')")
+        return p if p.endswith(".npz") else p + ".npz"
+
     def save_weights(self, path):
-        """.npz keyed '<keras layer name>/<index>' (h5py is unavailable: SURVEY.md section 5)."""
+        """.npz keyed '<keras layer name>/<index>' (h5py is unavailable: SURVEY.md section 5). The same path rule
+        as load_weights: '.h5' / '.hdf5' are refused on both sides, anything else gets '.npz' appended once."""
         d = {}
         for n in self.layer_names():
             for i, a in enumerate(self.get_layer(n).get_weights()):
                 d[f"{n}/{i}"] = a
-        np.savez(path, **d)
+        np.savez(self._npz_path(path), **d)
 
-    def load_weights(self, path):
-        if str(path).endswith((".h5", ".hdf5")):
-            raise YoloHipError("HDF5 weights need h5py, which is not available here; convert to .npz "
-                               "(keys '<layer name>/<index>')")
-        d = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+    def load_weights(self, path, by_name=False, skip_mismatch=False):
+        """Keras semantics: every parameterised layer must be in the file with matching shapes (ValueError otherwise);
+        by_name=True loads the layers the file has and returns the names it skipped, skip_mismatch=True (with by_name)
+        also skips layers whose shapes differ."""
+        d = np.load(self._npz_path(path))
+        skipped = []
         for n in self.layer_names():
             layer = self.get_layer(n)
-            k = len(layer.get_weights())
-            if k and f"{n}/0" in d:
-                layer.set_weights([d[f"{n}/{i}"] for i in range(k)])
+            cur = layer.get_weights()
+            if not cur:
+                continue
+            keys = [f"{n}/{i}" for i in range(len(cur))]
+            if not all(k in d for k in keys):
+                if not by_name:
+                    raise ValueError(f"load_weights: layer '{n}' is missing from {path} (pass by_name=True to load a "
+                                     f"partial / renamed checkpoint)")
+                skipped.append(n)
+                continue
+            new = [d[k] for k in keys]
+            if any(a.shape != b.shape for a, b in zip(new, cur)):
+                if not (by_name and skip_mismatch):
+                    raise ValueError(f"load_weights: layer '{n}' has shapes {[a.shape for a in new]} in the file, "
+                                     f"{[b.shape for b in cur]} in the model")
+                skipped.append(n)
+                continue
+            layer.set_weights(new)
+        return skipped
 
     # ---- inference ----
     def __call__(self, x, training=False):
-        outs = self.net.forward(_to_input(x), training=training)
+        # Keras returns fresh tensors: clone the network's persistent head buffers (the zero-copy path stays
+        # internal: train_step_device / infer), so that `a = model(x1); b = model(x2)` leaves `a` intact
+        outs = [t.clone() for t in self.net.forward(_to_input(x), training=training)]
         return outs[0] if self.single_output else outs
 
     def predict(self, x, batch_size=32, verbose=0, **_):
@@ -361,8 +389,23 @@ class Model:
         rng = np.random.default_rng(0)
         hist = {"loss": []}
         pipelined = os.environ.get("YOLO_FIT_PIPELINE", "1") != "0"
+        # Keras callbacks (README.md:262-275 passes ModelCheckpoint-style objects): the epoch-level hooks are called
+        # with Keras' signatures; batch-level hooks would force a host sync per batch and are not called
+        cbs = list(callbacks or [])
+
+        def _cb(hook, *args):
+            for c in cbs:
+                f = getattr(c, hook, None)
+                if f is not None:
+                    f(*args)
+        for c in cbs:
+            if hasattr(c, "set_model"):
+                c.set_model(self)
+        self.stop_training = False
+        _cb("on_train_begin", {})
         for ep in range(initial_epoch, epochs):
             t0 = time.time()
+            _cb("on_epoch_begin", ep, {})
             tot, nb = 0.0, 0
             src = self._host_source(x, y, batch_size, shuffle, rng) if pipelined else None
             if src is not None:
@@ -392,6 +435,10 @@ class Model:
                 msg += f" - val_loss: {hist['val_loss'][-1]:.4f}"
             if verbose:
                 print(msg)
+            _cb("on_epoch_end", ep, {k: v[-1] for k, v in hist.items()})
+            if self.stop_training:
+                break
+        _cb("on_train_end", {})
         self.history = type("History", (), {"history": hist})()
         return self.history
 

@@ -81,13 +81,31 @@ def _wgrad_planes_variant(cout, cols):
 _PLANES_WAVES = 8 if _os.environ.get("YOLO_PLANES_WAVES") == "8" else 4
 
 
-def _planes_variant(cout):
-    """mirrors launch_gather_planes() in csrc/conv_planes.hip"""
+CONV_WIN = int(_os.environ.get("YOLO_CONV_WIN", "1"))
+
+
+def _planes_variant(cout, win=None):
+    """mirrors launch_gather_planes() in csrc/conv_planes.hip and launch_conv_win() in csrc/conv_win.hip;
+    win = (W of the source, M rows) of a 3x3 stride-1 layer, None otherwise"""
+    if win is not None and CONV_WIN and cout >= 128:
+        ws, m = win
+        t128 = ((m + 127) // 128) * ((cout + 127) // 128)
+        wgm = CONV_WIN if CONV_WIN in (2, 4) else (0 if ws > 64 else (4 if 256 < t128 <= 512 else 2))
+        if wgm:
+            return "conv_win_planes_kernel<%d,128>" % (64 * wgm)
     if cout <= 32:
         return "gather_conv_planes_kernel<128,32,4,1>"
     if cout <= 64:
         return "gather_conv_planes_kernel<128,64,4,2>"
     return "gather_conv_planes_kernel<128,128,%s>" % ("4,2" if _PLANES_WAVES == 8 else "2,2")
+
+
+def _win_key(d, hs, ws, cs):
+    """(W, M) when the window kernel covers the layer: 3x3, stride 1, 'same', 16-channel blocks"""
+    if d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.pad_t == 1 and d.pad_l == 1 and cs % 16 == 0 \
+            and d.H == d.Ho and d.W == d.Wo:
+        return (ws, d.N * hs * ws)
+    return None
 
 
 def _gather_variant(cout, flat, m=None):
@@ -265,7 +283,7 @@ def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None, absmax=None):
         check(_lib.load().yolo_conv2d_fwd_planes(byref(d), _p(xp), _p(wp), _p(bias), _p(out), _p(stats), _p(absmax),
                                                  _stream()), "yolo_conv2d_fwd_planes")
     if TIMER is not None:
-        TIMER.bracket(_planes_variant(d.Cout), _conv_flops(d), 1, run)
+        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin)), _conv_flops(d), 1, run)
     else:
         run()
     return out
@@ -282,7 +300,7 @@ def conv2d_dgrad_planes(d, dyp, wTp, dx=None, accumulate=False):
         check(_lib.load().yolo_conv2d_dgrad_planes(byref(d), _p(dyp), _p(wTp), _p(dx), int(bool(accumulate)), _stream()),
               "yolo_conv2d_dgrad_planes")
     if TIMER is not None:
-        TIMER.bracket(_planes_variant(d.Cin), _conv_flops(d), d.sh * d.sw, run)
+        TIMER.bracket(_planes_variant(d.Cin, _win_key(d, d.Ho, d.Wo, d.Cout)), _conv_flops(d), d.sh * d.sw, run)
     else:
         run()
     return dx
