@@ -290,6 +290,79 @@ def test_conv_window_kernel_fwd_dgrad(case, win, sk):
         ops.set_option(ops.OPT_CONV_SK, 0)
 
 
+# ---- the benchmark's own layer sizes against the float64 oracle (not against another device kernel) ----
+# YOLOv3-416 at bs 32, coarsest level: M = 5408 rows, K = 4608 (3x3, 512 -> 1024) and 1024 (1x1, 1024 -> 512)
+@pytest.mark.parametrize("case", [(32, 13, 13, 512, 1024, 3, 1, "same", False), (32, 13, 13, 1024, 512, 1, 1, "same", False)])
+def test_conv_planes_c3_layer_sizes_vs_fp64_oracle(case):
+    from tf2_yolo_amd import ops
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, _ = _mk(case, seed=31)
+    x.requires_grad_(True)
+    wk.requires_grad_(True)
+    ref = L.conv2d(x, wk, None, stride=s, padding=pad)
+    g = torch.Generator().manual_seed(32)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    xd, wd, dyd = x.detach().float().cuda(), _krsc(wk.detach()).float().cuda(), dy.float().cuda()
+    xp, wp = ops.split_planes(xd, n * h * w, cin), ops.split_planes(wd, cout, k * k * cin)
+    dyp = ops.split_planes(dyd, n * h * w, cout)
+    wTp = ops.split_planes(ops.filter_transpose(wd, cout, k * k, cin), cin, k * k * cout)
+    y = ops.conv2d_fwd_planes(d, xp, wp)
+    dx = ops.conv2d_dgrad_planes(d, dyp, wTp)
+    dw = torch.zeros(cout, k, k, cin, device="cuda")
+    ops.conv2d_wgrad_planes(d, xp, dyp, dw)
+    torch.cuda.synchronize()
+    e = (_relerr(y.double().cpu(), ref.detach()), _relerr(dx.double().cpu(), x.grad), _relerr(dw.double().cpu(), _krsc(wk.grad)))
+    print("C3 layer", case[:7], "fwd / dgrad / wgrad error vs fp64:", e)
+    assert max(e) < 2e-5, e      # measured 2e-6 .. 4e-6: fifty times inside the 1e-4 parity bar
+
+
+def _planes_with_bound(x2d, bound):
+    """planes of x2d [P][C] under an explicit upper bound of max|x| (yolo_bn_act_fwd_planes as an identity)"""
+    from tf2_yolo_amd import ops
+    from tf2_yolo_amd._lib import ACT_LINEAR
+    P, C = x2d.shape
+    pl = torch.zeros(ops.planes_bytes(P, C), dtype=torch.uint8, device="cuda")
+    b = torch.tensor([bound], dtype=torch.float32, device="cuda").view(torch.int32)
+    ops.bn_act_fwd(x2d, C, torch.ones(C, device="cuda"), torch.zeros(C, device="cuda"), ACT_LINEAR, planes=pl,
+                   bn_bound=b, want_out=False)
+    return pl
+
+
+@pytest.mark.parametrize("mode", ["loose_bound", "outlier"])
+def test_conv_planes_scaling_stress(mode):
+    """The planes carry ONE power-of-two scale per tensor, chosen from an upper bound of max|x|: small elements of a
+    tensor with a loose bound or a huge outlier fall into fp16's subnormal range (absolute error 2^-40 x bound).
+    loose_bound: the bound bn_finalize falls back to without per-channel maxima, sqrt(P) times the true maximum.
+    outlier: one element 10^6 times the rest; the error is measured on the outputs it does not touch."""
+    from tf2_yolo_amd import ops
+    n, h, w, cin, cout, k = 2, 51, 53, 128, 128, 3
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(n, h, w, cin, generator=g, dtype=torch.float64)
+    wk = torch.randn(k, k, cin, cout, generator=g, dtype=torch.float64) / (k * k * cin) ** 0.5
+    P = n * h * w
+    touched = torch.zeros(n, h, w, dtype=torch.bool)
+    if mode == "outlier":
+        x[1, 20, 30, 7] = 1.0e6
+        touched[1, 19:22, 29:32] = True
+        bound = float(x.abs().max())
+    else:
+        bound = float(x.abs().max()) * P ** 0.5
+    ref = L.conv2d(x, wk, None, stride=1, padding="same")
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, 1, "same")
+    xp = _planes_with_bound(x.float().cuda().reshape(P, cin), bound)
+    wp = ops.split_planes(_krsc(wk).float().cuda(), cout, k * k * cin)
+    y = ops.conv2d_fwd_planes(d, xp, wp).double().cpu()
+    torch.cuda.synchronize()
+    keep = ~touched
+    err = (y - ref)[keep].abs().max().item() / ref[keep].abs().max().item()
+    print("scaling stress", mode, "bound / max|x| =", bound / float(x[keep].abs().max()), "error", err)
+    assert err < TOL, err
+    if mode == "outlier":   # the touched outputs: relative to THEIR scale
+        assert (y - ref)[touched].abs().max().item() / ref[touched].abs().max().item() < TOL
+
+
 def test_conv_planes_rejects_unsupported_shapes():
     from tf2_yolo_amd import ops
     from tf2_yolo_amd._lib import YoloHipError

@@ -79,7 +79,7 @@ def _l2(a, b):
     return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
 
 
-def _setup(version, hw=None, N=2):
+def _setup(version, hw=None, N=2, unbiased=True, true_c1=False):
     import os
     rng = np.random.default_rng(version)
     # v4: the 107-layer CSP/PAN chain needs >= 50 samples per BN channel at the coarsest grid to be a
@@ -89,8 +89,8 @@ def _setup(version, hw=None, N=2):
     if version == 3:
         import yolov3
         y = yolov3.Yolo((hw, hw, 3), ["a", "b", "c"])
-        y.create_model(anchors=A9, pretrained_body=None)
-        fwd = lambda w, x, tr, m=None: OM.yolov3_forward(w, x, A9, training=tr, leaky_masks=m)
+        y.create_model(anchors=A9, pretrained_body=None, bn_unbiased_moving_var=unbiased)
+        fwd = lambda w, x, tr, m=None: OM.yolov3_forward(w, x, A9, training=tr, leaky_masks=m, unbiased_moving_var=unbiased)
         loss_o = [OL.wrap_yolo_loss_v3((g0 * 2 ** i, g0 * 2 ** i), 3, 3, anchors=A9[3 * i:3 * i + 3],
                                        loss_weight=[1, 1, 5, 1]) for i in range(3)]
         loss_g = y.loss()
@@ -98,8 +98,8 @@ def _setup(version, hw=None, N=2):
     elif version == 4:
         import yolov4
         y = yolov4.Yolo((hw, hw, 3), ["a", "b", "c"])
-        y.create_model(anchors=A9, pretrained_body=None)
-        fwd = lambda w, x, tr, m=None: OM.yolov4_forward(w, x, A9, training=tr, leaky_masks=m)
+        y.create_model(anchors=A9, pretrained_body=None, bn_unbiased_moving_var=unbiased)
+        fwd = lambda w, x, tr, m=None: OM.yolov4_forward(w, x, A9, training=tr, leaky_masks=m, unbiased_moving_var=unbiased)
         loss_o = [OL.wrap_yolo_loss_v4((g0 * 2 ** i, g0 * 2 ** i), 3, 3, anchors=A9[3 * i:3 * i + 3],
                                        loss_weight=[1, 5, 1]) for i in range(3)]
         loss_g = y.loss()
@@ -107,18 +107,22 @@ def _setup(version, hw=None, N=2):
     elif version == 2:
         import yolov2
         y = yolov2.Yolo((hw, hw, 3), ["a", "b", "c", "d"])
-        y.create_model(anchors=A5)
-        fwd = lambda w, x, tr, m=None: OM.yolov2_forward(w, x, A5, training=tr, leaky_masks=m)
+        y.create_model(anchors=A5, bn_unbiased_moving_var=unbiased)
+        fwd = lambda w, x, tr, m=None: OM.yolov2_forward(w, x, A5, training=tr, leaky_masks=m, unbiased_moving_var=unbiased)
         loss_o = [OL.wrap_yolo_loss_v2((g0, g0), 5, 4, A5, loss_weight=[1, 1, 5, 1])]
         loss_g = [y.loss()]
         grids = [g0]
     else:
         import yolov1_5
-        y = yolov1_5.Yolo((2 * hw, 2 * hw, 3), ["a", "b"])
-        y.create_model(bbox_num=2)
+        # true_c1: BASELINE.json config 1 at its real size: 224x224, ONE class, B = 2, grid 4x4
+        names = ["raccoon"] if true_c1 else ["a", "b"]
+        y = yolov1_5.Yolo((2 * hw, 2 * hw, 3), names)
+        y.create_model(bbox_num=2, bn_unbiased_moving_var=unbiased)
+        if true_c1:
+            g0 = y.grid_shape[0]      # 224 -> 112 -> 56 -> 28 -> 14 -> 7 -> ceil(7/2) = 4 (yolov1_5/__init__.py:91)
         assert tuple(y.grid_shape) == (g0, g0)
-        fwd = lambda w, x, tr, m=None: OM.yolov1_5_forward(w, x, training=tr, leaky_masks=m)
-        loss_o = [OL.wrap_yolo_loss_v1((g0, g0), 2, 2, binary_weight=0.5, loss_weight=[5, 5, 1, 1])]
+        fwd = lambda w, x, tr, m=None: OM.yolov1_5_forward(w, x, training=tr, leaky_masks=m, unbiased_moving_var=unbiased)
+        loss_o = [OL.wrap_yolo_loss_v1((g0, g0), 2, len(names), binary_weight=0.5, loss_weight=[5, 5, 1, 1])]
         loss_g = [y.loss(binary_weight=0.5)]
         grids = [g0]
     model = y.model
@@ -142,10 +146,16 @@ def _gpu_leaky_masks(net):
     return masks
 
 
-@pytest.mark.parametrize("version", [3, 2, 1, 4])
-def test_model_parity(version):
+# (version, BN moving variance fed Bessel-corrected [tf.keras fused BN, the default] or biased, C1 at its true size)
+@pytest.mark.parametrize("version,unbiased,true_c1", [(3, True, False), (2, True, False), (1, True, False), (4, True, False),
+                                                      (3, False, False), (1, True, True)])
+def test_model_parity(version, unbiased, true_c1):
     from tf2_yolo_amd import optimizers
-    y, model, fwd, loss_o, loss_g, x, ys = _setup(version)
+    if true_c1:   # YOLOv1.5 224x224, 1 class, bs 4, B = 2: grid 4x4 -- BASELINE.json configs[0] as it is quoted
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(version, hw=112, N=4, unbiased=unbiased, true_c1=True)
+        assert tuple(y.grid_shape) == (4, 4) and x.shape == (4, 224, 224, 3)
+    else:
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(version, unbiased=unbiased)
     net = model.net
     w = _weights_dict(model)
     xt = torch.tensor(x, dtype=torch.float64)

@@ -272,7 +272,7 @@ def conv_flops_per_image(builder):
 # runtime
 # --------------------------------------------------------------------------------------------
 class Network:
-    def __init__(self, builder, device="cuda", seed=1234, unbiased_moving_var=False):
+    def __init__(self, builder, device="cuda", seed=1234, unbiased_moving_var=True):
         if not torch.cuda.is_available():
             raise YoloHipError("tf2_yolo_amd needs a HIP device: there is no CPU fallback")
         self.device = torch.device(device)

@@ -92,7 +92,11 @@ class YoloV3(_IOUnavailable):
         self.file_names = None
 
     def create_model(self, anchors=graphs.V3_DEFAULT_ANCHORS, backbone="full_darknet", pretrained_weights=None,
-                     pretrained_body="pascal_voc", seed=1234):
+                     pretrained_body="pascal_voc", seed=1234, bn_unbiased_moving_var=True):
+        """yolov3/__init__.py:100-181. Extra keyword (no reference counterpart): bn_unbiased_moving_var -- which batch
+        variance BatchNormalization feeds into its moving average. True (default) = the Bessel-corrected variance that
+        tf.keras' fused BatchNormalization of TF 2.0 - 2.15 (the reference's `tensorflow>=2.0.0` era) feeds; False =
+        the biased one (non-fused / Keras 3 behaviour). Normalisation itself always uses the biased batch variance."""
         if isinstance(pretrained_body, str):
             _offline("pretrained_body", pretrained_body)
         if backbone not in ("full_darknet", "tiny_darknet"):
@@ -101,7 +105,7 @@ class YoloV3(_IOUnavailable):
                                  "(SURVEY.md section 2 row 15)")
             raise ValueError(f"Invalid backbone: {backbone}")
         builder = graphs.build_yolov3(self.input_shape, self.class_num, anchors, backbone)
-        self.model = Model(builder, version=3, seed=seed)
+        self.model = Model(builder, version=3, seed=seed, unbiased_moving_var=bn_unbiased_moving_var)
         if pretrained_body is not None:
             self.model.set_body_weights(pretrained_body)
         if pretrained_weights is not None:
@@ -209,7 +213,7 @@ class YoloV4(_IOUnavailable):
                 layer.set_weights([layer.get_weights()[0] * amp])
 
     def create_model(self, anchors=None, backbone="csp_darknet", pretrained_weights=None, pretrained_body="ms_coco",
-                     seed=1234):
+                     seed=1234, bn_unbiased_moving_var=True):
         use_arg_anchors = True
         if pretrained_weights is None:
             if anchors is None:
@@ -226,7 +230,7 @@ class YoloV4(_IOUnavailable):
                 raise ValueError(f"backbone {backbone!r} lives in keras.applications, outside the HIP path")
             raise ValueError(f"Invalid backbone: {backbone}")
         builder = graphs.build_yolov4(self.input_shape, self.class_num, anchors)
-        self._model = Model(builder, version=4, seed=seed)
+        self._model = Model(builder, version=4, seed=seed, unbiased_moving_var=bn_unbiased_moving_var)
         if pretrained_body is not None:
             self._model.set_body_weights(pretrained_body)
         if pretrained_weights is not None:
@@ -280,7 +284,7 @@ class YoloV2(_IOUnavailable):
         self.file_names = None
 
     def create_model(self, anchors=V2_DEFAULT_ANCHORS, backbone="darknet", pretrained_weights=None,
-                     pretrained_backbone=None, seed=1234):
+                     pretrained_backbone=None, seed=1234, bn_unbiased_moving_var=True):
         if backbone != "darknet":
             if backbone in ("unet", "mobilenet"):
                 raise ValueError(f"backbone {backbone!r} is outside the HIP path (SURVEY.md section 2 row 15)")
@@ -288,7 +292,7 @@ class YoloV2(_IOUnavailable):
         if isinstance(pretrained_backbone, str):
             _offline("pretrained_backbone", pretrained_backbone)
         builder = graphs.build_yolov2(self.input_shape, self.class_num, anchors)
-        self.model = Model(builder, version=2, seed=seed)
+        self.model = Model(builder, version=2, seed=seed, unbiased_moving_var=bn_unbiased_moving_var)
         if pretrained_backbone is not None:
             self.model.set_body_weights(pretrained_backbone)
         if pretrained_weights is not None:
@@ -318,9 +322,10 @@ class YoloV1_5(_IOUnavailable):
         self.model = None
         self.file_names = None
 
-    def create_model(self, bbox_num=2, pretrained_weights=None, pretrained_backbone=None, seed=1234):
+    def create_model(self, bbox_num=2, pretrained_weights=None, pretrained_backbone=None, seed=1234,
+                     bn_unbiased_moving_var=True):
         builder = graphs.build_yolov1_5(self.input_shape, self.class_num, bbox_num)
-        self.model = Model(builder, version=1, seed=seed)
+        self.model = Model(builder, version=1, seed=seed, unbiased_moving_var=bn_unbiased_moving_var)
         if pretrained_backbone is not None:
             self.model.set_body_weights(pretrained_backbone)
         if pretrained_weights is not None:

@@ -37,7 +37,7 @@ class LayerView:
 
 
 class Model:
-    def __init__(self, builder, version, seed=1234, unbiased_moving_var=False):
+    def __init__(self, builder, version, seed=1234, unbiased_moving_var=True):
         self.net = Network(builder, seed=seed, unbiased_moving_var=unbiased_moving_var)
         self.version = version
         self.single_output = len(self.net.outputs) == 1 and version in (1, 2)
