@@ -404,6 +404,20 @@ int yolo_pr_curve(const double* joint, const int* gt_id, const unsigned char* ma
                   int precision_mode, void* workspace, size_t workspace_bytes, double* precision,
                   double* recall, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Label tensors (the step in front of the loss): box -> grid encoder of the reference's data sequences
+ * (utils/tools.py:179-209: x = box_x % cell_w / cell_w, w = box_w / img_w, conf = 1, class bit; a later box of the
+ * same cell overwrites x, y, w, h, class bits accumulate) and the 2x label pyramid utils/tools.py:342-367
+ * (per 2x2 block that holds an object: the box with the largest w*h, first maximum; its centre re-expressed in the
+ * coarser cell), as yolov3/__init__.py:41-53 applies it. float64 arithmetic in the reference's operation order:
+ * bit-identical to its float64 arrays; label32 / out32 (optional) receive the float32 cast Keras feeds the loss.
+ * boxes: [nb][4] = x1, y1, x2, y2 in pixels; cls: [nb] class ids; first: [N+1] box range of every image.
+ * ------------------------------------------------------------------------------------ */
+int yolo_encode_labels(const double* boxes, const int* cls, const int* first, int N, double img_h, double img_w,
+                       int gh, int gw, int C, double* label64, float* label32, void* stream);
+int yolo_down2xlabel(const double* label_in, int N, int gh, int gw, int ch, double* label_out, float* out32,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -109,6 +109,31 @@ def yolov3_forward(weights, x, anchors, training=False, unbiased_moving_var=Fals
     return outs, c
 
 
+def yolov3_tiny_forward(weights, x, anchors, training=False, unbiased_moving_var=False, leaky_masks=None):
+    """tiny-YOLOv3 body, yolov3/models/darknet.py:107-135 (+ the heads of yolov3/models/__init__.py:13-70 on its two
+    outputs, `create_model(backbone="tiny_darknet")`, yolov3/__init__.py:141-142). The reference's layers are
+    unnamed; the names are this repo's (tf2_yolo_amd/graphs.py:_tiny_v3_body). MaxPooling2D(2, 'same'): stride 2
+    down to 13x13, then ONE stride-1 pool that keeps 13x13 by padding bottom/right with -inf (:122)."""
+    c = _Ctx(weights, training, x.dtype, unbiased_moving_var, leaky_masks)
+    t = x
+    for i, _f in enumerate((16, 32, 64, 128), start=1):
+        t = c.cbl(t, f"tiny_c{i}")
+        t = L.maxpool(t, 2, 2, "same")
+    t1 = c.cbl(t, "tiny_c5")
+    t = L.maxpool(t1, 2, 2, "same")
+    t = c.cbl(t, "tiny_c6")
+    t = L.maxpool(t, 2, 1, "same")
+    t = c.cbl(t, "tiny_c7")
+    t2 = c.cbl(t, "tiny_c8")
+    o1 = c.cbl(t2, "tiny_out1")
+    t = L.upsample2x(c.cbl(t2, "tiny_up"))
+    t = torch.cat([t, t1], dim=-1)
+    o2 = c.cbl(t, "tiny_out2")
+    per = len(anchors) // 2
+    outs = [_head_v234(c, o, i + 1, anchors[i * per:(i + 1) * per], 3) for i, o in enumerate((o1, o2))]
+    return outs, c
+
+
 # ------------------------------------------- v4 -------------------------------------------------
 def yolov4_forward(weights, x, anchors, training=False, unbiased_moving_var=False, leaky_masks=None):
     c = _Ctx(weights, training, x.dtype, unbiased_moving_var, leaky_masks)

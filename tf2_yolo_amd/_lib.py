@@ -43,6 +43,8 @@ SIGNATURES = {
     "yolo_device_available": (c_int, []),
     "yolo_set_option": (c_int, [c_int, c_int]),
     "yolo_set_debug_buffer": (c_int, [_P, c_size_t]),
+    "yolo_encode_labels": (c_int, [_P, _P, _P, c_int, c_double, c_double, c_int, c_int, c_int, _P, _P, _P]),
+    "yolo_down2xlabel": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "yolo_conv_workspace_bytes": (c_size_t, []),
     "yolo_set_conv_workspace": (c_int, [_P, c_size_t, _P]),
     "yolo_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P]),

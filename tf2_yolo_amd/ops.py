@@ -607,6 +607,31 @@ def metrics(cfg, y_true, y_pred, recall_thresh=0.5, out=None):
     return out
 
 
+def encode_labels(boxes, cls, first, n_images, img_hw, grid_shape, class_num):
+    """yolo_encode_labels: boxes float64 [nb,4] (x1,y1,x2,y2 pixels), cls int32 [nb], first int32 [N+1] (CUDA tensors).
+    Returns (label64 [N,gh,gw,5+C] float64, label32 float32)."""
+    if boxes.dtype != torch.float64 or cls.dtype != torch.int32 or first.dtype != torch.int32:
+        raise YoloHipError("encode_labels: boxes float64, cls / first int32")
+    gh, gw = grid_shape
+    l64 = torch.empty((n_images, gh, gw, 5 + class_num), device=boxes.device, dtype=torch.float64)
+    l32 = torch.empty((n_images, gh, gw, 5 + class_num), device=boxes.device, dtype=torch.float32)
+    check(_lib.load().yolo_encode_labels(_p(boxes.contiguous()), _p(cls.contiguous()), _p(first.contiguous()), n_images,
+                                         float(img_hw[0]), float(img_hw[1]), gh, gw, class_num, _p(l64), _p(l32),
+                                         _stream()), "yolo_encode_labels")
+    return l64, l32
+
+
+def down2xlabel(label64):
+    """yolo_down2xlabel on a float64 CUDA label [N,gh,gw,ch] -> (float64, float32) labels of the 2x coarser grid"""
+    if label64.dtype != torch.float64 or not label64.is_cuda or not label64.is_contiguous():
+        raise YoloHipError("down2xlabel: contiguous float64 CUDA tensor expected")
+    n, gh, gw, ch = label64.shape
+    o64 = torch.empty((n, gh // 2, gw // 2, ch), device=label64.device, dtype=torch.float64)
+    o32 = torch.empty((n, gh // 2, gw // 2, ch), device=label64.device, dtype=torch.float32)
+    check(_lib.load().yolo_down2xlabel(_p(label64), n, gh, gw, ch, _p(o64), _p(o32), _stream()), "yolo_down2xlabel")
+    return o64, o32
+
+
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, zero_grad=True):
     check(_lib.load().yolo_adam_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, int(step),
                                      float(grad_scale), int(bool(zero_grad)), _stream()), "yolo_adam_step")
