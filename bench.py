@@ -107,6 +107,49 @@ def cpu_baseline(threads):
                       f"(TensorFlow is not installable in this pipeline)"}
 
 
+def decode_nms_block():
+    """BASELINE.json config 5 (outside the timed region): decode + the three NMS modes on BASELINE.md's uniform-noise
+    levels, GPU milliseconds beside the reference's own CPU milliseconds (tests/golden/tools_timing.json, produced in
+    the build container by tests/golden/make_timing.py -- the reference does not travel to the GPU box)."""
+    from tf2_yolo_amd import tools
+    path = os.path.join(ROOT, "tests", "golden", "tools_timing.json")
+    cpu = json.load(open(path)) if os.path.exists(path) else None
+    rng = np.random.default_rng(1234)
+    lv = [torch.from_numpy(rng.random((g, g, 255), dtype=np.float32)).cuda() for g in (13, 26, 52)]
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, r
+
+    cases = []
+    for thr, n in ((0.9, 10), (0.5, 3)):
+        t_dec, dec = timed(lambda: tools.decode_device(*lv, class_num=80, threshold=thr, version=3), n)
+        c = {"conf_threshold": thr, "candidates": int(dec.shape[0]), "gpu_decode_ms": round(t_dec, 3)}
+        for name, fn in (("nms", lambda: tools.nms(dec, class_num=80, nms_threshold=0.5)),
+                         ("diou_nms", lambda: tools.nms(dec, class_num=80, nms_threshold=0.5, iou_mode=2)),
+                         ("soft_nms", lambda: tools.soft_nms(dec, class_num=80, nms_threshold=0.5, conf_threshold=thr,
+                                                             sigma=0.5))):
+            t, out = timed(fn, n)
+            c[f"gpu_{name}_ms"] = round(t, 3)
+            c[f"{name}_kept"] = int(out.shape[0])
+        if cpu is not None:
+            ref = next((r for r in cpu["cases"] if r["conf_threshold"] == thr), None)
+            if ref is not None:
+                c["cpu_reference"] = {k: ref[k] for k in ref if k.endswith("_ms") or k.endswith("_kept") or k == "candidates"}
+                c["same_counts_as_reference"] = bool(ref["candidates"] == c["candidates"] and all(
+                    ref[f"{m}_kept"] == c[f"{m}_kept"] for m in ("nms", "diou_nms", "soft_nms")))
+        cases.append(c)
+    return {"what": "YOLOv3-416 shaped uniform-noise predictions (13,26,52 levels, C=80), decode + NMS; GPU = this library "
+                    "(results bit-identical to the reference's on the golden vectors, tests/test_gpu_decode_nms.py), "
+                    "CPU = the reference's utils.tools on one core of the build container",
+            "cpu_host": None if cpu is None else cpu["host"], "cases": cases}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -259,7 +302,7 @@ def main():
                                    if "split" in name else "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": hbm_traffic_from_profile(name),
-                    "frac_of_fp32_mfma_peak": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                    "ratio_to_fp32_input_mfma_peak_NOT_a_roofline_fraction": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic_source": "newest profiles/r*_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                       "passes, gfx950 x2 FETCH correction), bytes per launch",
                     "launches": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
@@ -277,14 +320,19 @@ def main():
         out = {"metric": "images/sec training YOLOv3 416x416 bs=32/GPU", "value": round(world * args.batch * args.steps / dt, 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "arithmetic": "fp32 storage and fp32 accumulation everywhere; conv operands enter the matrix cores as two scaled fp16 planes (22-23 significant bits, fp32 has 24), one product = 3 fp16 MFMA passes exact in the fp32 accumulator: measured 2e-6 from the exact kernels at K=9216, parity bar 1e-4 vs the float64 oracle; first conv (Cin=3), Cout<=32 layers and stride-2 filter gradients use the exact bf16x6 / fp32-input MFMA kernels; YOLO_CONV_PLANES=0 selects the exact bf16x6 kernels everywhere (474 img/s), YOLO_CONV_MODE=fp32 the fp32-input MFMA kernels",
+               "vs_baseline": None, "dtype": "f32-storage/fp16x2-mfma", "data": "synthetic",
+               "arithmetic": "fp32 storage and fp32 accumulation everywhere; conv operands enter the matrix cores as two scaled fp16 planes (22-23 significant bits, fp32 has 24), one product = 3 fp16 MFMA passes exact in the fp32 accumulator: measured 1.5e-6 / 2.4e-6 / 6e-7 (fwd / dgrad / wgrad) against the float64 oracle at the 13x13x512->1024 3x3 layer, bs 32, K=4608 (tests/test_gpu_conv.py), parity bar 1e-4; the first conv (Cin=3) and Cout<=32 layers use the exact bf16x6 / fp32-input MFMA kernels (stride-2 filter gradients run on the planes kernels too); YOLO_CONV_PLANES=0 selects the exact bf16x6 kernels everywhere (474 img/s), YOLO_CONV_MODE=fp32 the fp32-input MFMA kernels",
                "config": {"workload": "YOLOv3 Darknet-53 416x416, 9 anchors / 3 FPN scales, C=80: training step = "
                                       "forward (batch-stat BN) + 3 fused loss/grad kernels + backward + "
                                       "gradient all-reduce + Adam",
                           "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                           "parallelism": f"dp{world}", "loss": round(loss_val, 4), "replicas_in_sync": dp_in_sync},
                "roofline": roof, "forward": fwd}
+        if world == 1:
+            try:
+                out["decode_nms"] = decode_nms_block()
+            except Exception as e:   # informational block: never lose the headline line over it
+                out["decode_nms"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (bounded sample) ...")
             try:

@@ -405,6 +405,16 @@ int yolo_pr_curve(const double* joint, const int* gt_id, const unsigned char* ma
                   double* recall, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Gradient exchange (data parallelism; no reference counterpart). SURVEY.md section 8b lists a
+ * `yolo_allreduce_bucket` wrapper: it is deliberately NOT exported. The exchange is torch.distributed's
+ * all_reduce (backend "nccl" = RCCL over xGMI) on contiguous slices of the caller's flat gradient buffer, issued
+ * from the host side (tf2_yolo_amd/dp.py) on a communication stream -- RCCL needs its communicator, its own stream
+ * ordering and process-group bootstrap, all of which live above this C-ABI; the library only guarantees that the
+ * parameter gradients of a unit are complete on the stream(s) it was given when its backward calls have been
+ * enqueued. yolo_adam_step applies the 1/world factor (grad_scale).
+ * ------------------------------------------------------------------------------------ */
+
+/* ------------------------------------------------------------------------------------
  * Label tensors (the step in front of the loss): box -> grid encoder of the reference's data sequences
  * (utils/tools.py:179-209: x = box_x % cell_w / cell_w, w = box_w / img_w, conf = 1, class bit; a later box of the
  * same cell overwrites x, y, w, h, class bits accumulate) and the 2x label pyramid utils/tools.py:342-367

@@ -80,7 +80,8 @@ if "c5" in which:
     lv = [outs[2][0], outs[1][0], outs[0][0]]
     t_dec, dec = timed(lambda: tools.decode_device(*lv, class_num=80, threshold=0.5, version=3))
     print(json.dumps({"config": "C5 decode on model output thr=.5", "rows": int(dec.shape[0]), "ms": round(t_dec, 3)}), flush=True)
-    noise = [torch.from_numpy(np.random.default_rng(1234).random((g, g, 255), dtype=np.float32)).cuda() for g in (13, 26, 52)]
+    nrng = np.random.default_rng(1234)     # ONE generator, levels drawn 13 -> 26 -> 52: BASELINE.md's inputs (131 304 / 4 425 candidates)
+    noise = [torch.from_numpy(nrng.random((g, g, 255), dtype=np.float32)).cuda() for g in (13, 26, 52)]
     for thr in (0.9, 0.5):
         t_dec, dec = timed(lambda: tools.decode_device(*noise, class_num=80, threshold=thr, version=3), n=10)
         res = {"config": f"C5 uniform-noise levels (13,26,52) thr={thr}", "rows": int(dec.shape[0]), "decode_ms": round(t_dec, 3)}

@@ -29,7 +29,7 @@ struct GatherConvArgs {
   int kw, pad_t, pad_l;  // FLAT mode: tap t = (r*kw+s), oy = r-pad_t, ox = s-pad_l
   int tiles_n;
   int nblocks;
-  // planes kernels (conv_planes.hip): src / wgt point to bf16 planes; byte sizes and all-zero block indices
+  // planes kernels (conv_planes.hip): src / wgt point to fp16 planes (planes.hpp); byte sizes and all-zero block indices
   unsigned src_bytes, wgt_bytes;
   int zero_blk_src, zero_blk_wgt;
   int nt_store;  // planes kernels: non-temporal stores of the output (it is not re-read by this kernel)
@@ -67,8 +67,9 @@ struct WgradArgs {
   int ntaps;
   int kw, pad_t, pad_l;
   int tiles_co, tiles_j;
+  int nblocks;      // planes kernel: workgroups of the (1-D, XCD-remapped) grid = tiles_co * tiles_j * splits
   long long chunk;  // pixels per split (multiple of 32)
-  // planes kernel (conv_wgrad_planes.hip): src / dy point to bf16 planes
+  // planes kernel (conv_wgrad_planes.hip): src / dy point to fp16 planes
   unsigned src_bytes, dy_bytes;
   int zero_blk_src, zero_blk_dy;
 };

@@ -39,10 +39,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
-  const int tile_co = blockIdx.x % a.tiles_co;
-  const int j0 = (blockIdx.x / a.tiles_co) * BN;
+  // 1-D grid, XCD-aware: blocks b, b+8, ... share an XCD (round-robin dispatch), so give every XCD a contiguous
+  // run of (pixel chunk, tile) pairs with the tile index fastest: the tiles_co x tiles_j workgroups that contract
+  // the SAME pixel chunk then sit on one XCD and fetch its x / dy rows once through that L2. (A 2-D grid dealt them
+  // to all eight XCDs: 867 MB beyond-L2 traffic per launch on the 52x52x128->256 layer against 133 MB of operands,
+  // i.e. HBM-bound at 4.3 TB/s; profiles/r02_a_conv_pmc.json.)
+  const int lid = xcd_remap(blockIdx.x, a.nblocks);
+  const int tiles = a.tiles_co * a.tiles_j;
+  const int split = lid / tiles;
+  const int tile = lid - split * tiles;
+  const int tile_co = tile % a.tiles_co;
+  const int j0 = (tile / a.tiles_co) * BN;
   const int co0 = tile_co * BM;
-  const long long p_begin = (long long)blockIdx.y * a.chunk;   // multiple of 16
+  const long long p_begin = (long long)split * a.chunk;   // multiple of 16
   long long p_end = p_begin + a.chunk;
   if (p_end > a.M) p_end = a.M;
   if (p_begin >= p_end) return;
@@ -272,10 +281,11 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   chunk = (chunk + 15) / 16 * 16;
   splits = (a.M + chunk - 1) / chunk;
   a.chunk = chunk;
-  if (tiles > 0x7fffffffLL || splits > 65535) {
+  if (tiles * splits > 0x7fffffffLL || splits > 65535) {
     set_error("wgrad(planes): bad grid %lld x %lld", tiles, splits);
     return YOLO_ERR_INVALID_ARG;
   }
+  a.nblocks = (int)(tiles * splits);
   constexpr size_t lds = 3 * (BM / 32 + BN / 32) * PL_PLANES * 1024;
   static bool attr_set = false;
   if (!attr_set) {
@@ -283,8 +293,8 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_planes_kernel<BM, BN, WGM, WGN>), dim3((unsigned)tiles, (unsigned)splits),
-                     dim3(64 * WGM * WGN), lds, st, a);
+  hipLaunchKernelGGL((wgrad_planes_kernel<BM, BN, WGM, WGN>), dim3((unsigned)(tiles * splits)), dim3(64 * WGM * WGN), lds,
+                     st, a);
   return check_launch("wgrad_planes_kernel");
 }
 
@@ -307,7 +317,9 @@ int launch_wgrad_planes(WgradArgs& a, hipStream_t st) {
   if (a.Cout <= 64 && cols <= 64) return launch_wp<64, 64, 2, 2>(a, st);
   if (a.Cout <= 64) return launch_wp<64, 128, 2, 4>(a, st);
   if (cols <= 64) return launch_wp<128, 64, 4, 2>(a, st);
-  static const int waves = [] { const char* e = getenv("YOLO_WGRAD_WAVES"); return e ? atoi(e) : 8; }();
+  // 4 waves x (64 x 64): 12 MFMAs per wave between barriers instead of 6. Alone 160-178 us against 200-207 us on the
+  // 3x3 layers; in the training step (beside the data-gradient stream) 33.25 against 33.58 ms. YOLO_WGRAD_WAVES=8: old form
+  static const int waves = [] { const char* e = getenv("YOLO_WGRAD_WAVES"); return e ? atoi(e) : 4; }();
   if (waves == 4) return launch_wp<128, 128, 2, 2>(a, st);
   return launch_wp<128, 128, 4, 2>(a, st);
 }

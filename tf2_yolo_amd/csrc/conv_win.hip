@@ -494,9 +494,16 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
   a.sk_grid = 0;
   a.dbg = g_opt[OPT_DBG];
   unsigned grid = (unsigned)nb;
-  if (g_opt[OPT_CONV_SK] != 0 && resident > 0 && g_sk_ws != nullptr && nb <= (long long)SK_TICKETS) {
+  // Policy (YOLO_CONV_SK / yolo_set_option key 2): 1 = automatic -- only launches that would leave most of the chip
+  // idle (fewer tiles than half the resident workgroups: small batches, e.g. the bs-1 inference forward, 16 tiles of
+  // 288 stages on a 13x13 layer), split into at most 8 parts per tile (the last arriver reads the other parts'
+  // slabs: 64 KB each); at training sizes one workgroup per tile measured faster (the slab round trips cost more
+  // than the ragged last round). A value > 1 forces that many workgroups (benchmarks).
+  const bool sk_auto = g_opt[OPT_CONV_SK] == 1 && nb * 2 < resident;
+  if ((sk_auto || g_opt[OPT_CONV_SK] > 1) && resident > 0 && g_sk_ws != nullptr && nb <= (long long)SK_TICKETS) {
     long long G = g_opt[OPT_CONV_SK] > 1 ? g_opt[OPT_CONV_SK] : resident;
     const long long units = nb * (a.Cs >> 4);
+    if (sk_auto && G > nb * 8) G = nb * 8;
     if (G > units) G = units;
     if (SK_TICKETS * 4 + (size_t)G * 2 * BM * 128 * 4 <= g_sk_bytes && G >= 1) {
       a.sk_grid = (int)G;

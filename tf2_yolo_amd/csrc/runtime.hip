@@ -26,8 +26,8 @@ void init_options() {
   for (int i = 0; i < OPT_COUNT; ++i) g_opt[i] = 0;
   const char* e = getenv("YOLO_CONV_WIN");       // 0 off, 1 automatic, 2 force 128x128 tiles, 4 force 256x128 tiles
   g_opt[OPT_CONV_WIN] = e ? atoi(e) : 1;
-  e = getenv("YOLO_CONV_SK");                    // stream-K form of the window kernel: 0 off, 1 on (needs a workspace)
-  g_opt[OPT_CONV_SK] = e ? atoi(e) : 0;
+  e = getenv("YOLO_CONV_SK");                    // stream-K form of the window kernel: 0 off, 1 automatic (small
+  g_opt[OPT_CONV_SK] = e ? atoi(e) : 1;          // launches only; needs yolo_set_conv_workspace), > 1 forced grid
 }
 
 }  // namespace yolo
@@ -42,7 +42,8 @@ extern "C" int yolo_set_option(int key, int value) {
   return YOLO_OK;
 }
 
-extern "C" size_t yolo_conv_workspace_bytes(void) { return (size_t)(1 << 20) + (size_t)1024 * 2 * 256 * 128 * 4; }
+// tickets (1 MB) + two accumulator slabs (up to 256 x 128 fp32) for each of up to 512 workgroups
+extern "C" size_t yolo_conv_workspace_bytes(void) { return (size_t)(1 << 20) + (size_t)512 * 2 * 256 * 128 * 4; }
 
 extern "C" int yolo_set_conv_workspace(void* p, size_t bytes, void* stream) {
   yolo::init_options();

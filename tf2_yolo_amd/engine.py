@@ -318,6 +318,7 @@ class Network:
         self.training = False
         self.grad_ready_hook = None   # called as hook(unit) after a unit's parameter grads are enqueued
         self._infer_scale_valid = False
+        ops.ensure_conv_workspace()   # scratch of the persistent (stream-K) window kernel: small-batch launches
         # consumers per tensor decide whether a tensor needs a gradient at all
         self._needs_grad = self._compute_needs_grad()
         # pre-split ("planes") copies of the filters for the LDS-DMA conv kernels: [Cout][taps*Cin] for

@@ -55,7 +55,8 @@ def _conv_flops(d):
 
 import os as _os
 CONV_MODE = "fp32" if _os.environ.get("YOLO_CONV_MODE", "split")[:1] in ("f", "0") else "split"
-# engine-level choice: keep conv operands as pre-split bf16 planes and use the LDS-DMA kernels (conv_planes.hip)
+# engine-level choice: keep conv operands as pre-split scaled fp16 planes (h + l) and use the LDS-DMA kernels
+# (conv_planes.hip, conv_win.hip, conv_wgrad_planes.hip)
 USE_PLANES = CONV_MODE == "split" and _os.environ.get("YOLO_CONV_PLANES", "1") != "0"
 
 
@@ -68,11 +69,12 @@ def planes_dgrad_ok(cin, cout):
 
 
 def planes_wgrad_ok(cin, cout, taps, stride=1):
+    # (stride is not a criterion: stride-2 filter gradients run on the planes kernel too)
     return USE_PLANES and cin % 16 == 0 and cout % 16 == 0 and cout >= 64 and taps * cin >= 64
 
 
 def _wgrad_planes_variant(cout, cols):
-    big = "2,2" if _os.environ.get("YOLO_WGRAD_WAVES") == "4" else "4,2"
+    big = "4,2" if _os.environ.get("YOLO_WGRAD_WAVES") == "8" else "2,2"
     return "wgrad_planes_kernel<%d,%d,%s>" % (64 if cout <= 64 else 128, 64 if cols <= 64 else 128,
                                              "2,2" if (cout <= 64 and cols <= 64) else "2,4" if cout <= 64
                                              else "4,2" if cols <= 64 else big)
@@ -210,7 +212,8 @@ def planes_bytes(rows, c):
 
 
 def split_planes(x, rows, c, out=None):
-    """fp32 [rows][c] -> exact bf16 x 3 planes (include/yolo_hip.h: yolo_split_planes); returns a uint8 buffer"""
+    """fp32 [rows][c] -> two scaled fp16 planes h + l (22-23 significant bits; include/yolo_hip.h: yolo_split_planes);
+    returns a uint8 buffer"""
     _chk_f32(x)
     if x.numel() != rows * c:
         raise YoloHipError("split_planes: tensor size does not match rows x C")
