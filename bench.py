@@ -55,6 +55,10 @@ def hbm_traffic_from_profile(kernel):
     base, _, rest = kernel.partition("<")
     dims = rest.rstrip(">").split(",")
     flat = "true" if "flat" in dims else "false"
+    if base == "conv_win_planes_kernel":   # timer name <rows,128> = rocprof conv_win_kernel<rows/64, window chunks, false>
+        fam = [v for n, v in prof.items() if n.startswith(f"conv_win_kernel<{int(dims[0]) // 64},")]
+        cnt = sum(v["launches"] for v in fam)
+        return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / cnt) if cnt else None
     if base == "gather_conv_kernel" and len(dims) >= 2:
         for name, v in prof.items():
             if name.startswith(f"{base}<{dims[0]},{dims[1]},") and name.endswith(f",{flat}>"):
@@ -64,6 +68,34 @@ def hbm_traffic_from_profile(kernel):
         cnt = sum(v["launches"] for n, v in prof.items() if n.startswith("wgrad_kernel"))
         return int(tot / cnt) if cnt else None
     return None
+
+
+def pmc_from_profile(kernel):
+    """MFMA-busy %, held clock and L2 hit rate of the kernel family from the newest committed PMC passes
+    (profiles/r*_conv_pmc.json, scripts/pmc_round.sh: the standalone layer benchmark under rocprofv3 --pmc; bench.py
+    cannot collect counters itself). Averages over the profiled layers of that family; None if there is no profile."""
+    import glob
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_pmc.json")))
+    if not paths:
+        return None
+    fam = ("wgrad128x128" if kernel.startswith("wgrad_planes_kernel<128,128") else
+           "wgrad64x128" if kernel.startswith("wgrad_planes_kernel<64,128") else
+           "win128" if kernel.startswith("conv_win_planes_kernel<128") else
+           "win256" if kernel.startswith("conv_win_planes_kernel<256") else
+           "planes128x128" if kernel.startswith("gather_conv_planes_kernel<128,128") else
+           "planes128x64" if kernel.startswith("gather_conv_planes_kernel<128,64") else
+           "planes128x32" if kernel.startswith("gather_conv_planes_kernel<128,32") else None)
+    if fam is None:
+        return None
+    rows = [k for k in json.load(open(paths[-1]))["kernels"] if k["label"].startswith(fam) and "mfma_busy_pct" in k["derived"]]
+    if not rows:
+        return None
+    avg = lambda key: round(sum(k["derived"][key] for k in rows if key in k["derived"]) / len(rows), 3)
+    return {"mfma_busy_pct": avg("mfma_busy_pct"), "effective_clock_ghz": avg("effective_clock_ghz"),
+            "l2_hit_rate": avg("l2_hit_rate"), "lds_active_pct": avg("lds_active_pct"),
+            "layers": [k["layer_H_Cin_Cout_k_s_N"] + " " + k["mode"] for k in rows],
+            "source": os.path.basename(paths[-1]) + " (standalone launches under rocprofv3 --pmc, SQ_VALU_MFMA_BUSY_CYCLES / 1024 "
+                                                    "SIMDs over GRBM_GUI_ACTIVE / 8 XCDs)"}
 
 
 def cpu_baseline(threads):
@@ -302,6 +334,7 @@ def main():
                                    if "split" in name else "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                     "traffic": hbm_traffic_from_profile(name),
+                    "pmc": pmc_from_profile(name),
                     "ratio_to_fp32_input_mfma_peak_NOT_a_roofline_fraction": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                     "traffic_source": "newest profiles/r*_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                       "passes, gfx950 x2 FETCH correction), bytes per launch",

@@ -157,6 +157,21 @@ int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_planes, const 
                            const float* bias, float* y, double* stats, unsigned* absmax, void* stream);
 int yolo_conv2d_dgrad_planes(const yolo_conv_desc* d, const void* dy_planes, const void* wT_planes,
                              float* dx, int accumulate, void* stream);
+/* Inference form with the fused epilogue of SURVEY.md section 8b (the folded BatchNormalization + activation of
+ * yolov3/models/backbone.py:39-55, yolov4/models/backbone.py:76-111 inside the convolution):
+ *   y = act(scale[c] * (conv(x, w) + bias[c]) + shift[c]) (+ residual)        scale / shift from yolo_bn_fold_inference
+ * epilogue = YOLO_EPI_NONE (plain conv, scale / shift ignored), _AFFINE (no activation), _AFFINE_LEAKY, _AFFINE_MISH;
+ * residual (optional) is a tensor laid out like y (the Add of a residual block). absmax (optional, uint32[Cout], zeroed
+ * by the caller) receives the bit patterns of the per-channel max|y| BEFORE the residual is added; yolo_split_planes_absmax
+ * turns y into the planes the next convolution reads, taking its bound from that vector (+ *extra_bound, the bound of
+ * the residual tensor) -- two launches per layer where the unfused path needs three (conv, bound, BN/activation).
+ * The arithmetic is the unfused path's (same fp32 operations in the same order): the fp32 result y is bit-identical. */
+enum { YOLO_EPI_NONE = 0, YOLO_EPI_AFFINE = 1, YOLO_EPI_AFFINE_LEAKY = 2, YOLO_EPI_AFFINE_MISH = 3 };
+int yolo_conv2d_fwd_planes_epi(const yolo_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                               int epilogue, const float* scale, const float* shift, const float* residual, float* y,
+                               unsigned* absmax, void* stream);
+int yolo_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax, const float* extra_bound,
+                             void* planes, float* out_bound, void* stream);
 /* yolo_conv2d_wgrad on pre-split operands (dw += ..., same contract; the bias gradient stays with
  * yolo_conv2d_wgrad_bias on the fp32 dy). Requires Cin % 16 == 0, Cout % 16 == 0, Cout >= 64, kh*kw*Cin >= 64. */
 int yolo_conv2d_wgrad_planes(const yolo_conv_desc* d, const void* x_planes, const void* dy_planes,

@@ -74,8 +74,10 @@ int main(int argc, char** argv) {
   hipStream_t st;
   CK(hipStreamCreate(&st));
   // key 99 = composite variant v: option 0 (window kernel) = v % 10, option 2 (stream-K form) = v / 10
+#define YOLO_SET(k, v) YK(yolo_set_option(k, v))
   auto set_variant = [&](int v) {
     if (key == 99) { YK(yolo_set_option(0, v % 10)); YK(yolo_set_option(2, v / 10)); }
+    else if (key == 97) { YOLO_SET(0, 1); YOLO_SET(4, v); }   // tile order of the window kernel: 0 auto, 1 column-fastest, 2 row-fastest
     else if (key == 98) { YK(yolo_set_option(0, 2)); YK(yolo_set_option(2, v / 10)); YK(yolo_set_option(3, v % 10)); }
     else YK(yolo_set_option(key, v));
   };

@@ -363,6 +363,65 @@ def test_conv_planes_scaling_stress(mode):
         assert (y - ref)[touched].abs().max().item() / ref[touched].abs().max().item() < TOL
 
 
+@pytest.mark.parametrize("act,with_res,case", [
+    ("leaky", False, (2, 13, 13, 64, 128, 3, 1, "same", False)),
+    ("leaky", True, (2, 26, 26, 128, 128, 3, 1, "same", False)),       # residual block: x + act(BN(conv(.)))
+    ("mish", True, (1, 19, 19, 64, 64, 3, 1, "same", False)),          # v4 CSP block
+    ("mish", False, (2, 16, 16, 32, 64, 1, 1, "same", True)),          # 1x1, conv bias in front of BN (v2 style)
+    ("leaky", False, (2, 17, 13, 32, 64, 3, 2, "darknet_s2", False)),  # down-sampling conv
+])
+def test_conv_fused_inference_epilogue(act, with_res, case):
+    """yolo_conv2d_fwd_planes_epi (affine+leaky / affine+mish epilogue): against the float64
+    oracle (conv2d -> batchnorm_infer -> leaky | mish [-> + residual]) at 1e-4, and BIT-identical to the unfused device
+    path (conv kernel, then yolo_bn_act_fwd) -- same fp32 operations in the same order; then yolo_split_planes_absmax:
+    the planes it produces feed a second convolution that must again match the oracle."""
+    from tf2_yolo_amd import ops
+    from tf2_yolo_amd._lib import ACT_LEAKY, ACT_MISH
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=51)
+    g = torch.Generator().manual_seed(52)
+    gamma = 1 + 0.2 * torch.randn(cout, generator=g, dtype=torch.float64)
+    beta = 0.1 * torch.randn(cout, generator=g, dtype=torch.float64)
+    mm = 0.1 * torch.randn(cout, generator=g, dtype=torch.float64)
+    mv = 0.5 + torch.rand(cout, generator=g, dtype=torch.float64)
+    yc = L.conv2d(x, wk, b, stride=s, padding=pad)
+    res = torch.randn(yc.shape, generator=g, dtype=torch.float64) if with_res else None
+    z = L.batchnorm_infer(yc, gamma, beta, mm, mv)
+    ref = (L.leaky(z) if act == "leaky" else L.mish(z)) + (res if with_res else 0)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    xd, wd = x.float().cuda(), _krsc(wk).float().cuda()
+    bd = None if b is None else b.float().cuda()
+    scale, shift = torch.empty(cout, device="cuda"), torch.empty(cout, device="cuda")
+    ops.bn_fold_inference(cout, gamma.float().cuda(), beta.float().cuda(), mm.float().cuda(), mv.float().cuda(), scale, shift)
+    xp, wp = ops.split_planes(xd, n * h * w, cin), ops.split_planes(wd, cout, k * k * cin)
+    resd = res.float().cuda() if with_res else None
+    amax = torch.zeros(cout, device="cuda", dtype=torch.int32)
+    epi = ops.EPI_AFFINE_LEAKY if act == "leaky" else ops.EPI_AFFINE_MISH
+    y = ops.conv2d_fwd_planes_epi(d, xp, wp, bd, epi, scale, shift, residual=resd, absmax=amax)
+    torch.cuda.synchronize()
+    assert _relerr(y.double().cpu(), ref) < TOL
+    # unfused device path
+    y0 = ops.conv2d_fwd_planes(d, xp, wp, bd)
+    a0 = ops.bn_act_fwd(y0, cout, scale, shift, ACT_LEAKY if act == "leaky" else ACT_MISH, residual=resd)
+    torch.cuda.synchronize()
+    assert torch.equal(y, a0)
+    # absmax = per-channel max of |act(BN(conv))| BEFORE the residual
+    pre = ops.bn_act_fwd(y0, cout, scale, shift, ACT_LEAKY if act == "leaky" else ACT_MISH)
+    assert torch.equal(amax.view(torch.float32), pre.reshape(-1, cout).abs().max(0).values)
+    # the planes of y for the next conv (bound = max of absmax (+ bound of the residual)); a 1x1 conv on them vs the oracle
+    rows = n * d.Ho * d.Wo
+    pl = torch.zeros(ops.planes_bytes(rows, cout), dtype=torch.uint8, device="cuda")
+    rb = torch.tensor([float(res.abs().max())], device="cuda") if with_res else None
+    ob = torch.zeros(1, device="cuda")
+    ops.split_planes_absmax(y, rows, cout, amax, pl, extra_bound=rb, out_bound=ob)
+    assert float(ob.item()) >= float(y.abs().max()) > 0
+    w2 = torch.randn(1, 1, cout, 64, generator=g, dtype=torch.float64) / cout ** 0.5
+    d2 = ops.conv_desc((n, d.Ho, d.Wo, cout), 64, 1, 1, 1, "same")
+    y2 = ops.conv2d_fwd_planes(d2, pl, ops.split_planes(_krsc(w2).float().cuda(), 64, cout))
+    torch.cuda.synchronize()
+    assert _relerr(y2.double().cpu(), L.conv2d(ref, w2, None, stride=1, padding="same")) < TOL
+
+
 def test_conv_planes_rejects_unsupported_shapes():
     from tf2_yolo_amd import ops
     from tf2_yolo_amd._lib import YoloHipError

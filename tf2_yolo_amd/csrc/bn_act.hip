@@ -6,41 +6,9 @@
 //   yolov3/models/backbone.py:39-71, yolov4/models/backbone.py:22-37,76-123,
 //   yolov{1_5,2}/models/backbone.py:9-18.
 #include "planes.hpp"
+#include "act.hpp"
 
 namespace yolo {
-
-// Mish(z) = z * tanh(softplus(z)) (yolov4/models/backbone.py:22-37). With e = exp(-|z|), exactly:
-//   z > 0:  tanh(softplus(z)) = (1 + 2e) / (1 + 2e + 2e^2),        1 - tanh = 2e^2 / (1 + 2e + 2e^2)
-//   z <= 0: tanh(softplus(z)) = (e^2 + 2e) / (e^2 + 2e + 2),       1 - tanh = 2 / (e^2 + 2e + 2)
-// (from tanh(log(1 + u)) = ((1+u)^2 - 1) / ((1+u)^2 + 1), u = e^z): one exp and one division instead of
-// log1p + exp + tanh, all terms positive (no cancellation for large |z|, where 1 - tanh^2 would lose every bit).
-struct MishParts {
-  float t, omt, e;   // tanh(softplus(z)), 1 - t, exp(-|z|)
-};
-__device__ __forceinline__ MishParts mish_parts(float z) {
-  const float e = expf(-fabsf(z));
-  const bool pos = z > 0.f;
-  const float e2 = e * e;
-  const float a = pos ? fmaf(2.f, e, 1.f) : fmaf(2.f, e, e2);   // numerator of t
-  const float b = pos ? 2.f * e2 : 2.f;                          // numerator of 1 - t
-  const float r = 1.f / (a + b);
-  return MishParts{a * r, b * r, e};
-}
-__device__ __forceinline__ float act_fwd(float z, int act) {
-  if (act == YOLO_ACT_LEAKY) return z > 0.f ? z : 0.1f * z;
-  if (act == YOLO_ACT_MISH) return z * mish_parts(z).t;
-  return z;
-}
-__device__ __forceinline__ float act_grad(float z, int act) {
-  if (act == YOLO_ACT_LEAKY) return z > 0.f ? 1.f : 0.1f;
-  if (act == YOLO_ACT_MISH) {
-    // d/dz [z t] = t + z (1 - t^2) sigmoid(z),  1 - t^2 = (1 - t)(1 + t),  sigmoid = 1/(1+e) or e/(1+e)
-    const MishParts m = mish_parts(z);
-    const float sg = (z > 0.f ? 1.f : m.e) / (1.f + m.e);
-    return fmaf(z * m.omt * (1.f + m.t), sg, m.t);
-  }
-  return 1.f;
-}
 
 // All per-channel reductions spread their fp64 atomics over YOLO_BN_STAT_SLOTS replicas of the [NQ][C]
 // result (replica = blockIdx.x mod SLOTS): 1024 blocks hammering the same 2C addresses ran at the

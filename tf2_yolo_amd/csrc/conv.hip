@@ -781,6 +781,40 @@ extern "C" int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_pla
   return launch_gather_planes(a, as_stream(stream));
 }
 
+// inference: y = act(scale[c] * (conv(x, w) + bias) + shift[c]) (+ residual); absmax = per-channel max of |y| before the
+// residual is added (the caller adds the residual tensor's bound)
+extern "C" int yolo_conv2d_fwd_planes_epi(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,
+                                          const float* bias, int epilogue, const float* scale, const float* shift,
+                                          const float* residual, float* y, unsigned* absmax, void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x_planes && w_planes && y, "conv_fwd_planes_epi: null pointer");
+  YOLO_REQUIRE(epilogue == YOLO_EPI_NONE || epilogue == YOLO_EPI_AFFINE_LEAKY || epilogue == YOLO_EPI_AFFINE_MISH ||
+               epilogue == YOLO_EPI_AFFINE, "conv_fwd_planes_epi: bad epilogue %d", epilogue);
+  YOLO_REQUIRE(epilogue == YOLO_EPI_NONE || (scale && shift), "conv_fwd_planes_epi: affine epilogue without scale / shift");
+  GatherConvArgs a{};
+  a.src = reinterpret_cast<const float*>(x_planes);
+  a.wgt = reinterpret_cast<const float*>(w_planes);
+  a.bias = bias;
+  a.dst = y;
+  fill_fwd_args(d, a);
+  a.stats = nullptr;
+  a.absmax = absmax;
+  if (epilogue != YOLO_EPI_NONE) {
+    a.epi_scale = scale;
+    a.epi_shift = shift;
+    a.epi_act = epilogue == YOLO_EPI_AFFINE_LEAKY ? YOLO_ACT_LEAKY : epilogue == YOLO_EPI_AFFINE_MISH ? YOLO_ACT_MISH : YOLO_ACT_LINEAR;
+  }
+  a.epi_res = residual;
+  YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_planes_epi: needs Cin %% 16 == 0 and Cout >= 32");
+  return launch_gather_planes(a, as_stream(stream));
+}
+
+extern "C" int yolo_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax,
+                                        const float* extra_bound, void* planes, float* out_bound, void* stream) {
+  YOLO_REQUIRE(x && planes && absmax, "split_planes_absmax: null pointer");
+  return launch_split_planes_absmax(x, rows, C, absmax, extra_bound, planes, out_bound, as_stream(stream));
+}
+
 extern "C" size_t yolo_planes_bytes(long long rows, int C) {
   if (rows <= 0 || C <= 0 || (C % 16) != 0) return 0;
   return (size_t)planes_bytes(rows, C);

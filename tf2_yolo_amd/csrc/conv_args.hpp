@@ -36,8 +36,15 @@ struct GatherConvArgs {
   int vec_store; // planes kernels, 128x128 tiles: output through LDS as dwordx4 rows (YOLO_VEC_STORE, default 1)
   int kc;        // planes kernels: 16-channel blocks per chunk of the stage order
   int dbg;       // planes kernels: diagnostic knock-outs (YOLO_PLANES_DBG), 0 in production
+  // fused inference epilogue of the planes kernels (planes_epilogue.hpp): dst = act(epi_scale[c] * y + epi_shift[c])
+  // (+ epi_res, a tensor laid out like dst); epi_scale == nullptr: plain y. absmax then holds max|dst| before the residual
+  const float* epi_scale;
+  const float* epi_shift;
+  const float* epi_res;
+  int epi_act;
   // conv_win.hip, stream-K form: workgroups of the launch (0 = one tile per workgroup), part slabs, tile tickets
   int sk_grid;
+  int tile_order;   // conv_win.hip: 0 = column tile fastest inside an XCD's run, 1 = row tile fastest
   float* sk_slabs;
   unsigned* sk_tickets;
   unsigned long long* stamps;  // diagnostic builds of conv_win.hip: 8 x u64 per workgroup (s_memtime / s_memrealtime)
@@ -80,6 +87,8 @@ bool gather_split_supported(const GatherConvArgs& a);
 // conv_planes.hip
 long long planes_bytes(long long rows, int C);
 int launch_split_planes(const float* x, long long rows, int C, void* planes, hipStream_t st);
+int launch_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax, const float* extra_bound,
+                               void* planes, float* out_bound, hipStream_t st);
 int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, void* planes, hipStream_t st);
 int launch_split_planes_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
@@ -90,7 +99,7 @@ bool gather_planes_supported(const GatherConvArgs& a);
 int launch_conv_win(GatherConvArgs& a, int variant, hipStream_t st);
 bool conv_win_supported(const GatherConvArgs& a);
 // run-time options (yolo_set_option; defaults from the environment): see runtime.hip
-enum { OPT_CONV_WIN = 0, OPT_STAMPS = 1, OPT_CONV_SK = 2, OPT_DBG = 3, OPT_COUNT = 16 };
+enum { OPT_CONV_WIN = 0, OPT_STAMPS = 1, OPT_CONV_SK = 2, OPT_DBG = 3, OPT_TILE_ORDER = 4, OPT_COUNT = 16 };
 int set_conv_workspace(void* p, size_t bytes, hipStream_t st);   // conv_win.hip
 extern void* g_dbg_buf;        // yolo_set_debug_buffer
 extern size_t g_dbg_bytes;

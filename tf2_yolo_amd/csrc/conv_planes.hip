@@ -64,6 +64,58 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
   }
 }
 
+// The same split with the bound taken from a per-channel max|x| vector (left by a conv epilogue) plus an optional
+// extra term (the bound of a residual that was added afterwards): every workgroup folds the C values itself, so the
+// inference path needs no separate bound kernel. Also leaves the bound in *out_bound (optional).
+__global__ __launch_bounds__(256) void split_planes_absmax_kernel(const float* __restrict__ x, long long rows, int C,
+                                                                 const unsigned* __restrict__ absmax,
+                                                                 const float* __restrict__ extra,
+                                                                 unsigned char* __restrict__ out, long long rows_padded,
+                                                                 float* __restrict__ out_bound) {
+  __shared__ float s_max[4];
+  float m = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, __builtin_bit_cast(float, absmax[c]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  __syncthreads();
+  const float bound = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])) * 1.001f + (extra ? extra[0] : 0.f) + 1e-30f;
+  unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
+  const float sc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bound));
+  const int G = C >> 3;
+  const int gbn = (G + 15) >> 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    header[0] = __builtin_bit_cast(unsigned, bound);
+    reinterpret_cast<float*>(header)[1] = sc;
+    reinterpret_cast<float*>(header)[2] = 1.f / sc;
+    if (out_bound != nullptr) out_bound[0] = bound;
+  }
+  const long long rb = blockIdx.x / gbn;
+  const int g = (int)(blockIdx.x - rb * gbn) * 16 + (threadIdx.x >> 4);
+  if (g >= G) return;
+  const long long row0 = rb * (16 * SPLIT_BLOCKS_PER_WG) + (threadIdx.x & 15);
+  f32x4 v[SPLIT_BLOCKS_PER_WG][2];
+#pragma unroll
+  for (int u = 0; u < SPLIT_BLOCKS_PER_WG; ++u) {
+    const long long row = row0 + 16 * u;
+    v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+      const float* p = x + row * C + g * 8;
+      v[u][0] = *reinterpret_cast<const f32x4*>(p);
+      v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < SPLIT_BLOCKS_PER_WG; ++u) {
+    const long long row = row0 + 16 * u;
+    if (row >= rows_padded) continue;
+    const Planes8 s = split8(v[u][0], v[u][1], sc);
+    unsigned char* o = out + planes_unit_offset(row, g, C);
+    *reinterpret_cast<u32x4*>(o) = s.h;
+    *reinterpret_cast<u32x4*>(o + 512) = s.l;
+  }
+}
+
 // Dense [rows][Csrc] source with Csrc < C = Csrc rounded up to 16 (the 255-channel head gradients): scalar loads,
 // columns >= Csrc of the planes are zero.
 __global__ __launch_bounds__(256) void planes_amax_scalar_kernel(const float* __restrict__ x, long long n,
@@ -596,6 +648,23 @@ int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, 
   hipLaunchKernelGGL(split_planes_padded_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, rows, Csrc, C, out,
                      rows_padded);
   return check_launch("split_planes_padded_kernel");
+}
+
+int launch_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax, const float* extra_bound,
+                               void* planes, float* out_bound, hipStream_t st) {
+  if (C % 16 != 0 || rows <= 0) {
+    set_error("split_planes_absmax: C %% 16 != 0 or rows <= 0");
+    return YOLO_ERR_INVALID_ARG;
+  }
+  const long long rows_padded = ((rows + 15) / 16 + 1) * 16;
+  const long long blocks = ((rows_padded / 16 + SPLIT_BLOCKS_PER_WG - 1) / SPLIT_BLOCKS_PER_WG) * ((C / 8 + 15) / 16);
+  if (blocks > 0x7fffffffLL) {
+    set_error("split_planes_absmax: tensor too large");
+    return YOLO_ERR_INVALID_ARG;
+  }
+  hipLaunchKernelGGL(split_planes_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, rows, C, absmax, extra_bound,
+                     reinterpret_cast<unsigned char*>(planes), rows_padded, out_bound);
+  return check_launch("split_planes_absmax_kernel");
 }
 
 int launch_split_planes(const float* x, long long rows, int C, void* planes, hipStream_t st) {

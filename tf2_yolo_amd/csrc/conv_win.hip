@@ -121,8 +121,12 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
   const int cb0 = u_cur - tile * cpt;                                   // first channel block of this part
   const int cb1 = (cpt - cb0 < u_end - u_cur) ? cpt : cb0 + (u_end - u_cur);   // one past the last
   u_cur += cb1 - cb0;
-  const int tile_n = tile % a.tiles_n;
-  const int tile_m = tile / a.tiles_n;
+  // tile order inside an XCD's run of tiles: column tile fastest (neighbours share the input window) or, for layers
+  // whose FILTER is the big operand (13x13: 18.9 MB, five L2s' worth), row tile fastest (neighbours stream the same
+  // 128 filters; the windows are small) -- launch_win() decides
+  const int tiles_m = a.nblocks / a.tiles_n;
+  const int tile_n = a.tile_order ? tile / tiles_m : tile % a.tiles_n;
+  const int tile_m = a.tile_order ? tile % tiles_m : tile / a.tiles_n;
   const long long m0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -350,10 +354,7 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
               f32x4 v = mine4;
               if (a.dbg == 1 && p != own) { v = f32x4{0.f, 0.f, 0.f, 0.f}; }            // diagnostic: own part only
               else if (a.dbg == 2 && p == own) { v = f32x4{0.f, 0.f, 0.f, 0.f}; }       // diagnostic: the other parts only
-              else if (p != own) {   // sc1 load: served by L2 / memory, never by this CU's L1
-                const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(slab_of(w_first + p), 0, SLAB_BYTES, 0x00020000);
-                v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rp, (unsigned)off, 0, 16));
-              }
+              else if (p != own) v = *reinterpret_cast<const f32x4*>(slab_of(w_first + p) + off);   // (behind the acquire)
               t = (p == 0) ? v : t + v;
             }
 #pragma unroll
@@ -490,20 +491,29 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
       resident = per_cu * cus;
   }
+  // filters of 8 MB and more (the 13x13 3x3 layers): row tile fastest. Measured on the 13x13x1024->512 data gradient
+  // (172 tiles, each streaming 4.7 MB of filters): 977 MB beyond-L2 per launch = 6 TB/s with the column tile fastest.
+  {
+    const long long wbytes = (long long)a.Cout * a.ldw * 4;
+    a.tile_order = g_opt[OPT_TILE_ORDER] == 0 ? (wbytes >= (8LL << 20) ? 1 : 0) : g_opt[OPT_TILE_ORDER] - 1;
+  }
   // stream-K: as many workgroups as the chip holds, each an equal share of the (tile, channel block) units
   a.sk_grid = 0;
   a.dbg = g_opt[OPT_DBG];
   unsigned grid = (unsigned)nb;
   // Policy (YOLO_CONV_SK / yolo_set_option key 2): 1 = automatic -- only launches that would leave most of the chip
-  // idle (fewer tiles than half the resident workgroups: small batches, e.g. the bs-1 inference forward, 16 tiles of
-  // 288 stages on a 13x13 layer), split into at most 8 parts per tile (the last arriver reads the other parts'
+  // idle (fewer tiles than half the resident workgroups AND at least 32 channel blocks per tile: the bs-1 inference
+  // forward of the 13x13 layers, 16 tiles of 288 stages), split into at most 4 parts per tile (the last arriver reads the other parts'
   // slabs: 64 KB each); at training sizes one workgroup per tile measured faster (the slab round trips cost more
   // than the ragged last round). A value > 1 forces that many workgroups (benchmarks).
-  const bool sk_auto = g_opt[OPT_CONV_SK] == 1 && nb * 2 < resident;
+  // (measured at bs 1: 13x13x512->1024, 16 tiles of 288 stages: 66 us -> 41 us with 4 parts per tile, 54 us with 8,
+  // 190 us with 32 -- the last arriver reads the other parts one after the other; layers with fewer than 32 channel
+  // blocks (26x26: 41 us, 52x52: 24 us) do not gain at any split)
+  const bool sk_auto = g_opt[OPT_CONV_SK] == 1 && nb * 2 < resident && (a.Cs >> 4) >= 32;
   if ((sk_auto || g_opt[OPT_CONV_SK] > 1) && resident > 0 && g_sk_ws != nullptr && nb <= (long long)SK_TICKETS) {
     long long G = g_opt[OPT_CONV_SK] > 1 ? g_opt[OPT_CONV_SK] : resident;
     const long long units = nb * (a.Cs >> 4);
-    if (sk_auto && G > nb * 8) G = nb * 8;
+    if (sk_auto && G > nb * 4) G = nb * 4;
     if (G > units) G = units;
     if (SK_TICKETS * 4 + (size_t)G * 2 * BM * 128 * 4 <= g_sk_bytes && G >= 1) {
       a.sk_grid = (int)G;

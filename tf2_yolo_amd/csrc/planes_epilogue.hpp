@@ -5,6 +5,7 @@
 // LDS_BYTES = bytes of `smem` the epilogue may use.
 #pragma once
 #include "planes.hpp"
+#include "act.hpp"
 
 namespace yolo {
 
@@ -81,12 +82,15 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
     float* strip = smf + FIXED + wave * (RP * TLD);
     constexpr int C4 = WCOLS / 4;                  // dwordx4 pieces per row of the sub-tile
     constexpr int ITER = RP * C4 / 64;
-    float bvj[TN];
+    float bvj[TN], escj[TN], eshj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
       bvj[j] = (a.bias != nullptr && col < a.Cout) ? a.bias[col] : 0.f;
+      escj[j] = (a.epi_scale != nullptr && col < a.Cout) ? a.epi_scale[col] : 1.f;
+      eshj[j] = (a.epi_scale != nullptr && col < a.Cout) ? a.epi_shift[col] : 0.f;
     }
+    const bool fused = a.epi_scale != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -97,7 +101,8 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
 #pragma unroll
           for (int q = hp * (RP / 2); q < (hp + 1) * (RP / 2); ++q) {
             const int rl = (q & 3) + 8 * ((q >> 2) - hp * (RP / 8)) + 4 * (lane >> 5);   // row inside the pass
-            const float v = fmaf(acc[i][j][q], unscale, bvj[j]);
+            float v = fmaf(acc[i][j][q], unscale, bvj[j]);
+            if (fused) v = act_fwd(fmaf(escj[j], v, eshj[j]), a.epi_act);
             strip[rl * TLD + j * 32 + (lane & 31)] = v;
             if (want_stats) {
               const float vm = (row0 + rl < rows_valid) ? v : 0.f;
@@ -125,6 +130,7 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
           if (offs[it] >= 0 && col < a.Cout) {
             f32x4* p = reinterpret_cast<f32x4*>(a.dst + offs[it] + col);
             f32x4 v = vv[it];
+            if (a.epi_res != nullptr) v += *reinterpret_cast<const f32x4*>(a.epi_res + offs[it] + col);
             if (a.accumulate) v += *p;
             if (a.nt_store) __builtin_nontemporal_store(v, p); else *p = v;
           }
@@ -146,16 +152,21 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
         const int col = n0 + (wn * TN + j) * 32 + (lane & 31);
         const bool cok = col < a.Cout;
         const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
+        const float esc = (a.epi_scale != nullptr && cok) ? a.epi_scale[col] : 1.f;
+        const float esh = (a.epi_scale != nullptr && cok) ? a.epi_shift[col] : 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const bool ok = cok && offs[q] >= 0;
           float v = fmaf(acc[i][j][q], unscale, bv);
+          if (a.epi_scale != nullptr) v = act_fwd(fmaf(esc, v, esh), a.epi_act);
+          const float vstat = v;           // statistics / max|.| before the residual (its bound is added by the caller)
           if (ok) {
+            if (a.epi_res != nullptr) v += a.epi_res[offs[q] + col];
             if (a.accumulate) v += a.dst[offs[q] + col];
             if constexpr ((DBG & 16) != 0) { if (v == 1234.5678f) a.dst[offs[q] + col] = v; }
             else if (a.nt_store) __builtin_nontemporal_store(v, &a.dst[offs[q] + col]); else a.dst[offs[q] + col] = v;
           }
-          const float vm = ok ? v : 0.f;
+          const float vm = ok ? (a.epi_scale != nullptr ? vstat : v) : 0.f;
           csum[j] += vm;
           csq[j] = fmaf(vm, vm, csq[j]);
           cmx[j] = fmaxf(cmx[j], fabsf(vm));

@@ -292,6 +292,7 @@ class Network:
         self._wT_valid = False
         self._overlap_wgrad = os.environ.get("YOLO_BWD_OVERLAP", "1") != "0"
         self._use_infer_graph = os.environ.get("YOLO_INFER_GRAPH", "1") != "0"
+        self._fuse_infer = os.environ.get("YOLO_INFER_FUSE", "1") != "0"
         self._infer_graphs = {}
         self._wgrad_stream = None
         self._wgrad_pending = False
@@ -619,6 +620,8 @@ class Network:
                                         scale, shift, smean, sinv, unbiased=self.unbiased_moving_var,
                                         bound=self._aux[u.aux_off:u.aux_off + 1],
                                         absmax=self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout])
+                    elif self._fuse_infer and self._fused_infer_unit(u, bias, gamma, beta, scale, shift):
+                        continue
                     else:
                         amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout]
                         if u.planes_fwd:
@@ -674,6 +677,32 @@ class Network:
         if not training:
             self._infer_scale_valid = True
         return [self.act[t.tid] for t in self.outputs]
+
+    def _fused_infer_unit(self, u, bias, gamma, beta, scale, shift):
+        """Inference form of a conv-BN-activation(-Add) unit in two launches (include/yolo_hip.h, fused epilogue): the
+        folded BatchNormalization, the activation and the residual Add run in the conv's epilogue, then ONE pass turns
+        the result into the planes of the consumer convolutions (bound = the epilogue's per-channel max + the
+        residual's bound). Returns False when the unit keeps the three-launch path (no planes operand / consumer)."""
+        if not u.planes_fwd or u.cout % 16 != 0:
+            return False
+        pl = self._xplanes.get(u.out.tid)
+        if pl is None or (u.residual is not None and u.residual.tid not in self._tbound_set):
+            return False
+        if not self._infer_scale_valid:
+            ops.bn_fold_inference(u.cout, gamma, beta, self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
+                                  scale, shift)
+        amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout]
+        res = self.act[u.residual.tid] if u.residual is not None else None
+        epi = {ACT_LEAKY: ops.EPI_AFFINE_LEAKY, ACT_MISH: ops.EPI_AFFINE_MISH}.get(u.act, ops.EPI_AFFINE)
+        ops.conv2d_fwd_planes_epi(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias, epi, scale,
+                                  shift, residual=res, out=u.a, absmax=amax)
+        tb = self._tbound
+        ops.split_planes_absmax(u.a, self.batch * u.out.h * u.out.w, u.cout, amax, pl,
+                                extra_bound=tb[u.residual.tid:u.residual.tid + 1] if u.residual is not None else None,
+                                out_bound=tb[u.out.tid:u.out.tid + 1])
+        self._tbound_set.add(u.out.tid)
+        self._xp_valid.add(u.out.tid)
+        return True
 
     # ---- backward -----------------------------------------------------------------------
     def _add_grad(self, grads, t, buf):

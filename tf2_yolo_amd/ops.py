@@ -292,6 +292,40 @@ def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None, absmax=None):
     return out
 
 
+EPI_NONE, EPI_AFFINE, EPI_AFFINE_LEAKY, EPI_AFFINE_MISH = 0, 1, 2, 3   # include/yolo_hip.h YOLO_EPI_*
+
+
+def conv2d_fwd_planes_epi(d, xp, wp, bias, epilogue, scale, shift, residual=None, out=None, absmax=None):
+    """inference: out = act(scale * (conv + bias) + shift) (+ residual) in ONE kernel (yolo_conv2d_fwd_planes_epi);
+    absmax: per-channel max|out| before the residual (bit patterns, zeroed by the caller)"""
+    _chk_f32(bias, scale, shift, residual)
+    if out is None:
+        out = torch.empty((d.N, d.Ho, d.Wo, d.Cout), device=xp.device, dtype=torch.float32)
+    if xp.numel() < planes_bytes(d.N * d.H * d.W, d.Cin) or wp.numel() < planes_bytes(d.Cout, d.kh * d.kw * d.Cin):
+        raise YoloHipError("conv2d_fwd_planes_epi: planes buffers do not match the descriptor")
+    if out.numel() != d.N * d.Ho * d.Wo * d.Cout or (residual is not None and residual.numel() != out.numel()):
+        raise YoloHipError("conv2d_fwd_planes_epi: output / residual size does not match the descriptor")
+    def run():
+        check(_lib.load().yolo_conv2d_fwd_planes_epi(byref(d), _p(xp), _p(wp), _p(bias), int(epilogue), _p(scale), _p(shift),
+                                                     _p(residual), _p(out), _p(absmax), _stream()),
+              "yolo_conv2d_fwd_planes_epi")
+    if TIMER is not None:
+        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin)), _conv_flops(d), 1, run)
+    else:
+        run()
+    return out
+
+
+def split_planes_absmax(x, rows, c, absmax, planes, extra_bound=None, out_bound=None):
+    """planes of x [rows][c] with the bound max_c absmax[c] (+ extra_bound[0]); yolo_split_planes_absmax"""
+    _chk_f32(x, extra_bound, out_bound)
+    if planes.numel() < planes_bytes(rows, c):
+        raise YoloHipError("split_planes_absmax: planes buffer too small")
+    check(_lib.load().yolo_split_planes_absmax(_p(x), rows, c, _p(absmax), _p(extra_bound), _p(planes), _p(out_bound),
+                                               _stream()), "yolo_split_planes_absmax")
+    return planes
+
+
 def conv2d_dgrad_planes(d, dyp, wTp, dx=None, accumulate=False):
     if dx is None:
         dx = torch.empty((d.N, d.H, d.W, d.Cin), device=dyp.device, dtype=torch.float32)
