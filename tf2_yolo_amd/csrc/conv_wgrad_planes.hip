@@ -271,8 +271,27 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   // Measured: 3x3 layers are flat from 1024 to 2048 workgroups, 1x1 layers (few pixels per split, the atomics
   // of 1024 workgroups cost as much as their MFMAs) run 25 % faster at 256.
   static const long long target_env = [] { const char* e = getenv("YOLO_WGRAD_TARGET"); return e ? atoll(e) : 0LL; }();
-  const long long target = target_env > 0 ? target_env : (a.ntaps == 1 ? 256 : 1024);
-  long long splits = (target + tiles - 1) / tiles;
+  // 3x3 layers: whole rounds of the workgroups the chip holds at once (occupancy x CUs): 1026 workgroups on 768
+  // slots are two rounds, the second a third full (52x52x128->256: 167 us; 756 workgroups: 154 us)
+  static int resident = 0;
+  if (resident == 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    constexpr size_t lds_q = 3 * (BM / 32 + BN / 32) * PL_PLANES * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN>),
+                                                     64 * WGM * WGN, lds_q) == hipSuccess &&
+        hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      resident = per_cu * cus;
+    if (resident <= 0) resident = 512;
+  }
+  long long target = target_env > 0 ? target_env : (a.ntaps == 1 ? 256 : 1024);
+  if (target_env <= 0 && a.ntaps > 1) {
+    const long long s1 = resident / tiles, s2 = 2LL * resident / tiles;
+    if (s1 >= 1 && tiles * s1 * 10 >= 7LL * resident) target = tiles * s1;         // one round, at least 70 % full
+    else if (s2 >= 1 && tiles * s2 * 10 >= 17LL * resident) target = tiles * s2;   // two rounds
+  }
+  long long splits = target / tiles > 0 ? (target_env > 0 || a.ntaps == 1 ? (target + tiles - 1) / tiles : target / tiles) : 1;
   const long long max_splits = (a.M + 255) / 256;  // at least 16 stages per workgroup
   if (splits > max_splits) splits = max_splits;
   if (splits > 65535) splits = 65535;
