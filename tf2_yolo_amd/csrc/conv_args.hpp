@@ -93,7 +93,6 @@ int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, 
 int launch_split_planes_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st);
-int launch_gather_planes16(GatherConvArgs& a, hipStream_t st);   // conv_planes16.hip (16x16x32 MFMA shape)
 bool gather_planes_supported(const GatherConvArgs& a);
 // conv_win.hip (3x3 stride-1 forward / data gradient with the input window kept in LDS); returns 1 = not covered
 int launch_conv_win(GatherConvArgs& a, int variant, hipStream_t st);

@@ -423,9 +423,6 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   static const int kc_env = [] { const char* e = getenv("YOLO_PLANES_KC"); return e ? atoi(e) : 0; }();
   a.kc = kc_env > 0 ? kc_env : (a.Cs >> 4);
   if (a.kc > (a.Cs >> 4)) a.kc = a.Cs >> 4;
-  // YOLO_PLANES_MFMA=16 selects the 16x16x32-MFMA build of the kernel (conv_planes16.hip): measured equal
-  static const int shape = [] { const char* e = getenv("YOLO_PLANES_MFMA"); return e ? atoi(e) : 32; }();
-  if (shape == 16 && a.Cout > 32) return launch_gather_planes16(a, st);
   // 3x3 stride-1 forward / data gradient: the kernel that keeps the input window in LDS (conv_win.hip)
   init_options();
   if (g_opt[OPT_CONV_WIN] != 0) {
