@@ -312,13 +312,13 @@ def main():
 
     dp_in_sync = None
     if world > 1 or force_dp:   # outside the timed region: every replica must hold bit-identical weights after K steps
-        chk = model.net.params.data.double().sum().reshape(1)
-        lo, hi = chk.clone(), chk.clone()
+        # element-wise: min over ranks == max over ranks for EVERY parameter (not one checksum)
+        lo, hi = model.net.params.data.clone(), model.net.params.data.clone()
         if backend != "nccl":
             lo, hi = lo.cpu(), hi.cpu()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        dp_in_sync = bool(lo.item() == hi.item())
+        dp_in_sync = bool(torch.equal(lo, hi))
 
     if rank == 0:
         roof = None

@@ -440,6 +440,15 @@ class Network:
     def allocate(self, N):
         if self.batch == N:
             return
+        # the planes kernels address their operands with 32-bit buffer offsets: say so HERE, with the largest batch
+        # that fits, instead of failing inside forward (use YOLO_CONV_PLANES=0, the exact register-staged kernels,
+        # for larger batches)
+        if ops.USE_PLANES:
+            worst = max((t.h * t.w * t.c * 4 for t in self.tensors), default=0)
+            if worst and N * worst + (1 << 20) >= (1 << 32):
+                raise YoloHipError(f"batch {N}: the largest activation ({worst / 2 ** 20:.1f} MiB per image) would exceed the "
+                                   f"4 GiB a planes operand may span; the largest batch for this model is "
+                                   f"{((1 << 32) - (1 << 20)) // worst - 1} (or set YOLO_CONV_PLANES=0)")
         self.batch = N
         self._infer_graphs = {}   # captured graphs point into the buffers re-allocated below
         self.act = {}
