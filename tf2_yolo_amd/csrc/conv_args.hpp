@@ -11,6 +11,23 @@ struct Tap {
   int oy, ox, woff;
 };
 
+// BatchNorm finalisation folded into the last tile of a planes convolution (planes_epilogue.hpp): ticket == nullptr = off
+struct BnFinalizeArgs {
+  const float* gamma;
+  const float* beta;
+  float* mmean;   // moving statistics, updated in place (nullptr: left alone)
+  float* mvar;
+  float* scale;
+  float* shift;
+  float* smean;
+  float* sinv;
+  unsigned* bound;   // optional: bit pattern of an upper bound of max|act(BN(y))| (zeroed by the caller)
+  unsigned* ticket;  // one u32, zero before the launch; the kernel leaves it at zero
+  long long P;
+  float eps, momentum;
+  int unbiased;
+};
+
 struct GatherConvArgs {
   const float* src;
   const float* wgt;
@@ -47,6 +64,8 @@ struct GatherConvArgs {
   int tile_order;   // conv_win.hip: 0 = column tile fastest inside an XCD's run, 1 = row tile fastest
   float* sk_slabs;
   unsigned* sk_tickets;
+  int stat_slots;   // replica slots of `stats` the tiles spread their atomics over (power of two <= YOLO_BN_STAT_SLOTS)
+  BnFinalizeArgs bnf;
   unsigned long long* stamps;  // diagnostic builds of conv_win.hip: 8 x u64 per workgroup (s_memtime / s_memrealtime)
   Tap taps[MAX_TAPS];
 };
