@@ -162,12 +162,19 @@ def _gpu_leaky_masks(net):
 
 # (version, BN moving variance fed Bessel-corrected [tf.keras fused BN, the default] or biased, C1 at its true size)
 @pytest.mark.parametrize("version,unbiased,true_c1", [(3, True, False), (2, True, False), (1, True, False), (4, True, False),
-                                                      (3, False, False), (1, True, True), (3, True, "tiny")])
+                                                      (3, False, False), (1, True, True), (3, True, "tiny"),
+                                                      (3, True, "416"), (4, True, "608")])
 def test_model_parity(version, unbiased, true_c1):
     from tf2_yolo_amd import optimizers
     if true_c1 == "tiny":   # tiny-YOLOv3 at 96x96: grids 3 and 6, the stride-1 'same' max-pool on a 3x3 map
         y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=96, N=4, unbiased=unbiased, tiny=True)
         assert len(model.output) == 2 and tuple(model.output[0].shape[1:3]) == (3, 3)
+    elif true_c1 == "416":   # BASELINE.json's headline graph at its true resolution (bs 2): 13 / 26 / 52 grids, the
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=416, N=2, unbiased=unbiased)   # window kernels' real shapes
+        assert [tuple(o.shape[1:3]) for o in model.output] == [(13, 13), (26, 26), (52, 52)]
+    elif true_c1 == "608":   # configs[2]: YOLOv4 CSPDarknet-53 + SPP + PAN at 608x608 (bs 2): 19 / 38 / 76 grids
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(4, hw=608, N=2, unbiased=unbiased)
+        assert sorted(tuple(o.shape[1:3]) for o in model.output) == [(19, 19), (38, 38), (76, 76)]
     elif true_c1:   # YOLOv1.5 224x224, 1 class, bs 4, B = 2: grid 4x4 -- BASELINE.json configs[0] as it is quoted
         y, model, fwd, loss_o, loss_g, x, ys = _setup(version, hw=112, N=4, unbiased=unbiased, true_c1=True)
         assert tuple(y.grid_shape) == (4, 4) and x.shape == (4, 224, 224, 3)
