@@ -51,7 +51,11 @@ int yolo_device_available(void);
 /* Run-time tuning / diagnostic switches of the library (no reference counterpart). key 0 = YOLO_OPT_CONV_WIN:
  * kernel used by yolo_conv2d_fwd_planes / _dgrad_planes for 3x3 stride-1 layers: 0 = per-tap streaming kernel,
  * 1 = input-window kernel with automatic tile choice, 2 / 4 = window kernel with 128x128 / 256x128 tiles.
- * Results are identical up to fp32 summation order. Defaults come from the environment (YOLO_CONV_WIN). */
+ * Results are identical up to fp32 summation order. Defaults come from the environment (YOLO_CONV_WIN).
+ * key 2 = YOLO_OPT_CONV_SK (YOLO_CONV_SK): what happens to launches whose tiles would leave most of the chip idle
+ * (bs-1 inference): 0 = nothing, 1 = split-K (every tile computed by up to 32 workgroups, a reduce kernel adds the parts
+ * in order and runs the epilogue), -1 = the stream-K form of the window kernel, > 1 = stream-K with that many workgroups.
+ * key -1 resets every option to its default. */
 enum { YOLO_OPT_CONV_WIN = 0, YOLO_OPT_STAMPS = 1, YOLO_OPT_CONV_SK = 2 };
 int yolo_set_option(int key, int value);
 /* Scratch for the persistent ("stream-K") form of the 3x3 window kernel (key 2 = YOLO_OPT_CONV_SK != 0): tile

@@ -266,12 +266,13 @@ WIN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("sk", [0, 1])
+@pytest.mark.parametrize("sk", [0, 1, -1, 5])
 @pytest.mark.parametrize("win", [2, 4])
 @pytest.mark.parametrize("case", WIN_CASES)
 def test_conv_window_kernel_fwd_dgrad(case, win, sk):
-    """sk = 1: the persistent stream-K form; at these sizes every workgroup gets ONE (tile, channel block) unit, so
-    every tile with more than one channel block is combined from as many parts as it has blocks"""
+    """sk = 0: one workgroup per tile; 1: split-K + reduce kernel (launches without statistics: the per-tap y0 and the
+    data gradients here); -1: the stream-K policy; 5: stream-K forced onto five workgroups (parts of a tile combined by
+    the last arriver, workgroups spanning tile boundaries)"""
     from tf2_yolo_amd import ops
     ops.ensure_conv_workspace()
     ops.set_option(ops.OPT_CONV_SK, sk)
@@ -315,8 +316,73 @@ def test_conv_window_kernel_fwd_dgrad(case, win, sk):
             torch.cuda.synchronize()
             assert _relerr(dx2.double().cpu(), 2 * x.grad) < TOL
     finally:
-        ops.set_option(ops.OPT_CONV_WIN, 0)
+        ops.reset_options()
+
+
+# ---- split-K of launches that leave most of the chip idle (bs-1 inference; conv_win.hip: conv_split_reduce_kernel) ----
+@pytest.mark.parametrize("case", [
+    (1, 13, 13, 512, 1024, 3, 1, "same", False),       # window kernel: 16 tiles x 16 parts
+    (1, 13, 13, 1024, 512, 1, 1, "same", True),        # per-tap kernel, 1x1: 8 tiles x 8 parts; bias
+    (1, 26, 26, 256, 512, 3, 1, "same", False),        # window kernel: 24 tiles x 8 parts
+    (2, 17, 13, 64, 128, 3, 2, "darknet_s2", False),   # per-tap kernel, stride 2: 4 parts of one channel block
+    (1, 19, 19, 80, 160, 3, 1, "same", True),          # 5 channel blocks (uneven parts), ragged column tile
+])
+def test_conv_split_k(case):
+    """YOLO_CONV_SK=1 (the default): every tile computed by several workgroups, the reduce kernel adds the parts in
+    order and runs the epilogue. Forward (plain, and with the fused inference epilogue + residual + per-channel max),
+    data gradient (plain and accumulating) against the float64 oracle at 1e-4 and against the unsplit launch at 1e-5;
+    two runs are bit-identical (ordered sum, no atomics on the values)."""
+    from tf2_yolo_amd import ops
+    from tf2_yolo_amd._lib import ACT_LEAKY
+    ops.ensure_conv_workspace()
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=71)
+    x.requires_grad_(True)
+    ref = L.conv2d(x, wk, b, stride=s, padding=pad)
+    g = torch.Generator().manual_seed(72)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    xd, wd = x.detach().float().cuda(), _krsc(wk).float().cuda()
+    bd = None if b is None else b.float().cuda()
+    xp, wp = ops.split_planes(xd, n * h * w, cin), ops.split_planes(wd, cout, k * k * cin)
+    scale = (1 + 0.2 * torch.randn(cout, generator=g)).cuda()
+    shift = (0.1 * torch.randn(cout, generator=g)).cuda()
+    res = torch.randn(ref.shape, generator=g).cuda()
+    wT = ops.filter_transpose(wd, cout, k * k, cin)
+    dyp = ops.split_planes(dy.float().cuda(), n * d.Ho * d.Wo, cout)
+    wTp = ops.split_planes(wT, cin, k * k * cout)
+
+    def run():
+        amax = torch.zeros(cout, device="cuda", dtype=torch.int32)
+        y = ops.conv2d_fwd_planes(d, xp, wp, bd)
+        ye = ops.conv2d_fwd_planes_epi(d, xp, wp, bd, ops.EPI_AFFINE_LEAKY, scale, shift, residual=res, absmax=amax)
+        dx = ops.conv2d_dgrad_planes(d, dyp, wTp)
+        dx2 = dx.clone()
+        ops.conv2d_dgrad_planes(d, dyp, wTp, dx=dx2, accumulate=True)
+        torch.cuda.synchronize()
+        return y, ye, dx, dx2, amax
+
+    try:
         ops.set_option(ops.OPT_CONV_SK, 0)
+        y0, ye0, dx0, dx20, amax0 = run()
+        ops.set_option(ops.OPT_CONV_SK, 1)
+        y, ye, dx, dx2, amax = run()
+        again = run()
+    finally:
+        ops.reset_options()
+    assert not torch.equal(y, y0) or not torch.equal(dx, dx0), "the split-K path did not run"
+    assert _relerr(y.double().cpu(), ref.detach()) < TOL and _relerr(dx.double().cpu(), x.grad) < TOL
+    assert _relerr(dx2.double().cpu(), 2 * x.grad) < TOL
+    z = L.leaky(ref.detach() * scale.double().cpu() + shift.double().cpu())
+    assert _relerr(ye.double().cpu(), z + res.double().cpu()) < TOL
+    for a, a0 in ((y, y0), (ye, ye0), (dx, dx0), (dx2, dx20)):
+        assert _relerr(a.double(), a0.double()) < 1e-5
+    # per-channel max|.| before the residual
+    pre = ops.bn_act_fwd(y, cout, scale, shift, ACT_LEAKY)
+    assert torch.equal(amax.view(torch.float32), pre.reshape(-1, cout).abs().max(0).values)
+    for a, a1 in zip((y, ye, dx, dx2, amax), again):
+        assert torch.equal(a, a1)
 
 
 # ---- the benchmark's own layer sizes against the float64 oracle (not against another device kernel) ----

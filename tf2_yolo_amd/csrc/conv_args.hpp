@@ -64,6 +64,10 @@ struct GatherConvArgs {
   int tile_order;   // conv_win.hip: 0 = column tile fastest inside an XCD's run, 1 = row tile fastest
   float* sk_slabs;
   unsigned* sk_tickets;
+  // split-K for launches that would leave most of the chip idle (bs-1 inference): split_parts > 1 = every tile is
+  // computed by that many workgroups (equal runs of 16-channel blocks), each writing its accumulators to slab
+  // (tile * split_parts + part) of sk_slabs; conv_split_reduce_kernel adds the parts in order and runs the epilogue
+  int split_parts;
   int stat_slots;   // replica slots of `stats` the tiles spread their atomics over (power of two <= YOLO_BN_STAT_SLOTS)
   BnFinalizeArgs bnf;
   unsigned long long* stamps;  // diagnostic builds of conv_win.hip: 8 x u64 per workgroup (s_memtime / s_memrealtime)
@@ -114,6 +118,9 @@ int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_b
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st);
 bool gather_planes_supported(const GatherConvArgs& a);
 // conv_win.hip (3x3 stride-1 forward / data gradient with the input window kept in LDS); returns 1 = not covered
+int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb);
+int launch_split_reduce(GatherConvArgs& a, int bm, hipStream_t st);
+float* conv_split_slabs();
 int launch_conv_win(GatherConvArgs& a, int variant, hipStream_t st);
 bool conv_win_supported(const GatherConvArgs& a);
 // run-time options (yolo_set_option; defaults from the environment): see runtime.hip

@@ -188,7 +188,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WGN, wn = wave % WGN;
 
-  const int tile = xcd_remap(blockIdx.x, a.nblocks);
+  // split-K (a.split_parts > 1, conv_win.hip: conv_split_reduce_kernel): grid = tiles x parts, part p of a tile
+  // contracts the 16-channel blocks [p * cpt / P, (p + 1) * cpt / P) of every tap and stores its accumulators to a slab
+  // (its own instantiation, DBG bit 32: inside the production kernel the slab path cost 44 registers = one wave per SIMD)
+  constexpr bool SPLIT = (DBG & 32) != 0;
+  const int SP = SPLIT ? a.split_parts : 1;
+  const int part = SPLIT ? (int)blockIdx.x / a.nblocks : 0;
+  const int tile = xcd_remap(SPLIT ? (int)blockIdx.x - part * a.nblocks : (int)blockIdx.x, a.nblocks);
   const int tile_n = tile % a.tiles_n;
   const int tile_m = tile / a.tiles_n;
   const long long m0 = (long long)tile_m * BM;
@@ -200,8 +206,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   const unsigned blkstrideA = (unsigned)((a.Cs >> 4) * PL_RECORD);
   const unsigned blkstrideB = (unsigned)((a.ldw >> 4) * PL_RECORD);
   const i32x4 rsrcA = planes_rsrc(a.src, a.src_bytes), rsrcB = planes_rsrc(a.wgt, a.wgt_bytes);
-  const int cpt = a.Cs >> 4;  // stages per tap
-  const int nk = a.ntaps * cpt;
+  const int cpt_all = a.Cs >> 4;  // 16-channel blocks per tap
+  const int cb_lo = (part * cpt_all) / SP;
+  const int cpt = ((part + 1) * cpt_all) / SP;   // one past my last channel block (the whole range without split-K)
+  const int nk = a.ntaps * (cpt - cb_lo);
 
   bool isA[LPW];
   int nimg[LPW], ys0[LPW], xs0[LPW];
@@ -235,7 +243,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   // plain tap-major order (every tap re-streams the whole input window: its lines have left L2 by the next tap
   // when 40+ workgroups share the 4 MB); a small kc makes the taps re-read the same few KB per pixel block
   // back to back while still streaming whole records. ----
-  int ld_tap = 0, ld_kk = 0, ld_cb = 0;   // tap, block inside the chunk, first block of the chunk
+  int ld_tap = 0, ld_kk = 0, ld_cb = cb_lo;   // tap, block inside the chunk, first block of the chunk
   auto loader_tap = [&]() {  // per-(chunk, tap) part of the source address (A: the shifted pixel, B: the filter tap)
 #pragma unroll
     for (int i = 0; i < LPW; ++i) {
@@ -372,7 +380,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the dummy tail DMAs too
   __syncthreads();  // every wave is done with the stage buffers: the epilogue reuses them
 
-  planes_epilogue<BM, BN, WGM, WGN, 3 * STAGE_BYTES, DBG>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
+  if constexpr (SPLIT)
+    store_split_slab<TM, TN>(a, acc, BM * BN * 4, tile * SP + part, wave, lane);
+  else
+    planes_epilogue<BM, BN, WGM, WGN, 3 * STAGE_BYTES, DBG>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
 }
 
 template <int BM, int BN, int WGM, int WGN, int DBG = 0>
@@ -391,6 +402,25 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN, DBG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
+  }
+  a.split_parts = 1;
+  if constexpr (BM == 128 && BN == 128 && WGM == 2 && WGN == 2 && DBG == 0) {
+    // at least 8 stages per part (a.kc = the whole channel range in one chunk is the default stage order)
+    const int min_cb = a.ntaps >= 8 ? 1 : (8 + a.ntaps - 1) / a.ntaps;
+    a.split_parts = conv_split_parts(a, nb, BM, min_cb);
+    if (a.split_parts > 1) {
+      a.sk_slabs = conv_split_slabs();
+      static bool attr32 = false;
+      if (!attr32) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN, 32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr32 = true;
+      }
+      hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN, 32>), dim3((unsigned)(nb * a.split_parts)),
+                         dim3(64 * WGM * WGN), lds, st, a);
+      if (int rc = check_launch("gather_conv_planes_kernel(split)")) return rc;
+      return launch_split_reduce(a, BM, st);
+    }
   }
   hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN, DBG>), dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
   return check_launch("gather_conv_planes_kernel");

@@ -112,8 +112,11 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
   const int sk_q = G > 0 ? (a.nblocks * cpt) / G : 0, sk_r = G > 0 ? (a.nblocks * cpt) % G : 0;
   auto first_unit = [&](int w) { return w * sk_q + (w < sk_r ? w : sk_r); };
   auto owner_of = [&](int u) { return u < sk_r * (sk_q + 1) ? u / (sk_q + 1) : sk_r + (u - sk_r * (sk_q + 1)) / sk_q; };
-  const int u_begin = G > 0 ? first_unit(wl) : wl * cpt;
-  const int u_end = G > 0 ? first_unit(wl + 1) : (wl + 1) * cpt;
+  // split_parts > 1 (split-K with a reduce kernel behind it): logical workgroup wl = tile * P + part computes the
+  // channel blocks [part * cpt / P, (part + 1) * cpt / P) of its tile and nothing else
+  const int SP = a.split_parts;
+  const int u_begin = SP > 1 ? (wl / SP) * cpt + ((wl % SP) * cpt) / SP : G > 0 ? first_unit(wl) : wl * cpt;
+  const int u_end = SP > 1 ? (wl / SP) * cpt + ((wl % SP + 1) * cpt) / SP : G > 0 ? first_unit(wl + 1) : (wl + 1) * cpt;
 
   for (int u_cur = u_begin; u_cur < u_end;) {
   take_stamp(0);
@@ -304,7 +307,10 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
   __syncthreads();  // every wave is done with the LDS: the epilogue reuses it
 
   bool finish = true;
-  if (cb1 - cb0 < cpt) {
+  if (SP > 1) {
+    store_split_slab<TM, TN>(a, acc, BM * BN * 4, wl, wave, lane);   // conv_split_reduce_kernel finishes the tile
+    finish = false;
+  } else if (cb1 - cb0 < cpt) {
     // ---- part of a tile: publish my accumulators, draw a ticket; the last arriver combines ----
     constexpr int SLAB_BYTES = BM * BN * 4;
     const int w_first = owner_of(tile * cpt), w_last = owner_of(tile * cpt + cpt - 1);
@@ -466,6 +472,133 @@ int set_conv_workspace(void* p, size_t bytes, hipStream_t st) {
   return YOLO_OK;
 }
 
+
+// ---- split-K for launches that leave most of the chip idle (bs-1 inference: 16 tiles of 288 stages on 256 CUs, every
+// workgroup a latency-bound stream of 8 KB stages) ----
+// The tiles are computed by `split_parts` workgroups each (equal runs of 16-channel blocks, conv_win_kernel and
+// gather_conv_planes_kernel<128,128,2,2>), every part stores its accumulators to its own slab, and this kernel adds
+// the parts of a tile IN PART ORDER (bitwise reproducible), then does what planes_epilogue does: unscale, bias,
+// optional fused BatchNorm + activation (+ residual), optional accumulate, per-channel max|y|. One thread per 16-byte
+// accumulator piece (4 rows x 1 column): the loads of all parts are independent, the stores of a wave cover 128-byte
+// row pieces. (The stream-K form above lets the LAST ARRIVER of a tile read the other parts one after the other:
+// fine for 4 parts, 190 us for 32.)
+template <int BM>
+__global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConvArgs a) {
+  constexpr int BN = 128, WGN = 2, TM = 2, TN = 2;
+  constexpr int QPT = BM * BN / 4;   // 16-byte pieces per tile
+  constexpr int BPT = QPT / 256;     // workgroups per tile
+  const int tile = blockIdx.x / BPT;
+  const int qi = (blockIdx.x - tile * BPT) * 256 + threadIdx.x;
+  const int lane = qi & 63, q4 = (qi >> 6) & 3, j = (qi >> 8) & 1, i = (qi >> 9) & 1, wave = qi >> 10;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int tile_n = tile % a.tiles_n, tile_m = tile / a.tiles_n;
+  const int col = tile_n * BN + (wn * TN + j) * 32 + (lane & 31);
+  const long long mrow = (long long)tile_m * BM + (wm * TM + i) * 32 + 8 * q4 + 4 * (lane >> 5);
+  // (a workgroup = the four q4 pieces of ONE 32 x 32 accumulator block: 32 columns x 32 rows)
+  const bool active = col < a.Cout && mrow < a.M;
+  float mx = 0.f;
+  if (active) {
+  const int P = a.split_parts;
+  const f32x4* sl = reinterpret_cast<const f32x4*>(a.sk_slabs) + (size_t)tile * P * QPT + qi;
+  // the loads of up to 16 parts fly together (each is a miss: the slabs were written a kernel ago by other CUs; four at a
+  // time made this kernel a chain of eight round trips, 21 us); the additions stay in part order
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  int p = 0;
+  for (; p + 16 <= P; p += 16) {
+    f32x4 v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = sl[(size_t)(p + u) * QPT];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t = t + v[u];
+  }
+  for (; p + 4 <= P; p += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = sl[(size_t)(p + u) * QPT];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t = t + v[u];
+  }
+  for (; p < P; ++p) t = t + sl[(size_t)p * QPT];
+  const float unscale =
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2] *
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wgt) + a.wgt_bytes - PL_HEADER)[2];
+  const float bv = a.bias != nullptr ? a.bias[col] : 0.f;
+  const bool fused = a.epi_scale != nullptr;
+  const float esc = fused ? a.epi_scale[col] : 1.f, esh = fused ? a.epi_shift[col] : 0.f;
+  const bool dense = a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Hd == a.Hg && a.Wd == a.Wg;
+  const int HgWg = a.Hg * a.Wg;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long long m = mrow + e;
+    if (m < a.M) {
+      long long off;
+      if (dense) {
+        off = m * a.Cd;
+      } else {
+        const int n = (int)(m / HgWg);
+        const int rem = (int)(m - (long long)n * HgWg);
+        const int y = rem / a.Wg;
+        const int x = rem - y * a.Wg;
+        off = (((long long)n * a.Hd + (y * a.osy + a.ooy)) * a.Wd + (x * a.osx + a.oox)) * a.Cd;
+      }
+      float v = fmaf(t[e], unscale, bv);
+      if (fused) v = act_fwd(fmaf(esc, v, esh), a.epi_act);
+      const float vstat = v;     // max|.| before the residual, as planes_epilogue
+      if (a.epi_res != nullptr) v += a.epi_res[off + col];
+      if (a.accumulate) v += a.dst[off + col];
+      a.dst[off + col] = v;
+      mx = fmaxf(mx, fabsf(fused ? vstat : v));
+    }
+  }
+  }
+  if (a.absmax != nullptr) {
+    // one atomic per column and workgroup (256 same-address atomics from eight XCDs per column made this kernel 21 us)
+    __shared__ float smx[256];
+    smx[threadIdx.x] = mx;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      float m8 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m8 = fmaxf(m8, smx[threadIdx.x + 32 * u]);
+      if (col < a.Cout && __builtin_bit_cast(unsigned, m8) > a.absmax[col])
+        atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, m8));
+    }
+  }
+}
+
+// Parts per tile for a launch of nb tiles of bm x 128 (1 = do not split). Only launches without BatchNorm statistics
+// whose tiles would fill less than a quarter of the chip (at bs 32 the 13x13 layers have 172 tiles: +-0 to -8 % with two
+// parts, left alone), each part at least min_cb channel blocks long, as many parts as
+// it takes to give every CU two workgroups, at most 32; needs the workspace of yolo_set_conv_workspace.
+int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb) {
+  init_options();
+  if (g_opt[OPT_CONV_SK] != 1 || a.stats != nullptr || g_sk_ws == nullptr) return 1;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+  }
+  const long long slots = 2LL * cus;
+  if (nb * 4 > slots) return 1;
+  long long P = (a.Cs >> 4) / min_cb;
+  if (P > slots / nb) P = slots / nb;
+  if (P > 32) P = 32;
+  if (P < 2) return 1;
+  if (SK_TICKETS * 4 + (size_t)(nb * P) * bm * 128 * 4 > g_sk_bytes) return 1;
+  return (int)P;
+}
+
+int launch_split_reduce(GatherConvArgs& a, int bm, hipStream_t st) {
+  if (bm == 128)
+    hipLaunchKernelGGL(conv_split_reduce_kernel<128>, dim3((unsigned)a.nblocks * (128 * 128 / 4 / 256)), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(conv_split_reduce_kernel<256>, dim3((unsigned)a.nblocks * (256 * 128 / 4 / 256)), dim3(256), 0, st, a);
+  return check_launch("conv_split_reduce_kernel");
+}
+
+float* conv_split_slabs() { return reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(g_sk_ws) + SK_TICKETS * 4); }
+
 template <int WGM, int NCH>
 static int launch_win(GatherConvArgs& a, hipStream_t st) {
   constexpr int BM = 64 * WGM;
@@ -509,7 +642,17 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
   // (measured at bs 1: 13x13x512->1024, 16 tiles of 288 stages: 66 us -> 41 us with 4 parts per tile, 54 us with 8,
   // 190 us with 32 -- the last arriver reads the other parts one after the other; layers with fewer than 32 channel
   // blocks (26x26: 41 us, 52x52: 24 us) do not gain at any split)
-  const bool sk_auto = g_opt[OPT_CONV_SK] == 1 && nb * 2 < resident && (a.Cs >> 4) >= 32;
+  // YOLO_CONV_SK=1 (default): split-K with the reduce kernel (conv_split_parts); -1: the stream-K policy above
+  a.split_parts = WGM == 2 ? conv_split_parts(a, nb, BM, 2) : 1;
+  if (a.split_parts > 1) {
+    a.tile_order = 0;
+    a.sk_grid = (int)(nb * a.split_parts);
+    a.sk_slabs = conv_split_slabs();
+    hipLaunchKernelGGL((conv_win_kernel<WGM, NCH>), dim3((unsigned)a.sk_grid), dim3(128 * WGM), lds, st, a);
+    if (int rc = check_launch("conv_win_kernel(split)")) return rc;
+    return launch_split_reduce(a, BM, st);
+  }
+  const bool sk_auto = g_opt[OPT_CONV_SK] == -1 && nb * 2 < resident && (a.Cs >> 4) >= 32;
   if ((sk_auto || g_opt[OPT_CONV_SK] > 1) && resident > 0 && g_sk_ws != nullptr && nb <= (long long)SK_TICKETS) {
     long long G = g_opt[OPT_CONV_SK] > 1 ? g_opt[OPT_CONV_SK] : resident;
     const long long units = nb * (a.Cs >> 4);

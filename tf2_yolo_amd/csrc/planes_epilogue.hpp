@@ -13,6 +13,27 @@ struct NoStamp {
   __device__ __forceinline__ void operator()(int) const {}
 };
 
+// split-K (GatherConvArgs::split_parts > 1): a part's accumulators go to its slab in accumulator order --
+// 16-byte piece ((wave * TM + i) * TN + j) * 4 + q4 of lane l at byte (piece * 64 + l) * 16 -- for
+// conv_split_reduce_kernel (conv_win.hip), which adds the parts of a tile in part order and runs the epilogue
+template <int TM, int TN>
+__device__ __forceinline__ void store_split_slab(const GatherConvArgs& a, f32x16 (&acc)[TM][TN], const int slab_bytes,
+                                                 const int slab, const int wave, const int lane) {
+  unsigned char* mine = reinterpret_cast<unsigned char*>(a.sk_slabs) + (size_t)slab * slab_bytes;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(mine, 0, slab_bytes, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        // (bit_cast of the whole vector: hipcc 7.2 miscompiles __builtin_bit_cast applied to an ext-vector ELEMENT)
+        const f32x4 f = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f), rs,
+                                               (((wave * TM + i) * TN + j) * 4 + q4) * 1024 + lane * 16, 0, 0);
+      }
+}
+
 template <int BM, int BN, int WGM, int WGN, int LDS_BYTES, int DBG = 0, class STAMP = NoStamp>
 __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
                                                 unsigned char* smem, const long long m0, const int n0, const int tile_m,

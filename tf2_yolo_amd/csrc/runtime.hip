@@ -19,21 +19,31 @@ void set_error(const char* fmt, ...) {
 int g_opt[OPT_COUNT];
 void* g_dbg_buf = nullptr;
 size_t g_dbg_bytes = 0;
+static void options_from_env() {
+  for (int i = 0; i < OPT_COUNT; ++i) g_opt[i] = 0;
+  const char* e = getenv("YOLO_CONV_WIN");       // 0 off, 1 automatic, 2 force 128x128 tiles, 4 force 256x128 tiles
+  g_opt[OPT_CONV_WIN] = e ? atoi(e) : 1;
+  // launches that would leave most of the chip idle (needs yolo_set_conv_workspace): 0 = one workgroup per tile,
+  // 1 = split-K with a reduce kernel (window and per-tap kernels), -1 = stream-K form of the window kernel (tile
+  // tickets, the last arriver combines), > 1 = stream-K with that many workgroups (benchmarks, tests)
+  e = getenv("YOLO_CONV_SK");
+  g_opt[OPT_CONV_SK] = e ? atoi(e) : 1;
+}
 void init_options() {
   static bool done = false;
   if (done) return;
   done = true;
-  for (int i = 0; i < OPT_COUNT; ++i) g_opt[i] = 0;
-  const char* e = getenv("YOLO_CONV_WIN");       // 0 off, 1 automatic, 2 force 128x128 tiles, 4 force 256x128 tiles
-  g_opt[OPT_CONV_WIN] = e ? atoi(e) : 1;
-  e = getenv("YOLO_CONV_SK");                    // stream-K form of the window kernel: 0 off, 1 automatic (small
-  g_opt[OPT_CONV_SK] = e ? atoi(e) : 1;          // launches only; needs yolo_set_conv_workspace), > 1 forced grid
+  options_from_env();
 }
 
 }  // namespace yolo
 
 extern "C" int yolo_set_option(int key, int value) {
   yolo::init_options();
+  if (key == -1) {   // back to the defaults (environment)
+    yolo::options_from_env();
+    return YOLO_OK;
+  }
   if (key < 0 || key >= yolo::OPT_COUNT) {
     yolo::set_error("yolo_set_option: unknown key %d", key);
     return YOLO_ERR_INVALID_ARG;

@@ -143,6 +143,11 @@ def set_option(key, value):
     check(_lib.load().yolo_set_option(int(key), int(value)), "yolo_set_option")
 
 
+def reset_options():
+    """every option back to its default (the YOLO_* environment variables)"""
+    check(_lib.load().yolo_set_option(-1, 0), "yolo_set_option")
+
+
 def _stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
