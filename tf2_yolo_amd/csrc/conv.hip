@@ -877,6 +877,50 @@ static int dgrad_impl(const yolo_conv_desc* d, const float* dy, const float* wT,
   const bool flat = (d->Cout % 32) != 0;
   YOLO_REQUIRE(!flat || (d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1),
                "conv_dgrad: Cout %% 32 != 0 only supported for 1x1 stride-1 (head) convs");
+  // planes kernels, stride 2: ONE launch for the four parity classes (each class alone re-streams all of dy: 354 MB four
+  // times for the 416 -> 208 layer at bs 32). YOLO_DGRAD_CLASSES=0: one launch per class, as the fp32 kernels do.
+  static const bool fuse_classes = [] { const char* e = getenv("YOLO_DGRAD_CLASSES"); return !(e && atoi(e) == 0); }();
+  if (planes && fuse_classes && d->sh * d->sw > 1 && d->sh * d->sw <= 4) {
+    GatherConvArgs a{};
+    a.src = dy;
+    a.wgt = wT;
+    a.dst = dx;
+    a.N = d->N; a.Hs = d->Ho; a.Ws = d->Wo; a.Cs = d->Cout;
+    a.sy = 1; a.sx = 1;
+    a.Hd = d->H; a.Wd = d->W; a.Cd = d->Cin;
+    a.osy = d->sh; a.osx = d->sw;
+    a.Cout = d->Cin;
+    a.ldw = d->kh * d->kw * d->Cout;
+    a.accumulate = accumulate;
+    a.kw = 1;
+    int nt = 0, nc = 0;
+    bool ok = true;
+    for (int py = 0; py < d->sh && ok; ++py)
+      for (int px = 0; px < d->sw && ok; ++px) {
+        ClassGeom& c = a.cls[nc++];
+        c.Hg = (d->H - py + d->sh - 1) / d->sh;
+        c.Wg = (d->W - px + d->sw - 1) / d->sw;
+        c.M = (long long)d->N * c.Hg * c.Wg;
+        c.ooy = py; c.oox = px; c.tap0 = nt; c.ntaps = 0;
+        for (int r = 0; r < d->kh; ++r) {
+          const int ty = py + d->pad_t - r;
+          if (((ty % d->sh) + d->sh) % d->sh != 0) continue;
+          for (int s = 0; s < d->kw; ++s) {
+            const int tx = px + d->pad_l - s;
+            if (((tx % d->sw) + d->sw) % d->sw != 0) continue;
+            a.taps[nt++] = Tap{ty / d->sh, tx / d->sw, (r * d->kw + s) * d->Cout};
+            ++c.ntaps;
+          }
+        }
+        if (c.ntaps == 0 || c.Hg <= 0 || c.Wg <= 0) ok = false;   // (a class without taps: the per-class path below)
+      }
+    if (ok) {
+      a.ncls = nc;
+      a.M = a.cls[0].M; a.Hg = a.cls[0].Hg; a.Wg = a.cls[0].Wg; a.ooy = 0; a.oox = 0; a.ntaps = a.cls[0].ntaps;
+      YOLO_REQUIRE(gather_planes_supported(a), "conv_dgrad_planes: needs Cout %% 16 == 0 and Cin >= 32");
+      return launch_gather_planes(a, as_stream(stream));
+    }
+  }
   for (int py = 0; py < d->sh; ++py) {
     for (int px = 0; px < d->sw; ++px) {
       GatherConvArgs a{};

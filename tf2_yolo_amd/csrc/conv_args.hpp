@@ -28,6 +28,13 @@ struct BnFinalizeArgs {
   int unbiased;
 };
 
+// One launch for the stride x stride parity classes of a strided data gradient (conv.hip: dgrad_impl): class c computes the
+// output pixels (y * osy + ooy, x * osx + oox) of its own Hg x Wg grid from its own taps [tap0, tap0 + ntaps)
+struct ClassGeom {
+  long long M;
+  int Hg, Wg, ooy, oox, tap0, ntaps;
+};
+
 struct GatherConvArgs {
   const float* src;
   const float* wgt;
@@ -68,6 +75,10 @@ struct GatherConvArgs {
   // computed by that many workgroups (equal runs of 16-channel blocks), each writing its accumulators to slab
   // (tile * split_parts + part) of sk_slabs; conv_split_reduce_kernel adds the parts in order and runs the epilogue
   int split_parts;
+  // ncls > 1 (planes kernels, per-tap form): the tile index is (row tile, class, column tile); the classes of a pixel
+  // block sit next to each other in an XCD's run of tiles, so the rows of `src` they share come from HBM once
+  int ncls;
+  ClassGeom cls[4];
   int stat_slots;   // replica slots of `stats` the tiles spread their atomics over (power of two <= YOLO_BN_STAT_SLOTS)
   BnFinalizeArgs bnf;
   unsigned long long* stamps;  // diagnostic builds of conv_win.hip: 8 x u64 per workgroup (s_memtime / s_memrealtime)

@@ -3,6 +3,7 @@
 // arithmetic, no ds_write and no VGPR staging -- only DMA issue, fragment reads and the 3 fp16 MFMA passes
 // (l*h, h*l, h*h) per 32x32 fragment pair; the epilogue undoes the two power-of-two operand scales.
 #include "planes_epilogue.hpp"
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -202,11 +203,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   const int SP = SPLIT ? a.split_parts : 1;
   const int part = SPLIT ? (int)blockIdx.x / a.nblocks : 0;
   const int tile = xcd_remap(SPLIT ? (int)blockIdx.x - part * a.nblocks : (int)blockIdx.x, a.nblocks);
+  // multi-class launch (its own instantiation, DBG bit 64; a.ncls parity classes of a strided data gradient): tile =
+  // (row tile, class, column tile); everything that depends on the output grid comes from the class
+  constexpr bool MULTI = (DBG & 64) != 0;
   const int tile_n = tile % a.tiles_n;
-  const int tile_m = tile / a.tiles_n;
+  const int cls = MULTI ? (tile / a.tiles_n) % a.ncls : 0;
+  const int tile_m = MULTI ? tile / (a.tiles_n * a.ncls) : tile / a.tiles_n;
   const long long m0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
-  const int HgWg = a.Hg * a.Wg;
+  const EpiGeom G = MULTI ? EpiGeom{a.cls[cls].M, a.cls[cls].Hg, a.cls[cls].Wg, a.cls[cls].ooy, a.cls[cls].oox} : epi_geom_of(a);
+  const int tap0 = MULTI ? a.cls[cls].tap0 : 0;
+  const int ntaps = MULTI ? a.cls[cls].ntaps : a.ntaps;
+  if (MULTI && m0 >= G.M) return;   // (classes of an odd-sized image have different tile counts)
+  const int HgWg = G.Hg * G.Wg;
 
   // ---- loader role(s) ----
   const int r = lane & 31, hf = lane >> 5;
@@ -216,7 +225,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   const int cpt_all = a.Cs >> 4;  // 16-channel blocks per tap
   const int cb_lo = (part * cpt_all) / SP;
   const int cpt = ((part + 1) * cpt_all) / SP;   // one past my last channel block (the whole range without split-K)
-  const int nk = a.ntaps * (cpt - cb_lo);
+  const int nk = ntaps * (cpt - cb_lo);
 
   bool isA[LPW];
   int nimg[LPW], ys0[LPW], xs0[LPW];
@@ -229,12 +238,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
     nimg[i] = 0; ys0[i] = -(1 << 28); xs0[i] = 0; rowbaseB[i] = 0;
     if (isA[i]) {
       const long long m = m0 + rb * 32 + r;
-      if (m < a.M) {
+      if (m < G.M) {
         nimg[i] = (int)(m / HgWg);
         const int rem = (int)(m - (long long)nimg[i] * HgWg);
-        const int y = rem / a.Wg;
+        const int y = rem / G.Wg;
         ys0[i] = y * a.sy;
-        xs0[i] = (rem - y * a.Wg) * a.sx;
+        xs0[i] = (rem - y * G.Wg) * a.sx;
       }
     } else {
       const int co = n0 + rb * 32 + r;
@@ -258,14 +267,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
         ld_voff[i] = isA[i] ? (unsigned)a.zero_blk_src * blkstrideA : (unsigned)a.zero_blk_wgt * blkstrideB;
         ld_soff[i] = 0;
       } else if (isA[i]) {
-        const int ys = ys0[i] + a.taps[ld_tap].oy, xs = xs0[i] + a.taps[ld_tap].ox;
+        const int ys = ys0[i] + a.taps[tap0 + ld_tap].oy, xs = xs0[i] + a.taps[tap0 + ld_tap].ox;
         const bool ok = ((unsigned)ys < (unsigned)a.Hs) && ((unsigned)xs < (unsigned)a.Ws);
         const int pix = (nimg[i] * a.Hs + ys) * a.Ws + xs;
         ld_voff[i] = (ok ? ((unsigned)pix >> 4) : (unsigned)a.zero_blk_src) * blkstrideA + (ok ? (pix & 15) * 16 : 0) + hf * 256;
         ld_soff[i] = (unsigned)ld_cb * PL_RECORD;
       } else {
         ld_voff[i] = rowbaseB[i];
-        ld_soff[i] = (unsigned)((a.taps[ld_tap].woff >> 4) + ld_cb) * PL_RECORD;
+        ld_soff[i] = (unsigned)((a.taps[tap0 + ld_tap].woff >> 4) + ld_cb) * PL_RECORD;
       }
     }
   };
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
     const int kc_cur = (cpt - ld_cb < a.kc) ? (cpt - ld_cb) : a.kc;
     if (++ld_kk >= kc_cur) {
       ld_kk = 0;
-      if (++ld_tap == a.ntaps) {
+      if (++ld_tap == ntaps) {
         ld_tap = 0;
         ld_cb += a.kc;
       }
@@ -389,6 +398,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
 
   if constexpr (SPLIT)
     store_split_slab<TM, TN>(a, acc, BM * BN * 4, tile * SP + part, wave, lane);
+  else if constexpr (MULTI)
+    planes_epilogue<BM, BN, WGM, WGN, 3 * STAGE_BYTES, 0>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid, NoStamp(), &G);
   else
     planes_epilogue<BM, BN, WGM, WGN, 3 * STAGE_BYTES, DBG>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
 }
@@ -402,8 +413,29 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
     set_error("conv(planes): bad grid %lld", nb);
     return YOLO_ERR_INVALID_ARG;
   }
-  a.nblocks = (int)nb;
   constexpr size_t lds = 3 * (BM / 32 + BN / 32) * PL_PLANES * 1024;
+  if constexpr (DBG == 0) {
+    if (a.ncls > 1) {   // the parity classes of a strided data gradient in one launch
+      long long tm = 0;
+      for (int c = 0; c < a.ncls; ++c) tm = std::max(tm, (a.cls[c].M + BM - 1) / BM);
+      const long long nbm = tm * a.ncls * a.tiles_n;
+      if (nbm <= 0 || nbm > 0x7fffffffLL) {
+        set_error("conv(planes): bad grid %lld", nbm);
+        return YOLO_ERR_INVALID_ARG;
+      }
+      a.nblocks = (int)nbm;
+      a.split_parts = 1;
+      static bool attr64 = false;
+      if (!attr64) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN, 64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr64 = true;
+      }
+      hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN, 64>), dim3((unsigned)nbm), dim3(64 * WGM * WGN), lds, st, a);
+      return check_launch("gather_conv_planes_kernel(classes)");
+    }
+  }
+  a.nblocks = (int)nb;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN, DBG>),
@@ -463,7 +495,7 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   if (a.kc > (a.Cs >> 4)) a.kc = a.Cs >> 4;
   // 3x3 stride-1 forward / data gradient: the kernel that keeps the input window in LDS (conv_win.hip)
   init_options();
-  if (g_opt[OPT_CONV_WIN] != 0) {
+  if (g_opt[OPT_CONV_WIN] != 0 && a.ncls <= 1) {
     const int rc = launch_conv_win(a, g_opt[OPT_CONV_WIN], st);
     if (rc <= 0) return rc;
   }

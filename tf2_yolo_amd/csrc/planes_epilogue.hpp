@@ -13,6 +13,13 @@ struct NoStamp {
   __device__ __forceinline__ void operator()(int) const {}
 };
 
+// output geometry of the tile: the launch's (GatherConvArgs) or, in a multi-class launch, the class's
+struct EpiGeom {
+  long long M;
+  int Hg, Wg, ooy, oox;
+};
+__device__ __forceinline__ EpiGeom epi_geom_of(const GatherConvArgs& a) { return EpiGeom{a.M, a.Hg, a.Wg, a.ooy, a.oox}; }
+
 // split-K (GatherConvArgs::split_parts > 1): a part's accumulators go to its slab in accumulator order --
 // 16-byte piece ((wave * TM + i) * TN + j) * 4 + q4 of lane l at byte (piece * 64 + l) * 16 -- for
 // conv_split_reduce_kernel (conv_win.hip), which adds the parts of a tile in part order and runs the epilogue
@@ -38,7 +45,8 @@ template <int BM, int BN, int WGM, int WGN, int LDS_BYTES, int DBG = 0, class ST
 __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
                                                 unsigned char* smem, const long long m0, const int n0, const int tile_m,
                                                 const int wm, const int wn, const int lane, const int tid,
-                                                const STAMP& stampf = STAMP()) {
+                                                const STAMP& stampf = STAMP(), const EpiGeom* geom = nullptr) {
+  const EpiGeom G = geom != nullptr ? *geom : epi_geom_of(a);
   constexpr int NT = 64 * WGM * WGN;
   constexpr int NW = WGM * WGN;
   constexpr int TM = BM / WGM / 32;
@@ -48,21 +56,21 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
   long long* rowoff = reinterpret_cast<long long*>(smf);
   // offset (in floats) of every tile row in dst (-1: the row does not exist). Dense outputs (the forward pass and
   // stride-1 data gradients: output pixel m IS row m of dst) need no divisions.
-  const bool dense = a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Hd == a.Hg && a.Wd == a.Wg;
+  const bool dense = a.osy == 1 && a.osx == 1 && G.ooy == 0 && G.oox == 0 && a.Hd == G.Hg && a.Wd == G.Wg;
   {
-    const int HgWg = a.Hg * a.Wg;
+    const int HgWg = G.Hg * G.Wg;
     for (int rr = tid; rr < BM; rr += NT) {
       const long long m = m0 + rr;
       long long off = -1;
-      if (m < a.M) {
+      if (m < G.M) {
         if (dense) {
           off = m * a.Cd;
         } else {
           const int n = (int)(m / HgWg);
           const int rem = (int)(m - (long long)n * HgWg);
-          const int y = rem / a.Wg;
-          const int x = rem - y * a.Wg;
-          off = (((long long)n * a.Hd + (y * a.osy + a.ooy)) * a.Wd + (x * a.osx + a.oox)) * a.Cd;
+          const int y = rem / G.Wg;
+          const int x = rem - y * G.Wg;
+          off = (((long long)n * a.Hd + (y * a.osy + G.ooy)) * a.Wd + (x * a.osx + G.oox)) * a.Cd;
         }
       }
       rowoff[rr] = off;
@@ -82,7 +90,7 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
   asm volatile("" ::"v"(unscale));
   stampf(1);
   // rows of this tile that exist (the last row tile of a tensor is partial): row r of the tile is real iff r < rows_valid
-  const int rows_valid = (a.M - m0 < (long long)BM) ? (int)(a.M - m0) : BM;
+  const int rows_valid = (G.M - m0 < (long long)BM) ? (int)(G.M - m0) : BM;
   const bool want_stats = a.stats != nullptr || a.absmax != nullptr;   // (data gradients, inference: none)
   // Vector path. The C/D layout of the 32x32 MFMA leaves a lane with ONE column and 16 scattered rows of its
   // sub-tile (64 dword stores per lane, 128-B row pieces); every wave instead transposes its own sub-tile through a
