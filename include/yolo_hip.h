@@ -90,8 +90,6 @@ typedef struct yolo_conv_desc {
 /* BatchNorm statistics buffers hold YOLO_BN_STAT_SLOTS replicas of [2*C] doubles (sum, sum of
  * squares); producers spread their atomics over the replicas, yolo_bn_finalize adds them up. */
 #define YOLO_BN_STAT_SLOTS 64
-/* yolo_conv2d_fwd_planes_bn spreads its statistics over this many of those slots (the tile that finishes last sums them) */
-#define YOLO_BN_FUSED_SLOTS 8
 /* The backward reduction buffer `red` of yolo_bn_act_bwd_* holds YOLO_BN_RED_SLOTS per-workgroup partial
  * results of [2*C] doubles (every workgroup stores its own slot: no atomics, no zeroing needed) followed by
  * the final [2*C] sums: (YOLO_BN_RED_SLOTS + 1) * 2 * C doubles. */
@@ -163,16 +161,6 @@ int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_planes, const 
                            const float* bias, float* y, double* stats, unsigned* absmax, void* stream);
 int yolo_conv2d_dgrad_planes(const yolo_conv_desc* d, const void* dy_planes, const void* wT_planes,
                              float* dx, int accumulate, void* stream);
-/* Training forward of a Conv2D + BatchNormalization unit in ONE launch (yolov3/models/backbone.py:27-55): the
- * convolution with the statistics epilogue of yolo_conv2d_fwd_planes, and yolo_bn_finalize_bound's arithmetic done by
- * whichever output tile finishes last (a ticket; nobody waits). stats: double[YOLO_BN_FUSED_SLOTS][2*Cout], zeroed;
- * absmax: uint32[Cout], zeroed (optional); bound: one zeroed uint32 (optional); ticket: one zeroed uint32 the kernel
- * leaves at zero. The remaining arguments are yolo_bn_finalize_bound's. */
-int yolo_conv2d_fwd_planes_bn(const yolo_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
-                              float* y, double* stats, unsigned* absmax, const float* gamma, const float* beta,
-                              float eps, float momentum, int unbiased_moving_var, float* moving_mean,
-                              float* moving_var, float* scale, float* shift, float* save_mean, float* save_invstd,
-                              unsigned* bound, unsigned* ticket, void* stream);
 /* Inference form with the fused epilogue of SURVEY.md section 8b (the folded BatchNormalization + activation of
  * yolov3/models/backbone.py:39-55, yolov4/models/backbone.py:76-111 inside the convolution):
  *   y = act(scale[c] * (conv(x, w) + bias[c]) + shift[c]) (+ residual)        scale / shift from yolo_bn_fold_inference

@@ -517,71 +517,6 @@ def test_conv_fused_inference_epilogue(act, with_res, case):
     assert _relerr(y2.double().cpu(), L.conv2d(ref, w2, None, stride=1, padding="same")) < TOL
 
 
-@pytest.mark.parametrize("unbiased", [True, False])
-@pytest.mark.parametrize("case", [
-    (2, 13, 13, 64, 128, 3, 1, "same", False),       # window kernel, few tiles
-    (2, 52, 52, 64, 128, 3, 1, "same", False),       # window kernel, 43 tiles
-    (2, 26, 26, 512, 256, 3, 1, "same", False),      # window kernel, stream-K eligible (32 channel blocks)
-    (2, 26, 26, 128, 64, 1, 1, "same", True),        # per-tap kernel, 128 x 64 tiles, conv bias in front of BN
-    (3, 17, 13, 32, 96, 3, 2, "darknet_s2", False),  # stride 2, ragged column tile (Cout = 96)
-    (1, 13, 13, 512, 1024, 1, 1, "same", False),     # 1024 channels for one finishing workgroup
-])
-def test_conv_bn_finalize_in_the_last_tile(case, unbiased):
-    """yolo_conv2d_fwd_planes_bn: conv + statistics + BatchNorm finalisation in one launch (the tile that draws the last
-    ticket finalises). Against the two-launch device path (yolo_conv2d_fwd_planes, yolo_bn_finalize_bound) -- y bit-
-    identical, per-channel results to 1e-6 (the replica slots are summed in another order) -- and against the float64
-    oracle's batch statistics; run twice on the same buffers: the ticket must be back at zero."""
-    from tf2_yolo_amd import ops
-    n, h, w, cin, cout, k, s, pad, bias = case
-    x, wk, b = _mk(case, seed=61)
-    g = torch.Generator().manual_seed(62)
-    gamma = (1 + 0.2 * torch.randn(cout, generator=g)).cuda()
-    beta = (0.1 * torch.randn(cout, generator=g)).cuda()
-    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
-    xd, wd = x.float().cuda(), _krsc(wk).float().cuda()
-    bd = None if b is None else b.float().cuda()
-    xp, wp = ops.split_planes(xd, n * h * w, cin), ops.split_planes(wd, cout, k * k * cin)
-    P = n * d.Ho * d.Wo
-
-    def two_launches():
-        st = torch.zeros(ops.BN_STAT_SLOTS * 2 * cout, device="cuda", dtype=torch.float64)
-        amax = torch.zeros(cout, device="cuda", dtype=torch.int32)
-        bound = torch.zeros(1, device="cuda", dtype=torch.int32)
-        mm, mv = torch.full((cout,), 0.25, device="cuda"), torch.full((cout,), 2.0, device="cuda")
-        v = [torch.empty(cout, device="cuda") for _ in range(4)]
-        y = ops.conv2d_fwd_planes(d, xp, wp, bd, stats=st, absmax=amax)
-        ops.bn_finalize(st, P, cout, gamma, beta, mm, mv, *v, unbiased=unbiased, bound=bound, absmax=amax)
-        return y, v, mm, mv, bound, amax
-
-    st = torch.zeros(ops.BN_STAT_SLOTS * 2 * cout, device="cuda", dtype=torch.float64)
-    amax = torch.zeros(cout, device="cuda", dtype=torch.int32)
-    bound = torch.zeros(1, device="cuda", dtype=torch.int32)
-    ticket = torch.zeros(1, device="cuda", dtype=torch.int32)
-    y0, v0, mm0, mv0, bound0, amax0 = two_launches()
-    for rep in range(2):
-        st.zero_(); amax.zero_(); bound.zero_()
-        mm, mv = torch.full((cout,), 0.25, device="cuda"), torch.full((cout,), 2.0, device="cuda")
-        v = [torch.full((cout,), float("nan"), device="cuda") for _ in range(4)]
-        y = torch.empty_like(y0)
-        ops.conv2d_fwd_planes_bn(d, xp, wp, bd, y, st, amax, gamma, beta, mm, mv, *v, ticket, unbiased=unbiased, bound=bound)
-        torch.cuda.synchronize()
-        assert int(ticket.item()) == 0
-        assert torch.equal(y, y0) and torch.equal(amax, amax0)
-        for a, b0, name in zip(v + [mm, mv], v0 + [mm0, mv0], ("scale", "shift", "mean", "invstd", "mmean", "mvar")):
-            assert torch.isfinite(a).all(), name
-            err = ((a - b0).abs().max() / b0.abs().max().clamp_min(1e-30)).item()
-            assert err < 1e-6, (name, err)
-        rel = abs(float(bound.view(torch.float32)) / float(bound0.view(torch.float32)) - 1)
-        assert rel < 1e-6, rel
-    # the oracle's batch statistics (float64)
-    yc = L.conv2d(x, wk, b, stride=s, padding=pad).reshape(-1, cout)
-    mean, var = yc.mean(0), yc.var(0, unbiased=False)
-    assert ((v[2].double().cpu() - mean).abs().max() / yc.abs().max()).item() < TOL
-    assert ((v[3].double().cpu() - 1 / torch.sqrt(var + 1e-3)).abs().max() * torch.sqrt(var + 1e-3).max()).item() < 10 * TOL
-    fed = var * (P / (P - 1)) if unbiased else var
-    assert _relerr(mv.double().cpu(), 0.99 * 2.0 + 0.01 * fed) < TOL
-
-
 def test_conv_planes_rejects_unsupported_shapes():
     from tf2_yolo_amd import ops
     from tf2_yolo_amd._lib import YoloHipError

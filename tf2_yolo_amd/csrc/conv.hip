@@ -781,34 +781,6 @@ extern "C" int yolo_conv2d_fwd_planes(const yolo_conv_desc* d, const void* x_pla
   return launch_gather_planes(a, as_stream(stream));
 }
 
-// training forward of a conv + BatchNorm unit in ONE launch: the convolution with the statistics epilogue, and the
-// finalisation (yolo_bn_finalize_bound's arithmetic) done by whichever tile finishes last. `stats` needs only
-// YOLO_BN_FUSED_SLOTS replica slots (zeroed), `ticket` is one zeroed u32 that the kernel leaves at zero.
-extern "C" int yolo_conv2d_fwd_planes_bn(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,
-                                         const float* bias, float* y, double* stats, unsigned* absmax,
-                                         const float* gamma, const float* beta, float eps, float momentum,
-                                         int unbiased_moving_var, float* moving_mean, float* moving_var, float* scale,
-                                         float* shift, float* save_mean, float* save_invstd, unsigned* bound,
-                                         unsigned* ticket, void* stream) {
-  if (int rc = validate_desc(d)) return rc;
-  YOLO_REQUIRE(x_planes && w_planes && y && stats && gamma && beta && scale && shift && save_mean && save_invstd && ticket,
-               "conv_fwd_planes_bn: null pointer");
-  YOLO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "conv_fwd_planes_bn: moving stats must come in pairs");
-  GatherConvArgs a{};
-  a.src = reinterpret_cast<const float*>(x_planes);
-  a.wgt = reinterpret_cast<const float*>(w_planes);
-  a.bias = bias;
-  a.dst = y;
-  fill_fwd_args(d, a);
-  a.stats = stats;
-  a.absmax = absmax;
-  a.stat_slots = YOLO_BN_FUSED_SLOTS;
-  a.bnf = BnFinalizeArgs{gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd, bound, ticket,
-                         a.M, eps, momentum, unbiased_moving_var};
-  YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_planes_bn: needs Cin %% 16 == 0 and Cout >= 32");
-  return launch_gather_planes(a, as_stream(stream));
-}
-
 // inference: y = act(scale[c] * (conv(x, w) + bias) + shift[c]) (+ residual); absmax = per-channel max of |y| before the
 // residual is added (the caller adds the residual tensor's bound)
 extern "C" int yolo_conv2d_fwd_planes_epi(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,

@@ -11,23 +11,6 @@ struct Tap {
   int oy, ox, woff;
 };
 
-// BatchNorm finalisation folded into the last tile of a planes convolution (planes_epilogue.hpp): ticket == nullptr = off
-struct BnFinalizeArgs {
-  const float* gamma;
-  const float* beta;
-  float* mmean;   // moving statistics, updated in place (nullptr: left alone)
-  float* mvar;
-  float* scale;
-  float* shift;
-  float* smean;
-  float* sinv;
-  unsigned* bound;   // optional: bit pattern of an upper bound of max|act(BN(y))| (zeroed by the caller)
-  unsigned* ticket;  // one u32, zero before the launch; the kernel leaves it at zero
-  long long P;
-  float eps, momentum;
-  int unbiased;
-};
-
 // One launch for the stride x stride parity classes of a strided data gradient (conv.hip: dgrad_impl): class c computes the
 // output pixels (y * osy + ooy, x * osx + oox) of its own Hg x Wg grid from its own taps [tap0, tap0 + ntaps)
 struct ClassGeom {
@@ -79,8 +62,6 @@ struct GatherConvArgs {
   // block sit next to each other in an XCD's run of tiles, so the rows of `src` they share come from HBM once
   int ncls;
   ClassGeom cls[4];
-  int stat_slots;   // replica slots of `stats` the tiles spread their atomics over (power of two <= YOLO_BN_STAT_SLOTS)
-  BnFinalizeArgs bnf;
   unsigned long long* stamps;  // diagnostic builds of conv_win.hip: 8 x u64 per workgroup (s_memtime / s_memrealtime)
   Tap taps[MAX_TAPS];
 };

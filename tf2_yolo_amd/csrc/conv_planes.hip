@@ -482,7 +482,6 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   a.zero_blk_wgt = (a.Cout + 15) / 16;
   static const int nt = [] { const char* e = getenv("YOLO_NT_STORE"); return e ? atoi(e) : 1; }();
   a.nt_store = nt;
-  if (a.stat_slots == 0) a.stat_slots = YOLO_BN_STAT_SLOTS;
   static const int vecst = [] { const char* e = getenv("YOLO_VEC_STORE"); return e ? atoi(e) : 1; }();
   // (the wave-private staging of planes_epilogue.hpp has no workgroup barriers: used at every size)
   a.vec_store = vecst;

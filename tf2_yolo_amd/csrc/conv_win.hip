@@ -50,7 +50,10 @@
 namespace yolo {
 
 // WGM x 2 waves of 64x64: tile (64*WGM) x 128. NCH = window chunks of 64 pixels (LDS: 2 x NCH x 4 KB + 24 KB).
-template <int WGM, int NCH, bool STAMPS = false>
+// SPLIT: the split-K instantiation (every workgroup one part of one tile, accumulators to a slab, no epilogue). Its own
+// kernel because the slab path inside the production instantiation tripled its scratch (152 -> 440-496 bytes per lane)
+// and made every window launch of the training step 10-40 % slower.
+template <int WGM, int NCH, bool STAMPS = false, bool SPLIT = false>
 __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConvArgs a) {
   constexpr int WGN = 2;
   constexpr int BM = 64 * WGM, BN = 128;
@@ -114,9 +117,9 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
   auto owner_of = [&](int u) { return u < sk_r * (sk_q + 1) ? u / (sk_q + 1) : sk_r + (u - sk_r * (sk_q + 1)) / sk_q; };
   // split_parts > 1 (split-K with a reduce kernel behind it): logical workgroup wl = tile * P + part computes the
   // channel blocks [part * cpt / P, (part + 1) * cpt / P) of its tile and nothing else
-  const int SP = a.split_parts;
-  const int u_begin = SP > 1 ? (wl / SP) * cpt + ((wl % SP) * cpt) / SP : G > 0 ? first_unit(wl) : wl * cpt;
-  const int u_end = SP > 1 ? (wl / SP) * cpt + ((wl % SP + 1) * cpt) / SP : G > 0 ? first_unit(wl + 1) : (wl + 1) * cpt;
+  const int SP = SPLIT ? a.split_parts : 1;
+  const int u_begin = SPLIT ? (wl / SP) * cpt + ((wl % SP) * cpt) / SP : G > 0 ? first_unit(wl) : wl * cpt;
+  const int u_end = SPLIT ? (wl / SP) * cpt + ((wl % SP + 1) * cpt) / SP : G > 0 ? first_unit(wl + 1) : (wl + 1) * cpt;
 
   for (int u_cur = u_begin; u_cur < u_end;) {
   take_stamp(0);
@@ -306,11 +309,10 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail DMAs too
   __syncthreads();  // every wave is done with the LDS: the epilogue reuses it
 
-  bool finish = true;
-  if (SP > 1) {
-    store_split_slab<TM, TN>(a, acc, BM * BN * 4, wl, wave, lane);   // conv_split_reduce_kernel finishes the tile
-    finish = false;
-  } else if (cb1 - cb0 < cpt) {
+  bool finish = !SPLIT;
+  if constexpr (SPLIT) store_split_slab<TM, TN>(a, acc, BM * BN * 4, wl, wave, lane);   // conv_split_reduce_kernel finishes the tile
+  if constexpr (!SPLIT)
+  if (cb1 - cb0 < cpt) {
     // ---- part of a tile: publish my accumulators, draw a ticket; the last arriver combines ----
     constexpr int SLAB_BYTES = BM * BN * 4;
     const int w_first = owner_of(tile * cpt), w_last = owner_of(tile * cpt + cpt - 1);
@@ -392,8 +394,9 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
       epi_sum[5] += es[5] - es[4];     // stores, half 1
       ++epi_count;
     }
-  } else
-  if (finish) planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
+  } else if constexpr (!SPLIT) {
+    if (finish) planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
+  }
   __syncthreads();   // the next part's DMAs overwrite the LDS the epilogue used
   if constexpr (STAMPS) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the diagnostic build waits for its output stores)
@@ -648,7 +651,15 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
     a.tile_order = 0;
     a.sk_grid = (int)(nb * a.split_parts);
     a.sk_slabs = conv_split_slabs();
-    hipLaunchKernelGGL((conv_win_kernel<WGM, NCH>), dim3((unsigned)a.sk_grid), dim3(128 * WGM), lds, st, a);
+    if constexpr (WGM == 2) {
+      static bool attr_split = false;
+      if (!attr_split) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<WGM, NCH, false, true>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_split = true;
+      }
+      hipLaunchKernelGGL((conv_win_kernel<WGM, NCH, false, true>), dim3((unsigned)a.sk_grid), dim3(128 * WGM), lds, st, a);
+    }
     if (int rc = check_launch("conv_win_kernel(split)")) return rc;
     return launch_split_reduce(a, BM, st);
   }

@@ -228,63 +228,13 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
           mx = fmaxf(mx, sred[(w * BN + c) * 3 + 2]);
         }
         if (a.stats != nullptr) {
-          double* slot = a.stats + (long long)(tile_m & (a.stat_slots - 1)) * 2 * a.Cout;
+          double* slot = a.stats + (long long)(tile_m & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
           atomicAdd(&slot[col], (double)s1);
           atomicAdd(&slot[a.Cout + col], (double)s2);
         }
         // per-channel max|y| (bit patterns of non-negative floats order like integers); most tiles skip the atomic
         if (a.absmax != nullptr && __builtin_bit_cast(unsigned, mx) > a.absmax[col])
           atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, mx));
-      }
-    }
-    if (a.bnf.ticket != nullptr) {
-      // BatchNorm finalisation without a kernel of its own: every tile draws a ticket once its atomics have been
-      // performed at the L2; whoever draws the last one reads the few replica slots and writes scale / shift / saved
-      // and moving statistics / the output bound (the arithmetic of bn_finalize_kernel, bn_act.hip). Nobody waits.
-      unsigned* word = reinterpret_cast<unsigned*>(smem);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();     // (also: sred has been consumed)
-      if (tid == 0) *word = __hip_atomic_fetch_add(a.bnf.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      if (*word == (unsigned)(a.nblocks - 1)) {
-        if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __syncthreads();
-        const BnFinalizeArgs& f = a.bnf;
-        const int C = a.Cout;
-        float bnd = 0.f;
-        for (int c = tid; c < C; c += NT) {
-          double s1 = 0.0, s2 = 0.0;
-          for (int s = 0; s < a.stat_slots; ++s) {
-            s1 += a.stats[(long long)s * 2 * C + c];
-            s2 += a.stats[(long long)s * 2 * C + C + c];
-          }
-          const double mean = s1 / (double)f.P;
-          double var = s2 / (double)f.P - mean * mean;
-          if (var < 0.0) var = 0.0;
-          const double inv = 1.0 / sqrt(var + (double)f.eps);
-          const double g = (double)f.gamma[c], b = (double)f.beta[c];
-          f.scale[c] = (float)(g * inv);
-          f.shift[c] = (float)(b - mean * g * inv);
-          f.smean[c] = (float)mean;
-          f.sinv[c] = (float)inv;
-          if (f.bound != nullptr) {
-            const double dev = a.absmax != nullptr ? (double)__builtin_bit_cast(float, a.absmax[c]) + fabs(mean)
-                                                   : sqrt((double)f.P * var);
-            bnd = fmaxf(bnd, (float)(fabs(g) * inv * dev * 1.001 + fabs(b) + 1e-30));
-          }
-          if (f.mmean != nullptr) {
-            double fed = var;
-            if (f.unbiased && f.P > 1) fed = var * (double)f.P / (double)(f.P - 1);
-            f.mmean[c] = (float)((double)f.momentum * f.mmean[c] + (1.0 - (double)f.momentum) * mean);
-            f.mvar[c] = (float)((double)f.momentum * f.mvar[c] + (1.0 - (double)f.momentum) * fed);
-          }
-        }
-        if (f.bound != nullptr) {
-#pragma unroll
-          for (int o = 32; o > 0; o >>= 1) bnd = fmaxf(bnd, __shfl_xor(bnd, o, 64));
-          if (lane == 0 && bnd > 0.f) atomicMax(f.bound, __builtin_bit_cast(unsigned, bnd));
-        }
-        if (tid == 0) __hip_atomic_store(f.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }

@@ -295,9 +295,6 @@ class Network:
         self._wp_event = self._wT_event = None
         self._use_infer_graph = os.environ.get("YOLO_INFER_GRAPH", "1") != "0"
         self._fuse_infer = os.environ.get("YOLO_INFER_FUSE", "1") != "0"
-        # conv + BN finalisation in one launch (yolo_conv2d_fwd_planes_bn). Off by default: measured 4 % SLOWER in the
-        # step -- the one workgroup that finalises costs more than the tiny kernel it replaces
-        self._bn_ticket = os.environ.get("YOLO_BN_TICKET", "0") != "0"
         self._infer_graphs = {}
         self._wgrad_stream = None
         self._wgrad_pending = False
@@ -383,7 +380,6 @@ class Network:
         off = 0
         for u in self.units:
             u.aux_off = off       # [0] forward bound, [1..68] = the 68 words of yolo_bn_act_bwd_reduce_bound,
-                                  # [70] the ticket of yolo_conv2d_fwd_planes_bn,
             off += 72             # [72 .. 72+C) = per-channel max|conv out| from the conv epilogue
             if u.kind == "conv" and u.bn:
                 off += (u.cout + 7) // 8 * 8
@@ -648,16 +644,7 @@ class Network:
                 if u.bn:
                     scale, shift, smean, sinv, stats, _ = self._bn_bufs(u)
                     gamma, beta = P.view(u.p_gamma.name), P.view(u.p_beta.name)
-                    if training and u.planes_fwd and self._bn_ticket:
-                        # the statistics' finalisation rides in the convolution's last tile: one launch, not two
-                        ops.conv2d_fwd_planes_bn(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes],
-                                                 bias, u.y, stats, self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout],
-                                                 gamma, beta, self.state.view(u.s_mean.name),
-                                                 self.state.view(u.s_var.name), scale, shift, smean, sinv,
-                                                 self._aux[u.aux_off + 70:u.aux_off + 71],
-                                                 unbiased=self.unbiased_moving_var,
-                                                 bound=self._aux[u.aux_off:u.aux_off + 1])
-                    elif training:
+                    if training:
                         self._conv_fwd(u, xin, w, bias, u.y, stats)
                         ops.bn_finalize(stats, u.y.numel() // u.cout, u.cout, gamma, beta,
                                         self.state.view(u.s_mean.name), self.state.view(u.s_var.name),

@@ -300,36 +300,6 @@ def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None, absmax=None):
 EPI_NONE, EPI_AFFINE, EPI_AFFINE_LEAKY, EPI_AFFINE_MISH = 0, 1, 2, 3   # include/yolo_hip.h YOLO_EPI_*
 
 
-BN_FUSED_SLOTS = 8
-
-
-def conv2d_fwd_planes_bn(d, xp, wp, bias, out, stats, absmax, gamma, beta, moving_mean, moving_var, scale, shift,
-                         save_mean, save_invstd, ticket, eps=BN_EPS, momentum=BN_MOMENTUM, unbiased=False, bound=None):
-    """training forward of a conv + BatchNorm unit in ONE launch (yolo_conv2d_fwd_planes_bn): the convolution with the
-    statistics epilogue; the tile that finishes last does bn_finalize's work. stats: >= BN_FUSED_SLOTS x 2 x Cout zeroed
-    doubles; ticket: one zeroed int32 word (left at zero)."""
-    _chk_f32(bias, gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd)
-    if xp.numel() < planes_bytes(d.N * d.H * d.W, d.Cin) or wp.numel() < planes_bytes(d.Cout, d.kh * d.kw * d.Cin):
-        raise YoloHipError("conv2d_fwd_planes_bn: planes buffers do not match the descriptor")
-    if out.numel() != d.N * d.Ho * d.Wo * d.Cout:
-        raise YoloHipError("conv2d_fwd_planes_bn: output size does not match the descriptor")
-    if stats.numel() < BN_FUSED_SLOTS * 2 * d.Cout or stats.dtype != torch.float64:
-        raise YoloHipError("conv2d_fwd_planes_bn: stats must hold BN_FUSED_SLOTS x 2 x Cout doubles")
-    for t in (gamma, beta, scale, shift, save_mean, save_invstd):
-        if t.numel() != d.Cout:
-            raise YoloHipError("conv2d_fwd_planes_bn: per-channel vectors must have Cout entries")
-    def run():
-        check(_lib.load().yolo_conv2d_fwd_planes_bn(byref(d), _p(xp), _p(wp), _p(bias), _p(out), _p(stats), _p(absmax),
-                                                    _p(gamma), _p(beta), eps, momentum, int(unbiased), _p(moving_mean),
-                                                    _p(moving_var), _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
-                                                    _p(bound), _p(ticket), _stream()), "yolo_conv2d_fwd_planes_bn")
-    if TIMER is not None:
-        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin)), _conv_flops(d), 1, run)
-    else:
-        run()
-    return out
-
-
 def conv2d_fwd_planes_epi(d, xp, wp, bias, epilogue, scale, shift, residual=None, out=None, absmax=None):
     """inference: out = act(scale * (conv + bias) + shift) (+ residual) in ONE kernel (yolo_conv2d_fwd_planes_epi);
     absmax: per-channel max|out| before the residual (bit patterns, zeroed by the caller)"""
