@@ -53,7 +53,8 @@ namespace yolo {
 // SPLIT: the split-K instantiation (every workgroup one part of one tile, accumulators to a slab, no epilogue). Its own
 // kernel because the slab path inside the production instantiation tripled its scratch (152 -> 440-496 bytes per lane)
 // and made every window launch of the training step 10-40 % slower.
-template <int WGM, int NCH, bool STAMPS = false, bool SPLIT = false>
+// SK: the stream-K instantiation (a.sk_grid > 0: unit shares, slabs, tickets); the production kernel carries none of it.
+template <int WGM, int NCH, bool STAMPS = false, bool SPLIT = false, bool SK = false>
 __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConvArgs a) {
   constexpr int WGN = 2;
   constexpr int BM = 64 * WGM, BN = 128;
@@ -110,11 +111,13 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
   // ---- my share of the (tile, channel block) units: [u_begin, u_end) ----
   // sk_grid == 0: one whole tile per workgroup. Otherwise the units are dealt out evenly to sk_grid workgroups,
   // logical workgroup wl = XCD-aware remap of blockIdx (neighbours in unit space share an L2).
-  const int G = a.sk_grid;
+  const int G = (SK || SPLIT) ? a.sk_grid : 0;
   const int wl = xcd_remap(blockIdx.x, G > 0 ? G : a.nblocks);
-  const int sk_q = G > 0 ? (a.nblocks * cpt) / G : 0, sk_r = G > 0 ? (a.nblocks * cpt) % G : 0;
+  const int Gd = G > 0 ? G : 1;
+  const int sk_q = G > 0 ? (a.nblocks * cpt) / Gd : 0, sk_r = G > 0 ? (a.nblocks * cpt) % Gd : 0;
   auto first_unit = [&](int w) { return w * sk_q + (w < sk_r ? w : sk_r); };
-  auto owner_of = [&](int u) { return u < sk_r * (sk_q + 1) ? u / (sk_q + 1) : sk_r + (u - sk_r * (sk_q + 1)) / sk_q; };
+  const int sk_qd = sk_q > 0 ? sk_q : 1;   // (sk_q is the constant 0 outside the stream-K instantiation)
+  auto owner_of = [&](int u) { return u < sk_r * (sk_q + 1) ? u / (sk_q + 1) : sk_r + (u - sk_r * (sk_q + 1)) / sk_qd; };
   // split_parts > 1 (split-K with a reduce kernel behind it): logical workgroup wl = tile * P + part computes the
   // channel blocks [part * cpt / P, (part + 1) * cpt / P) of its tile and nothing else
   const int SP = SPLIT ? a.split_parts : 1;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
 
   bool finish = !SPLIT;
   if constexpr (SPLIT) store_split_slab<TM, TN>(a, acc, BM * BN * 4, wl, wave, lane);   // conv_split_reduce_kernel finishes the tile
-  if constexpr (!SPLIT)
+  if constexpr (SK)
   if (cb1 - cb0 < cpt) {
     // ---- part of a tile: publish my accumulators, draw a ticket; the last arriver combines ----
     constexpr int SLAB_BYTES = BM * BN * 4;
@@ -688,6 +691,16 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
       hipLaunchKernelGGL((conv_win_kernel<WGM, NCH, true>), dim3(grid), dim3(128 * WGM), lds, st, a);
       return check_launch("conv_win_kernel(stamps)");
     }
+  }
+  if (a.sk_grid > 0) {
+    static bool attr_sk = false;
+    if (!attr_sk) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<WGM, NCH, false, false, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_sk = true;
+    }
+    hipLaunchKernelGGL((conv_win_kernel<WGM, NCH, false, false, true>), dim3(grid), dim3(128 * WGM), lds, st, a);
+    return check_launch("conv_win_kernel(stream-K)");
   }
   hipLaunchKernelGGL((conv_win_kernel<WGM, NCH>), dim3(grid), dim3(128 * WGM), lds, st, a);
   return check_launch("conv_win_kernel");
