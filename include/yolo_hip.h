@@ -58,11 +58,12 @@ int yolo_device_available(void);
  * key -1 resets every option to its default. */
 enum { YOLO_OPT_CONV_WIN = 0, YOLO_OPT_STAMPS = 1, YOLO_OPT_CONV_SK = 2 };
 int yolo_set_option(int key, int value);
-/* Scratch for the persistent ("stream-K") form of the 3x3 window kernel (key 2 = YOLO_OPT_CONV_SK != 0): tile
- * tickets + the accumulator slabs of tiles shared by several workgroups. The caller owns the memory
- * (yolo_conv_workspace_bytes() bytes, device); the call zeroes the ticket area on `stream`. Every
- * yolo_conv2d_fwd_planes / _dgrad_planes call must then be ordered after it on ONE stream (the kernels leave the
- * tickets zero again). p == NULL unregisters (the kernels fall back to one workgroup per tile). */
+/* Scratch for the split-K / stream-K forms of the planes convolutions (key 2 = YOLO_OPT_CONV_SK != 0): the accumulator
+ * slabs of tiles computed by several workgroups (+ the stream-K form's tile tickets). The caller owns the memory
+ * (yolo_conv_workspace_bytes() bytes, device); the call zeroes the ticket area on `stream`. ONE workspace per process:
+ * every yolo_conv2d_fwd_planes(_epi) / _dgrad_planes call must be ordered after this call and after each other on one
+ * stream (two models convolving on two streams at once would share the slabs; the kernels leave the tickets zero again).
+ * p == NULL unregisters (one workgroup per tile everywhere). */
 size_t yolo_conv_workspace_bytes(void);
 int yolo_set_conv_workspace(void* p, size_t bytes, void* stream);
 /* Diagnostic builds only (key 1 = YOLO_OPT_STAMPS != 0): device buffer that receives 8 x uint64 clock stamps per
