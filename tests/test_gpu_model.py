@@ -163,10 +163,14 @@ def _gpu_leaky_masks(net):
 # (version, BN moving variance fed Bessel-corrected [tf.keras fused BN, the default] or biased, C1 at its true size)
 @pytest.mark.parametrize("version,unbiased,true_c1", [(3, True, False), (2, True, False), (1, True, False), (4, True, False),
                                                       (3, False, False), (1, True, True), (3, True, "tiny"),
-                                                      (3, True, "416"), (4, True, "608"), (2, True, "416")])
+                                                      (3, True, "416"), (4, True, "608"), (2, True, "416"),
+                                                      (3, True, "tiny416")])
 def test_model_parity(version, unbiased, true_c1):
     from tf2_yolo_amd import optimizers
-    if true_c1 == "tiny":   # tiny-YOLOv3 at 96x96: grids 3 and 6, the stride-1 'same' max-pool on a 3x3 map
+    if true_c1 == "tiny416":   # tiny-YOLOv3 at its usual resolution: 416x416, grids 13 and 26 (bs 2)
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=416, N=2, unbiased=unbiased, tiny=True)
+        assert [tuple(o.shape[1:3]) for o in model.output] == [(13, 13), (26, 26)]
+    elif true_c1 == "tiny":   # tiny-YOLOv3 at 96x96: grids 3 and 6, the stride-1 'same' max-pool on a 3x3 map
         y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=96, N=4, unbiased=unbiased, tiny=True)
         assert len(model.output) == 2 and tuple(model.output[0].shape[1:3]) == (3, 3)
     elif true_c1 == "416" and version == 2:   # configs[1]: YOLOv2 Darknet-19 + passthrough at 416x416 (bs 2): 13x13 grid
