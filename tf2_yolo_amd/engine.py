@@ -607,7 +607,7 @@ class Network:
         self.act[self.input.tid] = x
         self._xp_valid = set()
         self._tbound_set = set()
-        self._wp_event = self._wT_event = None
+        # (a pending event of an earlier forward stays until a planes conv / a backward has waited for it)
         if training and self._overlap_wgrad and self._prep_beside and not (self._wp_valid and self._wT_valid and self._wTp_valid):
             # the filters' planes (needed by the first planes conv) and their transposed forms (needed by backward) are
             # made on the second stream while the stem runs: 0.45 ms of HBM-bound launches beside MFMA-bound ones
