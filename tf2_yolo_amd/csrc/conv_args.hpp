@@ -110,7 +110,7 @@ int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_b
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st);
 bool gather_planes_supported(const GatherConvArgs& a);
 // conv_win.hip (3x3 stride-1 forward / data gradient with the input window kept in LDS); returns 1 = not covered
-int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb);
+int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb, int idle_div);
 int launch_split_reduce(GatherConvArgs& a, int bm, hipStream_t st);
 float* conv_split_slabs();
 int launch_conv_win(GatherConvArgs& a, int variant, hipStream_t st);

@@ -446,7 +446,7 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
   if constexpr (BM == 128 && BN == 128 && WGM == 2 && WGN == 2 && DBG == 0) {
     // at least 8 stages per part (a.kc = the whole channel range in one chunk is the default stage order)
     const int min_cb = a.ntaps >= 8 ? 1 : (8 + a.ntaps - 1) / a.ntaps;
-    a.split_parts = conv_split_parts(a, nb, BM, min_cb);
+    a.split_parts = conv_split_parts(a, nb, BM, min_cb, 4);
     if (a.split_parts > 1) {
       a.sk_slabs = conv_split_slabs();
       static bool attr32 = false;

@@ -573,10 +573,11 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
 }
 
 // Parts per tile for a launch of nb tiles of bm x 128 (1 = do not split). Only launches without BatchNorm statistics
-// whose tiles would fill less than a quarter of the chip (at bs 32 the 13x13 layers have 172 tiles: +-0 to -8 % with two
-// parts, left alone), each part at least min_cb channel blocks long, as many parts as
+// whose tiles would fill less than 1/idle_div of the chip's workgroup slots (window kernel: half -- the 13x13 data
+// gradients at bs 32, 172 tiles of 576 stages: 181 -> 169 us with two parts; per-tap kernel: a quarter -- the 13x13 1x1
+// layers at bs 32 have 64 stages per tile and lose 8 % with two parts), each part at least min_cb channel blocks long, as many parts as
 // it takes to give every CU two workgroups, at most 32; needs the workspace of yolo_set_conv_workspace.
-int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb) {
+int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb, int idle_div) {
   init_options();
   if (g_opt[OPT_CONV_SK] != 1 || a.stats != nullptr || g_sk_ws == nullptr) return 1;
   static int cus = 0;
@@ -586,7 +587,7 @@ int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb) 
       cus = 256;
   }
   const long long slots = 2LL * cus;
-  if (nb * 4 > slots) return 1;
+  if (nb * idle_div > slots) return 1;
   long long P = (a.Cs >> 4) / min_cb;
   if (P > slots / nb) P = slots / nb;
   if (P > 32) P = 32;
@@ -649,7 +650,7 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
   // 190 us with 32 -- the last arriver reads the other parts one after the other; layers with fewer than 32 channel
   // blocks (26x26: 41 us, 52x52: 24 us) do not gain at any split)
   // YOLO_CONV_SK=1 (default): split-K with the reduce kernel (conv_split_parts); -1: the stream-K policy above
-  a.split_parts = WGM == 2 ? conv_split_parts(a, nb, BM, 2) : 1;
+  a.split_parts = WGM == 2 ? conv_split_parts(a, nb, BM, 2, 2) : 1;
   if (a.split_parts > 1) {
     a.tile_order = 0;
     a.sk_grid = (int)(nb * a.split_parts);
