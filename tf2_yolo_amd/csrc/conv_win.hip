@@ -714,11 +714,11 @@ int launch_conv_win(GatherConvArgs& a, int variant, hipStream_t st) {
   int wgm = variant;
   if (wgm != 2 && wgm != 4) {
     // automatic (measured on YOLOv3-416 bs 32, scripts/win_sweep.sh): rows of more than 64 pixels need windows that
-    // leave one workgroup per CU -> the per-tap kernel; 256x128 tiles (8 waves) where 128x128 tiles would fill
-    // between one and two workgroups per CU (13x13x512->1024 forward, 26x26 data gradients: 338-344 tiles)
+    // leave one workgroup per CU -> the per-tap kernel. 128x128 tiles everywhere: the 256x128 tiles (8 waves) that round-2's
+    // first builds used where 128x128 tiles fill between one and two workgroups per CU (338-344 tiles) are 0.4 % of the
+    // step SLOWER since the production kernel lost its stream-K code (same-box A/B: 941 vs 945 images/s)
     if (a.Ws > 64) return 1;
-    const long long t128 = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-    wgm = (t128 > 256 && t128 <= 512) ? 4 : 2;
+    wgm = 2;
   }
   const int need = win_pixels_needed(a, 64 * wgm);
   const int nch = (need + 63) / 64;

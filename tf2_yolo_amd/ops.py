@@ -91,8 +91,7 @@ def _planes_variant(cout, win=None):
     win = (W of the source, M rows) of a 3x3 stride-1 layer, None otherwise"""
     if win is not None and CONV_WIN and cout >= 128:
         ws, m = win
-        t128 = ((m + 127) // 128) * ((cout + 127) // 128)
-        wgm = CONV_WIN if CONV_WIN in (2, 4) else (0 if ws > 64 else (4 if 256 < t128 <= 512 else 2))
+        wgm = CONV_WIN if CONV_WIN in (2, 4) else (0 if ws > 64 else 2)
         if wgm:
             return "conv_win_planes_kernel<%d,128>" % (64 * wgm)
     if cout <= 32:
