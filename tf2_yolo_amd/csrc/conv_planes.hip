@@ -504,7 +504,11 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   // gradient); the 128x64 tile doubles the workgroups. YOLO_PLANES_NARROW_BELOW = tile count under which it is used
   static const int narrow_below = [] { const char* e = getenv("YOLO_PLANES_NARROW_BELOW"); return e ? atoi(e) : 0; }();
   if (((a.M + 127) / 128) * ((a.Cout + 127) / 128) < narrow_below) return launch_planes<128, 64, 4, 2>(a, st);
-  static const int waves = [] { const char* e = getenv("YOLO_PLANES_WAVES"); return e ? atoi(e) : 4; }();
+  // 128x128 tile: 4 waves x (64x64) for the 3x3 launches this kernel still gets (stride 2, rows longer than 64 pixels),
+  // 8 waves x (32x64) for 1x1 layers -- HBM-bound, they want loads in flight (24 waves per CU instead of 12), not MFMAs
+  // per barrier. YOLO_PLANES_WAVES = 2 / 4 / 8 forces one form.
+  static const int waves_env = [] { const char* e = getenv("YOLO_PLANES_WAVES"); return e ? atoi(e) : 0; }();
+  const int waves = waves_env ? waves_env : (a.ntaps == 1 && a.ncls <= 1 ? 8 : 4);
 #ifdef YOLO_PLANES_KNOCKOUTS   // diagnostic build (make KNOCKOUTS=1): compile-time knock-outs of the 128x128 4-wave kernel
   switch (a.dbg) {
     case 1: return launch_planes<128, 128, 2, 2, 1>(a, st);
@@ -522,6 +526,11 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
 #endif
   if (waves == 2) return launch_planes<128, 128, 2, 1>(a, st);   // 2 waves x (64 x 128): one wave per SIMD, 512 registers
   if (waves == 4) return launch_planes<128, 128, 2, 2>(a, st);
+  {   // split-K (launches that leave the chip idle) lives in the 4-wave form
+    const long long nb = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+    const int min_cb = a.ntaps >= 8 ? 1 : (8 + a.ntaps - 1) / a.ntaps;
+    if (a.ncls <= 1 && conv_split_parts(a, nb, 128, min_cb, 4) > 1) return launch_planes<128, 128, 2, 2>(a, st);
+  }
   return launch_planes<128, 128, 4, 2>(a, st);
 }
 

@@ -80,15 +80,15 @@ def _wgrad_planes_variant(cout, cols):
                                              else "4,2" if cols <= 64 else big)
 
 
-_PLANES_WAVES = 8 if _os.environ.get("YOLO_PLANES_WAVES") == "8" else 4
+_PLANES_WAVES = int(_os.environ.get("YOLO_PLANES_WAVES", "0") or 0)   # 0: the library's automatic choice
 
 
 CONV_WIN = int(_os.environ.get("YOLO_CONV_WIN", "1"))
 
 
-def _planes_variant(cout, win=None):
+def _planes_variant(cout, win=None, k1=False):
     """mirrors launch_gather_planes() in csrc/conv_planes.hip and launch_conv_win() in csrc/conv_win.hip;
-    win = (W of the source, M rows) of a 3x3 stride-1 layer, None otherwise"""
+    win = (W of the source, M rows) of a 3x3 stride-1 layer, None otherwise; k1 = 1x1 stride-1 layer (8-wave tile)"""
     if win is not None and CONV_WIN and cout >= 128:
         ws, m = win
         wgm = CONV_WIN if CONV_WIN in (2, 4) else (0 if ws > 64 else 2)
@@ -98,7 +98,8 @@ def _planes_variant(cout, win=None):
         return "gather_conv_planes_kernel<128,32,4,1>"
     if cout <= 64:
         return "gather_conv_planes_kernel<128,64,4,2>"
-    return "gather_conv_planes_kernel<128,128,%s>" % ("4,2" if _PLANES_WAVES == 8 else "2,2")
+    waves8 = _PLANES_WAVES == 8 or (_PLANES_WAVES == 0 and k1)
+    return "gather_conv_planes_kernel<128,128,%s>" % ("4,2" if waves8 else "2,2")
 
 
 def _win_key(d, hs, ws, cs):
@@ -290,7 +291,7 @@ def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None, absmax=None):
         check(_lib.load().yolo_conv2d_fwd_planes(byref(d), _p(xp), _p(wp), _p(bias), _p(out), _p(stats), _p(absmax),
                                                  _stream()), "yolo_conv2d_fwd_planes")
     if TIMER is not None:
-        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin)), _conv_flops(d), 1, run)
+        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin), d.kh * d.kw == 1), _conv_flops(d), 1, run)
     else:
         run()
     return out
@@ -314,7 +315,7 @@ def conv2d_fwd_planes_epi(d, xp, wp, bias, epilogue, scale, shift, residual=None
                                                      _p(residual), _p(out), _p(absmax), _stream()),
               "yolo_conv2d_fwd_planes_epi")
     if TIMER is not None:
-        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin)), _conv_flops(d), 1, run)
+        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin), d.kh * d.kw == 1), _conv_flops(d), 1, run)
     else:
         run()
     return out
@@ -341,7 +342,7 @@ def conv2d_dgrad_planes(d, dyp, wTp, dx=None, accumulate=False):
         check(_lib.load().yolo_conv2d_dgrad_planes(byref(d), _p(dyp), _p(wTp), _p(dx), int(bool(accumulate)), _stream()),
               "yolo_conv2d_dgrad_planes")
     if TIMER is not None:
-        TIMER.bracket(_planes_variant(d.Cin, _win_key(d, d.Ho, d.Wo, d.Cout)), _conv_flops(d), d.sh * d.sw, run)
+        TIMER.bracket(_planes_variant(d.Cin, _win_key(d, d.Ho, d.Wo, d.Cout), d.kh * d.kw == 1 and d.sh * d.sw == 1), _conv_flops(d), 1, run)
     else:
         run()
     return dx
