@@ -178,7 +178,7 @@ int yolo_conv2d_fwd_planes_epi(const yolo_conv_desc* d, const void* x_planes, co
 int yolo_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax, const float* extra_bound,
                              void* planes, float* out_bound, void* stream);
 /* yolo_conv2d_wgrad on pre-split operands (dw += ..., same contract; the bias gradient stays with
- * yolo_conv2d_wgrad_bias on the fp32 dy). Requires Cin % 16 == 0, Cout % 16 == 0, Cout >= 64, kh*kw*Cin >= 64. */
+ * yolo_conv2d_wgrad_bias on the fp32 dy). Requires Cin % 16 == 0, Cout % 16 == 0, Cout >= 32, kh*kw*Cin >= 64. */
 int yolo_conv2d_wgrad_planes(const yolo_conv_desc* d, const void* x_planes, const void* dy_planes,
                              float* dw, void* stream);
 

@@ -529,7 +529,7 @@ def test_conv_planes_rejects_unsupported_shapes():
         ops.conv2d_fwd_planes(d, xp, wp)
 
 
-# Cin % 16 == 0, Cout % 16 == 0, Cout >= 64, k*k*Cin >= 64
+# Cin % 16 == 0, Cout % 16 == 0, Cout >= 32, k*k*Cin >= 64
 WGRAD_PLANES_CASES = [
     (2, 16, 16, 32, 64, 3, 1, "same", False),         # 64 x 128 tile
     (2, 17, 13, 32, 64, 3, 2, "darknet_s2", False),    # stride 2, odd sizes, pixel count not a multiple of 16
@@ -540,6 +540,9 @@ WGRAD_PLANES_CASES = [
     (2, 14, 14, 64, 64, 1, 1, "same", True),          # 64 x 64 tile
     (2, 13, 13, 64, 128, 1, 1, "same", False),        # 128 x 64 tile
     (4, 26, 26, 128, 256, 3, 1, "same", False),       # several pixel chunks (split-K) per tile
+    (2, 24, 24, 64, 32, 1, 1, "same", False),         # Cout = 32: half of a 64-row tile (the 208x208 1x1 64 -> 32 layer)
+    (4, 72, 72, 32, 64, 3, 2, "darknet_s2", False),   # stride 2 at 5184 output rows
+    (2, 104, 104, 32, 64, 3, 2, "same", True),        # stride 2, Keras 'same' (pad after only), 5408 rows; bias
 ]
 
 

@@ -976,7 +976,7 @@ extern "C" int yolo_conv2d_wgrad_planes(const yolo_conv_desc* d, const void* x_p
   a.dw = dw;
   fill_wgrad_args(d, a);
   YOLO_REQUIRE(wgrad_planes_supported(a),
-               "conv_wgrad_planes: needs Cin %% 16 == 0, Cout %% 16 == 0, Cout >= 64 and kh*kw*Cin >= 64");
+               "conv_wgrad_planes: needs Cin %% 16 == 0, Cout %% 16 == 0, Cout >= 32 and kh*kw*Cin >= 64");
   return launch_wgrad_planes(a, as_stream(stream));
 }
 

@@ -318,7 +318,7 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
 }
 
 bool wgrad_planes_supported(const WgradArgs& a) {
-  return (a.Cout % 16) == 0 && (a.Cs % 16) == 0 && a.Cout >= 64 && a.ntaps * a.Cs >= 64;
+  return (a.Cout % 16) == 0 && (a.Cs % 16) == 0 && a.Cout >= 32 && a.ntaps * a.Cs >= 64;   // (Cout = 32: half of a 64-row tile)
 }
 
 int launch_wgrad_planes(WgradArgs& a, hipStream_t st) {

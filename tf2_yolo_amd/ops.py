@@ -70,7 +70,7 @@ def planes_dgrad_ok(cin, cout):
 
 def planes_wgrad_ok(cin, cout, taps, stride=1):
     # (stride is not a criterion: stride-2 filter gradients run on the planes kernel too)
-    return USE_PLANES and cin % 16 == 0 and cout % 16 == 0 and cout >= 64 and taps * cin >= 64
+    return USE_PLANES and cin % 16 == 0 and cout % 16 == 0 and cout >= 32 and taps * cin >= 64
 
 
 def _wgrad_planes_variant(cout, cols):
