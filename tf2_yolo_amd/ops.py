@@ -203,7 +203,12 @@ def conv2d_fwd(d, x, w, bias=None, out=None, stats=None, absmax=None):
         check(_lib.load().yolo_conv2d_fwd_absmax(byref(d), _p(x), _p(w), _p(bias), _p(out), _p(stats), _p(absmax),
                                                  _stream()), "yolo_conv2d_fwd")
     if TIMER is not None:
-        TIMER.bracket(_gather_variant(d.Cout, d.Cin % 32 != 0, d.N * d.Ho * d.Wo), _conv_flops(d), 1, run)
+        # (csrc/stem.hip: stem_fwd_supported -- the direct Cin = 3 kernel takes the first layer at training sizes)
+        stem = (CONV_MODE == "split" and _os.environ.get("YOLO_STEM_DIRECT", "1") != "0" and d.Cin == 3 and d.Cout == 32
+                and d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.Ho == d.H and d.Wo == d.W
+                and d.N * d.H * d.W >= (1 << 20))
+        name = "stem_conv3x3_kernel" if stem else _gather_variant(d.Cout, d.Cin % 32 != 0, d.N * d.Ho * d.Wo)
+        TIMER.bracket(name, _conv_flops(d), 1, run)
     else:
         run()
     return out
