@@ -12,14 +12,26 @@ namespace yolo {
 constexpr int STEM_CO = 32;
 constexpr int STEM_K = 27;
 
-template <bool STATS>
+// the filter as [j = (r*3+s)*3+ci][co] + a bias row, for the kernel that takes it through the SCALAR cache
+__global__ __launch_bounds__(256) void stem_filter_prep_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ wt) {
+  for (int i = threadIdx.x; i < STEM_K * STEM_CO; i += 256) wt[(i % STEM_K) * STEM_CO + i / STEM_K] = w[i];   // w: [co][j]
+  if (threadIdx.x < STEM_CO) wt[STEM_K * STEM_CO + threadIdx.x] = bias != nullptr ? bias[threadIdx.x] : 0.f;
+}
+
+// SREG: the filter comes from `w` = the prepared [28][32] copy by scalar loads (uniform addresses: s_load into SGPRs, the
+// FMAs take it as their scalar operand) instead of 216 broadcast ds_read_b128 per pixel, which had the CU's LDS port
+// as the bottleneck (216 x 8 clocks per 64 pixels and wave = 280 us for the bs-32 tensor; the FMAs need 70 us)
+template <bool STATS, bool SREG>
 __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ bias, float* __restrict__ y,
                                                           double* __restrict__ stats, unsigned* __restrict__ absmax,
                                                           int H, int W, int pad_t, int pad_l, int M) {
-  __shared__ __attribute__((aligned(16))) float w_s[STEM_K + 1][STEM_CO];   // [j = (r*3+s)*3+ci][co]; row 27 = bias
-  for (int i = threadIdx.x; i < STEM_K * STEM_CO; i += 256) w_s[i % STEM_K][i / STEM_K] = w[i];   // w: [co][j]
-  if (threadIdx.x < STEM_CO) w_s[STEM_K][threadIdx.x] = bias != nullptr ? bias[threadIdx.x] : 0.f;
+  __shared__ __attribute__((aligned(16))) float w_s[SREG ? 1 : STEM_K + 1][STEM_CO];   // [j = (r*3+s)*3+ci][co]; row 27 = bias
+  if constexpr (!SREG) {
+    for (int i = threadIdx.x; i < STEM_K * STEM_CO; i += 256) w_s[i % STEM_K][i / STEM_K] = w[i];   // w: [co][j]
+    if (threadIdx.x < STEM_CO) w_s[STEM_K][threadIdx.x] = bias != nullptr ? bias[threadIdx.x] : 0.f;
+  }
   __shared__ __attribute__((aligned(16))) float t_s[4][64 * STEM_CO];   // per-wave output staging (8 KB each)
   __syncthreads();
   float s1[STATS ? STEM_CO : 1], s2[STATS ? STEM_CO : 1], mx[STATS ? STEM_CO : 1];
@@ -61,6 +73,17 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
     // kernel's critical resource
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 acc2[STEM_CO / 2];
+    if constexpr (SREG) {
+#pragma unroll
+      for (int c2 = 0; c2 < STEM_CO / 2; ++c2) acc2[c2] = f32x2{w[STEM_K * STEM_CO + 2 * c2], w[STEM_K * STEM_CO + 2 * c2 + 1]};
+#pragma unroll
+      for (int j = 0; j < STEM_K; ++j) {
+        const f32x2 pj = {patch[j], patch[j]};
+#pragma unroll
+        for (int c2 = 0; c2 < STEM_CO / 2; ++c2)   // (uniform addresses with constant offsets: scalar loads)
+          acc2[c2] = __builtin_elementwise_fma(pj, f32x2{w[j * STEM_CO + 2 * c2], w[j * STEM_CO + 2 * c2 + 1]}, acc2[c2]);
+      }
+    } else {
 #pragma unroll
     for (int c4 = 0; c4 < STEM_CO / 4; ++c4) {
       const f32x4 bv = *reinterpret_cast<const f32x4*>(&w_s[STEM_K][c4 * 4]);
@@ -76,6 +99,7 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
         acc2[2 * c4] = __builtin_elementwise_fma(pj, f32x2{wv[0], wv[1]}, acc2[2 * c4]);
         acc2[2 * c4 + 1] = __builtin_elementwise_fma(pj, f32x2{wv[2], wv[3]}, acc2[2 * c4 + 1]);
       }
+    }
     }
     float acc[STEM_CO];
 #pragma unroll
@@ -151,11 +175,21 @@ int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, con
   const int M = d->N * d->H * d->W;
   const bool st_on = stats != nullptr || absmax != nullptr;
   // one resident round: every lane walks M / (grid * 256) pixels (a second, partial round would idle most CUs)
+  // YOLO_STEM_SREG=0: the filter broadcast from LDS (round 1's kernel) instead of the scalar cache
+  static const bool sreg = [] { const char* e = getenv("YOLO_STEM_SREG"); return !(e && atoi(e) == 0); }();
+  static float* wt_ring = nullptr;   // 8 prepared filters (3.5 KB each), used round robin: launches in flight never share one
+  static unsigned wt_next = 0;
+  if (sreg && wt_ring == nullptr && hipMalloc(reinterpret_cast<void**>(&wt_ring), 8 * (STEM_K + 1) * STEM_CO * sizeof(float)) != hipSuccess) {
+    set_error("stem: hipMalloc of the filter scratch failed");
+    return YOLO_ERR_LAUNCH;
+  }
   static int per_cu[2] = {0, 0};
   if (per_cu[st_on] == 0) {
     int n = 0;
-    const void* fn = st_on ? reinterpret_cast<const void*>(&stem_conv3x3_kernel<true>)
-                           : reinterpret_cast<const void*>(&stem_conv3x3_kernel<false>);
+    const void* fn = sreg ? (st_on ? reinterpret_cast<const void*>(&stem_conv3x3_kernel<true, true>)
+                                   : reinterpret_cast<const void*>(&stem_conv3x3_kernel<false, true>))
+                          : (st_on ? reinterpret_cast<const void*>(&stem_conv3x3_kernel<true, false>)
+                                   : reinterpret_cast<const void*>(&stem_conv3x3_kernel<false, false>));
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, 0) != hipSuccess || n < 1) n = 2;
     per_cu[st_on] = n;
   }
@@ -168,11 +202,20 @@ int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, con
   }
   int grid = (M + 255) / 256;
   if (grid > per_cu[st_on] * cus) grid = per_cu[st_on] * cus;
-  if (st_on)
-    hipLaunchKernelGGL(stem_conv3x3_kernel<true>, dim3(grid), dim3(256), 0, st, x, w, bias, y, stats, absmax, d->H, d->W,
+  if (sreg) {
+    float* wt = wt_ring + (size_t)(wt_next++ & 7) * (STEM_K + 1) * STEM_CO;
+    hipLaunchKernelGGL(stem_filter_prep_kernel, dim3(1), dim3(256), 0, st, w, bias, wt);
+    if (st_on)
+      hipLaunchKernelGGL((stem_conv3x3_kernel<true, true>), dim3(grid), dim3(256), 0, st, x, wt, bias, y, stats, absmax, d->H,
+                         d->W, d->pad_t, d->pad_l, M);
+    else
+      hipLaunchKernelGGL((stem_conv3x3_kernel<false, true>), dim3(grid), dim3(256), 0, st, x, wt, bias, y, stats, absmax,
+                         d->H, d->W, d->pad_t, d->pad_l, M);
+  } else if (st_on)
+    hipLaunchKernelGGL((stem_conv3x3_kernel<true, false>), dim3(grid), dim3(256), 0, st, x, w, bias, y, stats, absmax, d->H, d->W,
                        d->pad_t, d->pad_l, M);
   else
-    hipLaunchKernelGGL(stem_conv3x3_kernel<false>, dim3(grid), dim3(256), 0, st, x, w, bias, y, stats, absmax, d->H,
+    hipLaunchKernelGGL((stem_conv3x3_kernel<false, false>), dim3(grid), dim3(256), 0, st, x, w, bias, y, stats, absmax, d->H,
                        d->W, d->pad_t, d->pad_l, M);
   return check_launch("stem_conv3x3_kernel");
 }
