@@ -260,6 +260,15 @@ int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scal
 int yolo_bn_act_bwd_reduce_bound(const float* x, const float* dout, long long P, int C, const float* scale,
                                  const float* shift, const float* save_mean, const float* save_invstd,
                                  int act, double* red, unsigned* bound_aux, void* stream);
+/* Backward of the stem unit -- Conv2D(32, 3x3, 'same') on the 3-channel image + BatchNormalization + activation
+ * (yolov3/models/backbone.py:60, yolov4/models/backbone.py:127, yolov2/models/backbone.py:44) -- behind
+ * yolo_bn_act_bwd_reduce(_bound): the backward apply of yolo_bn_act_bwd_apply and the filter gradient of
+ * yolo_conv2d_wgrad in ONE pass over (y, dout); the 32-channel gradient tensor (709 MB at bs 32) is never written.
+ * dw [32][27] and dgamma / dbeta are accumulated (+=); scratch: yolo_stem_bwd_scratch_bytes() bytes of device memory. */
+size_t yolo_stem_bwd_scratch_bytes(void);
+int yolo_stem_bn_bwd_wgrad(const yolo_conv_desc* d, const float* y, const float* dout, const float* image, const float* scale,
+                           const float* shift, const float* save_mean, const float* save_invstd, int act, const double* red,
+                           float* dgamma, float* dbeta, float* dw, void* scratch, size_t scratch_bytes, void* stream);
 int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, long long P, int C, const float* gamma,
                                  const float* scale, const float* shift, const float* save_mean,
                                  const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,

@@ -517,6 +517,46 @@ def test_conv_fused_inference_epilogue(act, with_res, case):
     assert _relerr(y2.double().cpu(), L.conv2d(ref, w2, None, stride=1, padding="same")) < TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 45), (1, 16, 16), (3, 130, 127), (2, 21, 400)])
+@pytest.mark.parametrize("act", ["leaky", "mish"])
+def test_stem_backward_fused(shape, act):
+    """yolo_stem_bn_bwd_wgrad (csrc/stem.hip): the BatchNorm / activation backward apply and the filter gradient of the
+    stem unit in one pass. Against the unfused device path (yolo_bn_act_bwd_apply, then yolo_conv2d_wgrad on the dy it
+    wrote) and, for the filter gradient, against float64 autograd on that dy."""
+    from tf2_yolo_amd import ops
+    from tf2_yolo_amd._lib import ACT_LEAKY, ACT_MISH
+    a = ACT_LEAKY if act == "leaky" else ACT_MISH
+    n, h, w = shape
+    g = torch.Generator().manual_seed(81)
+    img = torch.rand(n, h, w, 3, generator=g).cuda()
+    y = torch.randn(n, h, w, 32, generator=g).cuda()
+    dout = torch.randn(n, h, w, 32, generator=g).cuda()
+    gamma = (1 + 0.2 * torch.randn(32, generator=g)).cuda()
+    mean = (0.1 * torch.randn(32, generator=g)).cuda()
+    inv = (0.5 + torch.rand(32, generator=g)).cuda()
+    scale = gamma * inv
+    shift = (0.1 * torch.randn(32, generator=g)).cuda() - mean * scale
+    d = ops.conv_desc((n, h, w, 3), 32, 3, 3, 1, "same")
+
+    def bufs():
+        return (torch.zeros((ops.BN_RED_SLOTS + 1) * 64, device="cuda", dtype=torch.float64), torch.zeros(32, device="cuda"),
+                torch.zeros(32, device="cuda"), torch.zeros(32 * 27, device="cuda"))
+
+    red0, dg0, db0, dw0 = bufs()
+    dy = ops.bn_act_bwd(y, dout, 32, gamma, scale, shift, mean, inv, a, red0, dg0, db0)
+    ops.conv2d_wgrad(d, img, dy, dw0)
+    red1, dg1, db1, dw1 = bufs()
+    dw1 += 1.0    # accumulated, not overwritten
+    ops.stem_bn_bwd_wgrad(d, img, y, dout, scale, shift, mean, inv, a, red1, dg1, db1, dw1)
+    torch.cuda.synchronize()
+    assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert _relerr((dw1 - 1.0).double(), dw0.double()) < 1e-5
+    wk = torch.zeros(3, 3, 3, 32, dtype=torch.float64, requires_grad=True)
+    out = L.conv2d(img.double().cpu(), wk, None, stride=1, padding="same")
+    (out * dy.double().cpu()).sum().backward()
+    assert _relerr((dw1 - 1.0).double().cpu().reshape(32, 27), _krsc(wk.grad).reshape(32, 27)) < TOL
+
+
 def test_conv_planes_rejects_unsupported_shapes():
     from tf2_yolo_amd import ops
     from tf2_yolo_amd._lib import YoloHipError

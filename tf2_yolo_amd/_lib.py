@@ -58,6 +58,8 @@ SIGNATURES = {
     "yolo_split_planes_batch": (c_int, [_P, c_int, _LL, _P]),
     "yolo_filter_transpose_batch": (c_int, [_P, c_int, _LL, _P]),
     "yolo_conv2d_fwd_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
+    "yolo_stem_bwd_scratch_bytes": (c_size_t, []),
+    "yolo_stem_bn_bwd_wgrad": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_size_t, _P]),
     "yolo_conv2d_fwd_planes_epi": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "yolo_split_planes_absmax": (c_int, [_P, _LL, c_int, _P, _P, _P, _P, _P]),
     "yolo_conv2d_fwd_absmax": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),

@@ -760,6 +760,25 @@ extern "C" int yolo_conv2d_fwd_absmax(const yolo_conv_desc* d, const float* x, c
   return dispatch_gather(a, flat, as_stream(stream));
 }
 
+// Backward of the stem unit (Conv2D(32, 3x3, same) on the 3-channel image + BatchNormalization + activation) behind
+// yolo_bn_act_bwd_reduce: the BN / activation backward apply and the filter gradient in one pass over (y, dout); the
+// 32-channel gradient tensor is never written. dw (+=), dgamma / dbeta (+=) as the unfused entry points.
+extern "C" size_t yolo_stem_bwd_scratch_bytes(void) { return stem_bwd_scratch_bytes(); }
+extern "C" int yolo_stem_bn_bwd_wgrad(const yolo_conv_desc* d, const float* y, const float* dout, const float* image,
+                                      const float* scale, const float* shift, const float* save_mean,
+                                      const float* save_invstd, int act, const double* red, float* dgamma, float* dbeta,
+                                      float* dw, void* scratch, size_t scratch_bytes, void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(y && dout && image && scale && shift && save_mean && save_invstd && red && dw, "stem_bn_bwd_wgrad: null pointer");
+  YOLO_REQUIRE(d->Cin == 3 && d->Cout == 32 && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 && d->Ho == d->H &&
+                   d->Wo == d->W && d->W >= 16,
+               "stem_bn_bwd_wgrad: only Conv2D(32, 3x3, stride 1, same) on 3 channels, rows of 16 pixels or more");
+  YOLO_REQUIRE(act >= 0 && act <= 2, "stem_bn_bwd_wgrad: bad activation %d", act);
+  return launch_stem_bn_bwd_wgrad(d, y, dout, image, scale, shift, save_mean, save_invstd, act,
+                                  red + (long long)YOLO_BN_RED_SLOTS * 2 * d->Cout, dgamma, dbeta, dw,
+                                  reinterpret_cast<float*>(scratch), scratch_bytes, as_stream(stream));
+}
+
 extern "C" int yolo_conv2d_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y,
                                double* stats, void* stream) {
   return yolo_conv2d_fwd_absmax(d, x, w, bias, y, stats, nullptr, stream);

@@ -127,6 +127,10 @@ int launch_wgrad_planes(WgradArgs& a, hipStream_t st);
 bool wgrad_planes_supported(const WgradArgs& a);
 // stem.hip (direct fp32 kernel for the 3-channel 3x3 stem)
 bool stem_fwd_supported(const yolo_conv_desc* d);
+size_t stem_bwd_scratch_bytes();
+int launch_stem_bn_bwd_wgrad(const yolo_conv_desc* d, const float* y, const float* dout, const float* img, const float* scale,
+                             const float* shift, const float* smean, const float* sinv, int act, const double* redsum,
+                             float* dgamma, float* dbeta, float* dw, float* scratch, size_t scratch_bytes, hipStream_t st);
 int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y, double* stats,
                     unsigned* absmax, hipStream_t st);
 // conv_wgrad_split.hip

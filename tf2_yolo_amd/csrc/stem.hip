@@ -6,6 +6,7 @@
 // BatchNorm statistics of the output accumulated on the way.
 #include "common.hpp"
 #include "conv_args.hpp"
+#include "act.hpp"
 
 namespace yolo {
 
@@ -161,6 +162,123 @@ __global__ __launch_bounds__(256) void stem_conv3x3_kernel(const float* __restri
   }
 }
 
+
+// ---- backward of the stem unit: BatchNorm + activation backward APPLY fused with the filter gradient ----
+// The unfused path writes d(conv out) of the 32-channel full-resolution tensor (709 MB at bs 32) only for the stem's
+// filter gradient to read it again (0.40 + 0.35 ms). Here every wave computes d(conv out) of 16 pixels x 32 channels
+// exactly as bn_bwd_apply8_kernel does, passes it through a 2 KB strip of LDS into the A operand of the fp32 MFMA
+// (v_mfma_f32_32x32x2_f32: channels x pixel pairs), gathers the 27 taps of those pixels from the image as the B
+// operand, and keeps the 32 x 27 filter gradient in 16 accumulator registers; nothing of size P x 32 is written.
+// Workgroup partials go to `partial` ([gridDim.x][1024] in accumulator order), stem_wgrad_sum_kernel adds them to dW.
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256) void stem_bn_bwd_wgrad_kernel(
+    const float* __restrict__ y, const float* __restrict__ dout, const float* __restrict__ img, long long P, int H, int W,
+    int pad_t, int pad_l, double invP, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ smean, const float* __restrict__ sinv, int act, const double* __restrict__ redsum,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ partial) {
+  constexpr int C = STEM_CO, TLD = 36;   // strip rows of 36 floats: 16-byte aligned, conflict-free column reads
+  __shared__ __attribute__((aligned(16))) float strip[4][16 * TLD];
+  __shared__ float wsum[4][1024];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 15, g = lane >> 4;   // apply role: pixel r of the block, channels 8g .. 8g+7
+  float sc[8], sh[8], mu[8], cb[8], ck[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int c = g * 8 + k;
+    sc[k] = scale[c];
+    sh[k] = shift[c];
+    mu[k] = smean[c];
+    const float mdz = (float)(redsum[c] * invP);
+    const float mdzx = (float)(redsum[C + c] * invP);
+    cb[k] = -sc[k] * sinv[c] * mdzx;
+    ck[k] = -sc[k] * mdz;
+    if (blockIdx.x == 0 && wave == 0 && r == 0) {   // dbeta = sum dz, dgamma = sum dz xhat (as bn_bwd_apply8_kernel)
+      if (dbeta != nullptr) dbeta[c] += (float)redsum[c];
+      if (dgamma != nullptr) dgamma[c] += (float)redsum[C + c];
+    }
+  }
+  // MFMA role: k-half kh = lane / 32 (pixel 2i + kh of the block), column n = lane % 32 = (r3 * 3 + s3) * 3 + ci
+  const int kh = lane >> 5, n = lane & 31;
+  const bool ncol = n < STEM_K;
+  const int tap = n / 3, ci = n - tap * 3;
+  const int dyo = tap / 3 - pad_t, dxo = tap % 3 - pad_l;
+  const int HW = H * W;
+  f32x16s acc;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+  float* st = &strip[wave][0];
+  const long long nblk = (P + 15) / 16;
+  for (long long blk = (long long)blockIdx.x * 4 + wave; blk < nblk; blk += (long long)gridDim.x * 4) {
+    const long long p0 = blk * 16;
+    // ---- d(conv out) of my pixel / my 8 channels ----
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    if (p0 + r < P) {
+      const long long e = (p0 + r) * C + g * 8;
+      const f32x4 x0 = *reinterpret_cast<const f32x4*>(y + e), x1 = *reinterpret_cast<const f32x4*>(y + e + 4);
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(dout + e), d1 = *reinterpret_cast<const f32x4*>(dout + e + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dz0 = d0[k] * act_grad(fmaf(sc[k], x0[k], sh[k]), act);
+        const float dz1 = d1[k] * act_grad(fmaf(sc[4 + k], x1[k], sh[4 + k]), act);
+        o0[k] = fmaf(sc[k], dz0, fmaf(cb[k], x0[k] - mu[k], ck[k]));
+        o1[k] = fmaf(sc[4 + k], dz1, fmaf(cb[4 + k], x1[k] - mu[4 + k], ck[4 + k]));
+      }
+    }
+    *reinterpret_cast<f32x4*>(st + r * TLD + g * 8) = o0;
+    *reinterpret_cast<f32x4*>(st + r * TLD + g * 8 + 4) = o1;
+    // ---- the taps of the block's pixels: pixel p0 + 2i + kh, column n ----
+    const int nimg0 = (int)(p0 / HW);
+    const int rem0 = (int)(p0 - (long long)nimg0 * HW);
+    const int y0 = rem0 / W, x0p = rem0 - y0 * W;
+    float bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = 2 * i + kh;
+      int xx = x0p + k, yy = y0, nn = nimg0;
+      while (xx >= W) { xx -= W; ++yy; }
+      while (yy >= H) { yy -= H; ++nn; }
+      const int iy = yy + dyo, ix = xx + dxo;
+      const bool ok = ncol && (p0 + k < P) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const float* q = img + ((long long)(nn * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3 + ci;
+      const float v = *q;
+      bv[i] = ok ? v : 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its own strip writes are visible to itself)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const float av = st[(2 * i + kh) * TLD + n];   // A[m = channel n][k = kh]
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[i], acc, 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next block's writes
+  }
+  // ---- workgroup partial: the four waves' accumulators added in wave order ----
+#pragma unroll
+  for (int q = 0; q < 16; ++q) wsum[wave][q * 64 + lane] = acc[q];
+  __syncthreads();
+  for (int e = threadIdx.x; e < 1024; e += 256)
+    partial[(long long)blockIdx.x * 1024 + e] = (wsum[0][e] + wsum[1][e]) + (wsum[2][e] + wsum[3][e]);
+}
+
+// dW[c][j] += sum over the workgroup partials, in partial order (no atomics: reproducible). Accumulator element
+// (q, lane): channel m = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), column j = lane & 31 (j < 27 exist).
+__global__ __launch_bounds__(1024) void stem_wgrad_sum_kernel(const float* __restrict__ partial, int nparts,
+                                                             float* __restrict__ dw) {
+  __shared__ float red[16][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), grp = threadIdx.x >> 6;   // 16 groups of partials
+  float s = 0.f;
+  for (int pidx = grp; pidx < nparts; pidx += 16) s += partial[(long long)pidx * 1024 + e];
+  red[grp][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (grp == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int gI = 0; gI < 16; ++gI) t += red[gI][threadIdx.x];
+    const int q = e >> 6, lane = e & 63;
+    const int m = (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5), j = lane & 31;
+    if (j < STEM_K) dw[m * STEM_K + j] += t;
+  }
+}
+
 bool stem_fwd_supported(const yolo_conv_desc* d) {
   static const bool on = [] { const char* e = getenv("YOLO_STEM_DIRECT"); return !(e && atoi(e) == 0); }();
   // (below ~1 M pixels - bs 1 inference - a lane gets a single pixel and the kernel is bound by the latency of its
@@ -218,6 +336,28 @@ int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, con
     hipLaunchKernelGGL((stem_conv3x3_kernel<false, false>), dim3(grid), dim3(256), 0, st, x, w, bias, y, stats, absmax, d->H,
                        d->W, d->pad_t, d->pad_l, M);
   return check_launch("stem_conv3x3_kernel");
+}
+
+// workgroups of the fused stem backward (= partials of 4 KB each in the caller's scratch): two resident rounds' worth
+constexpr int STEM_BWD_GRID = 1024;
+size_t stem_bwd_scratch_bytes() { return (size_t)STEM_BWD_GRID * 1024 * sizeof(float); }
+
+int launch_stem_bn_bwd_wgrad(const yolo_conv_desc* d, const float* y, const float* dout, const float* img,
+                             const float* scale, const float* shift, const float* smean, const float* sinv, int act,
+                             const double* redsum, float* dgamma, float* dbeta, float* dw, float* scratch,
+                             size_t scratch_bytes, hipStream_t st) {
+  const long long P = (long long)d->N * d->H * d->W;
+  if (scratch == nullptr || scratch_bytes < stem_bwd_scratch_bytes()) {
+    set_error("stem backward: scratch of %zu bytes needed", stem_bwd_scratch_bytes());
+    return YOLO_ERR_INVALID_ARG;
+  }
+  long long grid = (P / 16 + 3) / 4;
+  if (grid > STEM_BWD_GRID) grid = STEM_BWD_GRID;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(stem_bn_bwd_wgrad_kernel, dim3((unsigned)grid), dim3(256), 0, st, y, dout, img, P, d->H, d->W, d->pad_t,
+                     d->pad_l, 1.0 / (double)P, scale, shift, smean, sinv, act, redsum, dgamma, dbeta, scratch);
+  hipLaunchKernelGGL(stem_wgrad_sum_kernel, dim3(16), dim3(1024), 0, st, scratch, (int)grid, dw);
+  return check_launch("stem_bn_bwd_wgrad_kernel");
 }
 
 }  // namespace yolo

@@ -292,6 +292,7 @@ class Network:
         self._wT_valid = False
         self._overlap_wgrad = os.environ.get("YOLO_BWD_OVERLAP", "1") != "0"
         self._prep_beside = os.environ.get("YOLO_PREP_OVERLAP", "1") != "0"   # filter preparation beside the stem
+        self._stem_fused = os.environ.get("YOLO_STEM_FUSED_BWD", "1") != "0"  # stem: BN backward apply + wgrad in one pass
         self._wp_event = self._wT_event = None
         self._use_infer_graph = os.environ.get("YOLO_INFER_GRAPH", "1") != "0"
         self._fuse_infer = os.environ.get("YOLO_INFER_FUSE", "1") != "0"
@@ -798,6 +799,14 @@ class Network:
                     need_pl = u.planes_wgrad or u.planes_dgrad
                     need_f32 = ((not u.planes_wgrad) or u.p_bias is not None
                                 or (self._needs_grad[u.src.tid] and not u.planes_dgrad))
+                    if (self._stem_fused and not need_pl and not self._needs_grad[u.src.tid] and u.p_bias is None
+                            and ops.stem_bn_bwd_supported(u.desc)):
+                        # the stem: BN / activation backward apply + filter gradient in one pass, no 32-channel dy tensor
+                        ops.stem_bn_bwd_wgrad(u.desc, xin, u.y, dout, scale, shift, smean, sinv, u.act, red,
+                                              self._gview(u.p_gamma), self._gview(u.p_beta), self._gview(u.p_kernel))
+                        if self.grad_ready_hook is not None:
+                            self.grad_ready_hook(u)
+                        continue
                     dyp = self._next_dyp_buffer() if need_pl else None
                     dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
                                         sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta),

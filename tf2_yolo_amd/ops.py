@@ -501,6 +501,38 @@ def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red
     return dx if want_dx else None
 
 
+_STEM_SCRATCH = None
+
+
+def stem_bn_bwd_supported(d):
+    """the fused stem backward (csrc/stem.hip): Conv2D(32, 3x3, stride 1, 'same') on 3 channels"""
+    return (d.Cin == 3 and d.Cout == 32 and d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.Ho == d.H
+            and d.Wo == d.W and d.W >= 16)
+
+
+def stem_bn_bwd_wgrad(d, image, y, dout, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dw):
+    """backward of the stem unit in one pass over (y, dout): yolo_bn_act_bwd_reduce, then the apply step fused with the
+    filter gradient (yolo_stem_bn_bwd_wgrad); dw / dgamma / dbeta are accumulated"""
+    global _STEM_SCRATCH
+    _chk_f32(image, y, dout, scale, shift, save_mean, save_invstd, dgamma, dbeta, dw)
+    lib = _lib.load()
+    P = d.N * d.H * d.W
+    if image.numel() != P * 3 or y.numel() != P * 32 or dout.numel() != P * 32 or dw.numel() != 32 * 27:
+        raise YoloHipError("stem_bn_bwd_wgrad: tensor sizes do not match the descriptor")
+    if _STEM_SCRATCH is None or _STEM_SCRATCH.device != y.device:
+        _STEM_SCRATCH = torch.empty(int(lib.yolo_stem_bwd_scratch_bytes()), dtype=torch.uint8, device=y.device)
+    check(lib.yolo_bn_act_bwd_reduce_bound(_p(y), _p(dout), P, 32, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
+                                           act, _p(red), _p(None), _stream()), "yolo_bn_act_bwd_reduce")
+    def run():
+        check(lib.yolo_stem_bn_bwd_wgrad(byref(d), _p(y), _p(dout), _p(image), _p(scale), _p(shift), _p(save_mean),
+                                         _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta), _p(dw), _p(_STEM_SCRATCH),
+                                         _STEM_SCRATCH.numel(), _stream()), "yolo_stem_bn_bwd_wgrad")
+    if TIMER is not None:
+        TIMER.bracket("stem_bn_bwd_wgrad_kernel", _conv_flops(d), 1, run)
+    else:
+        run()
+
+
 def act_fwd(x, act, out=None):
     if out is None:
         out = torch.empty_like(x)
