@@ -2,7 +2,7 @@
 # of the network (208x208 / 416x416, 32-64 channels), where the step is furthest from its floors
 TAG=${1:-r02_front}
 R=$PWD; export TMPDIR=/tmp
-OUT=$R/gpurun_out/${TAG}_conv_pmc.jsonl; : > $OUT
+OUT=$R/gpurun_out/${TAG}_layers_pmc.jsonl; : > $OUT
 GROUPS_=("GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
          "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_INSTS_VALU" \
          "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TA_BUSY_avr" "FETCH_SIZE" "WRITE_SIZE")
@@ -21,4 +21,4 @@ run_one l2_fwd_3x3s2_416_32to64 gather_conv_planes_kernel fwd 416,32,64,3,2,32
 run_one l2_dgrad_3x3s2_416_32to64 gather_conv_planes_kernel dgrad 416,32,64,3,2,32
 run_one l5_fwd_3x3s2_208_64to128 gather_conv_planes_kernel fwd 208,64,128,3,2,32
 run_one l7_dgrad_3x3_104_64to128 gather_conv_planes_kernel dgrad 104,64,128,3,1,32
-python3 $R/scripts/pmc_json.py $OUT > $R/gpurun_out/${TAG}_conv_pmc.json
+python3 $R/scripts/pmc_json.py $OUT > $R/gpurun_out/${TAG}_layers_pmc.json
