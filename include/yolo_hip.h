@@ -257,6 +257,12 @@ int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scal
                            int act, const float* residual, float* out, void* planes,
                            const unsigned* bn_bound, const float* residual_bound, float* out_bound,
                            void* stream);
+/* yolo_bn_act_fwd_planes with the residual given AS PLANES (the operand format its producer wrote for the convolutions:
+ * h + l = the value to 22-23 bits, the bound in the planes header): the fp32 copy of a residual block's input then need
+ * not exist. C % 16 == 0. */
+int yolo_bn_act_fwd_res_planes(const float* x, long long P, int C, const float* scale, const float* shift, int act,
+                               const void* residual_planes, float* out, void* planes, const unsigned* bn_bound,
+                               float* out_bound, void* stream);
 int yolo_bn_act_bwd_reduce_bound(const float* x, const float* dout, long long P, int C, const float* scale,
                                  const float* shift, const float* save_mean, const float* save_invstd,
                                  int act, double* red, unsigned* bound_aux, void* stream);

@@ -247,3 +247,42 @@ def test_bn_kernels_emit_planes(C, act, use_res):
     only = ops.bn_act_bwd(x, dout, C, gd, scale, shift, smean, sinv, act, red, None, None, planes=pl2, want_dx=False,
                           bound_aux=aux[1:69])
     assert only is None
+
+
+@pytest.mark.parametrize("C,act", [(32, 1), (64, 2), (128, 1), (48, 1)])
+def test_bn_act_fwd_residual_from_planes(C, act):
+    """yolo_bn_act_fwd_res_planes: the residual read from its PLANES (h + l = the value to 22-23 bits, bound from the planes
+    header) instead of an fp32 copy -- what the engine does for residual blocks in training, so that the fp32 copy of a
+    block's input is never written. Against the fp32-residual kernel: identical up to the planes' rounding of the
+    residual (2^-22 of the value or 2^-25 / scale), the output bound is bn bound + residual bound."""
+    from planes_util import planes_to_dense
+    from tf2_yolo_amd import ops
+    g = torch.Generator().manual_seed(100 + C + act)
+    N, H, W = 2, 9, 7
+    P = N * H * W
+    x = (torch.randn(N, H, W, C, generator=g) * 2 + 0.3).cuda()
+    res = (torch.randn(N, H, W, C, generator=g) * 3).cuda()
+    scale = (torch.rand(C, generator=g) + 0.5).cuda()
+    shift = torch.randn(C, generator=g).cuda()
+    rpl = ops.split_planes(res, P, C)
+    rdense, rbound, rs, _ = planes_to_dense(rpl.cpu(), P, C)
+    bnb = torch.tensor([float(ops.bn_act_fwd(x, C, scale, shift, act).abs().max()) * 1.01], device="cuda").view(torch.int32)
+    ob, ob2 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    pl = torch.zeros(ops.planes_bytes(P, C), device="cuda", dtype=torch.uint8)
+    pl2 = torch.zeros(ops.planes_bytes(P, C), device="cuda", dtype=torch.uint8)
+    o = ops.bn_act_fwd(x, C, scale, shift, act, None, planes=pl, bn_bound=bnb, out_bound=ob, residual_planes=rpl)
+    o_ref = ops.bn_act_fwd(x, C, scale, shift, act, res, planes=pl2, bn_bound=bnb,
+                           residual_bound=torch.tensor([rbound], device="cuda"), out_bound=ob2)
+    torch.cuda.synchronize()
+    assert float(ob) == float(ob2)
+    # exactly act(bn(x)) + the DECODED residual
+    plain = ops.bn_act_fwd(x, C, scale, shift, act)
+    assert torch.equal(o, plain + rdense.float().reshape(N, H, W, C).cuda())
+    err = (o.double() - o_ref.double()).abs().cpu().reshape(P, C)
+    lim = torch.maximum(2.0 ** -22 * res.double().abs().cpu().reshape(P, C), torch.tensor(2.0 ** -24 / rs, dtype=torch.float64))
+    assert (err <= lim + 2.0 ** -22 * o_ref.double().abs().cpu().reshape(P, C)).all()   # (+ one fp32 rounding of each sum)
+    # planes-only form (no fp32 output at all)
+    pl3 = torch.zeros(ops.planes_bytes(P, C), device="cuda", dtype=torch.uint8)
+    assert ops.bn_act_fwd(x, C, scale, shift, act, None, planes=pl3, bn_bound=bnb, want_out=False, residual_planes=rpl) is None
+    torch.cuda.synchronize()
+    assert torch.equal(pl3, pl)

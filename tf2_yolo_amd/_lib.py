@@ -72,6 +72,7 @@ SIGNATURES = {
     "yolo_bn_act_bwd_reduce": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P]),
     "yolo_bn_act_bwd_apply": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P]),
     "yolo_bn_act_fwd_planes": (c_int, [_P, _LL, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "yolo_bn_act_fwd_res_planes": (c_int, [_P, _LL, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "yolo_bn_act_bwd_apply_planes": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
                                              _P]),
     "yolo_bn_infer_bound": (c_int, [c_int, _P, _P, _P, _P, _P]),

@@ -330,13 +330,18 @@ __global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restric
                                                           unsigned char* __restrict__ planes,
                                                           const unsigned* __restrict__ bn_bound,
                                                           const float* __restrict__ res_bound,
-                                                          float* __restrict__ out_bound) {
+                                                          float* __restrict__ out_bound,
+                                                          const unsigned char* __restrict__ res_planes) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the residual may come as planes (the operand format its producer wrote for the convolutions: h + l = the value
+  // to 22-23 bits; then its fp32 copy need not exist at all): header = {bound, scale, 1 / scale}
+  const float* rhead = res_planes != nullptr ? reinterpret_cast<const float*>(res_planes + planes_body_bytes(P, C)) : nullptr;
+  const float rinv = rhead != nullptr ? rhead[2] : 0.f;
   // bound of the output = bound of the BN/activation part (bn_finalize) + bound of the residual
   float psc = 1.f;
   if (PLANES || out_bound != nullptr) {
     const float b = (bn_bound ? __builtin_bit_cast(float, bn_bound[0]) : 0.f) +
-                    ((res != nullptr && res_bound != nullptr) ? res_bound[0] : 0.f);
+                    (rhead != nullptr ? rhead[0] : (res != nullptr && res_bound != nullptr) ? res_bound[0] : 0.f);
     if (out_bound != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) out_bound[0] = b;
     if (PLANES) psc = planes_begin(planes, P, C, b);
   }
@@ -359,7 +364,15 @@ __global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restric
         o0[k] = act_fwd(fmaf(sc0[k], x0[k], sh0[k]), act);
         o1[k] = act_fwd(fmaf(sc1[k], x1[k], sh1[k]), act);
       }
-      if (res != nullptr) {
+      if (res_planes != nullptr) {
+        const unsigned char* ru = res_planes + planes_unit_offset(p, g8, C);
+        const f16x8 rh = *reinterpret_cast<const f16x8*>(ru), rl = *reinterpret_cast<const f16x8*>(ru + 512);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          o0[k] += ((float)rh[k] + (float)rl[k]) * rinv;           // (h + l exact in fp32, 1 / scale a power of two)
+          o1[k] += ((float)rh[4 + k] + (float)rl[4 + k]) * rinv;
+        }
+      } else if (res != nullptr) {
         o0 += *reinterpret_cast<const f32x4*>(res + e);
         o1 += *reinterpret_cast<const f32x4*>(res + e + 4);
       }
@@ -581,10 +594,32 @@ extern "C" int yolo_bn_infer_bound(int C, const float* scale, const float* shift
   return check_launch("bn_infer_bound_kernel");
 }
 
+static int bn_act_fwd_impl(const float* x, long long P, int C, const float* scale, const float* shift, int act,
+                           const float* residual, float* out, void* planes, const unsigned* bn_bound,
+                           const float* residual_bound, float* out_bound, const void* residual_planes, void* stream);
+
 extern "C" int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scale, const float* shift,
                                       int act, const float* residual, float* out, void* planes,
                                       const unsigned* bn_bound, const float* residual_bound, float* out_bound,
                                       void* stream) {
+  return bn_act_fwd_impl(x, P, C, scale, shift, act, residual, out, planes, bn_bound, residual_bound, out_bound, nullptr,
+                         stream);
+}
+
+// the residual given as PLANES (what its producer wrote for the convolutions; its bound comes from their header): the
+// fp32 copy of a residual block's input then need not be written at all. C % 16 == 0.
+extern "C" int yolo_bn_act_fwd_res_planes(const float* x, long long P, int C, const float* scale, const float* shift,
+                                          int act, const void* residual_planes, float* out, void* planes,
+                                          const unsigned* bn_bound, float* out_bound, void* stream) {
+  YOLO_REQUIRE(residual_planes != nullptr && C % 16 == 0, "bn_act_fwd_res_planes: needs residual planes and C %% 16 == 0");
+  return bn_act_fwd_impl(x, P, C, scale, shift, act, nullptr, out, planes, bn_bound, nullptr, out_bound, residual_planes,
+                         stream);
+}
+
+static int bn_act_fwd_impl(const float* x, long long P, int C, const float* scale, const float* shift, int act,
+                           const float* residual, float* out, void* planes, const unsigned* bn_bound,
+                           const float* residual_bound, float* out_bound, const void* residual_planes, void* stream) {
+  const unsigned char* rpl = reinterpret_cast<const unsigned char*>(residual_planes);
   YOLO_REQUIRE(x && scale && shift && (out || (planes && C % 8 == 0)) && P > 0 && C > 0, "bn_act_fwd: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_fwd: C=%d must be a multiple of 4", C);
   YOLO_REQUIRE(act >= 0 && act <= 2, "bn_act_fwd: bad activation %d", act);
@@ -598,11 +633,11 @@ extern "C" int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const 
     if (planes)
       hipLaunchKernelGGL(bn_act_fwd8_kernel<true>, dim3(g.gx, g.gy), dim3(256), 0, as_stream(stream), x, P, C, g.wpr,
                          g.blocks_per_wg, rows, scale, shift, act, residual, out,
-                         reinterpret_cast<unsigned char*>(planes), bn_bound, residual_bound, out_bound);
+                         reinterpret_cast<unsigned char*>(planes), bn_bound, residual_bound, out_bound, rpl);
     else
       hipLaunchKernelGGL(bn_act_fwd8_kernel<false>, dim3(g.gx, g.gy), dim3(256), 0, as_stream(stream), x, P, C, g.wpr,
                          g.blocks_per_wg, rows, scale, shift, act, residual, out, (unsigned char*)nullptr, bn_bound,
-                         residual_bound, out_bound);
+                         residual_bound, out_bound, rpl);
     return check_launch("bn_act_fwd8_kernel");
   }
   const long long n4 = P * (C / 4);

@@ -293,6 +293,7 @@ class Network:
         self._overlap_wgrad = os.environ.get("YOLO_BWD_OVERLAP", "1") != "0"
         self._prep_beside = os.environ.get("YOLO_PREP_OVERLAP", "1") != "0"   # filter preparation beside the stem
         self._stem_fused = os.environ.get("YOLO_STEM_FUSED_BWD", "1") != "0"  # stem: BN backward apply + wgrad in one pass
+        self._res_from_planes = os.environ.get("YOLO_RES_PLANES", "1") != "0"  # residual adds read the planes, not an fp32 copy
         self._wp_event = self._wT_event = None
         self._use_infer_graph = os.environ.get("YOLO_INFER_GRAPH", "1") != "0"
         self._fuse_infer = os.environ.get("YOLO_INFER_FUSE", "1") != "0"
@@ -370,9 +371,17 @@ class Network:
         for u in self.units:
             if u.kind == "conv":
                 cs = consumers.get(u.out.tid, [])
-                u.a_needed = (not cs) or (u.out.tid in out_tids) or u.cout % 16 != 0 or any(
-                    not (c.kind in ("conv", "head") and c.src.tid == u.out.tid and getattr(c, "residual", None) is not u.out
-                         and c.planes_fwd and c.planes_wgrad) for c in cs)
+                # the fp32 copy of a conv unit's output is written in training only if somebody reads it: consumers that take
+                # it as a planes operand (planes conv / head units) do not, nor do conv + BN units that ADD it as their
+                # residual (bn_act_fwd reads the residual from the planes too, yolo_bn_act_fwd_res_planes)
+                def reads_planes_only(c):
+                    if c.kind in ("conv", "head") and c.src.tid == u.out.tid and getattr(c, "residual", None) is not u.out:
+                        return c.planes_fwd and c.planes_wgrad
+                    return (self._res_from_planes and c.kind == "conv" and c.bn and getattr(c, "residual", None) is u.out
+                            and c.src.tid != u.out.tid and c.cout % 16 == 0)
+                has_planes_src = any(c.kind in ("conv", "head") and c.src.tid == u.out.tid and c.planes_fwd for c in cs)
+                u.a_needed = ((not cs) or (u.out.tid in out_tids) or u.cout % 16 != 0 or not has_planes_src
+                              or any(not reads_planes_only(c) for c in cs))
         self._wp_valid = False
         self._wTp_valid = False
         self._jobs_wp = self._jobs_wTp = self._jobs_wT = None
@@ -666,6 +675,10 @@ class Network:
                                                   self.state.view(u.s_var.name), scale, shift)
                         ops.bn_infer_bound(u.cout, scale, shift, amax, self._aux[u.aux_off:u.aux_off + 1])
                     res = self.act[u.residual.tid] if u.residual is not None else None
+                    res_pl = None
+                    if (res is not None and training and self._res_from_planes and u.cout % 16 == 0
+                            and u.residual.tid in self._xp_valid and u.residual.tid in self._tbound_set):
+                        res_pl, res = self._xplanes[u.residual.tid], None   # (its fp32 copy may not have been written)
                     # consumers that are planes-capable convs get their operand straight from this kernel; the scale
                     # comes from the bound bn_finalize (training) / bn_infer_bound (inference) derived from the conv
                     # epilogue's per-channel max|y|
@@ -678,8 +691,8 @@ class Network:
                     ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a, planes=pl,
                                    want_out=not (training and pl is not None and not u.a_needed),
                                    bn_bound=self._aux[u.aux_off:u.aux_off + 1],
-                                   residual_bound=tb[u.residual.tid:u.residual.tid + 1] if u.residual is not None else None,
-                                   out_bound=tb[u.out.tid:u.out.tid + 1])
+                                   residual_bound=tb[u.residual.tid:u.residual.tid + 1] if res is not None else None,
+                                   out_bound=tb[u.out.tid:u.out.tid + 1], residual_planes=res_pl)
                     if pl is not None:
                         self._xp_valid.add(u.out.tid)
                 else:

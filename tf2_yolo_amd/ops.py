@@ -458,7 +458,7 @@ def bn_fold_inference(C, gamma, beta, moving_mean, moving_var, scale, shift, eps
 
 
 def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None, planes=None, bn_bound=None, residual_bound=None,
-               out_bound=None, want_out=True):
+               out_bound=None, want_out=True, residual_planes=None):
     """planes: optional uint8 buffer (planes_bytes(P, C)) that also receives the result in the conv operand format;
     it needs bn_bound (from bn_finalize) and, with a residual, residual_bound (1 float: bound of the residual
     tensor). out_bound (1 float, optional) receives the bound of the result. want_out=False (with planes): only the
@@ -472,6 +472,13 @@ def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None, planes=None, bn
     P = x.numel() // C
     if planes is not None and planes.numel() < planes_bytes(P, C):
         raise YoloHipError("bn_act_fwd: planes buffer too small")
+    if residual_planes is not None:   # the residual in the conv operand format (its fp32 copy need not exist)
+        if residual is not None or residual_planes.numel() < planes_bytes(P, C):
+            raise YoloHipError("bn_act_fwd: give the residual either as fp32 or as planes of the same shape")
+        check(_lib.load().yolo_bn_act_fwd_res_planes(_p(x), P, C, _p(scale), _p(shift), act, _p(residual_planes), _p(out),
+                                                     _p(planes), _p(bn_bound), _p(out_bound), _stream()),
+              "yolo_bn_act_fwd_res_planes")
+        return out
     check(_lib.load().yolo_bn_act_fwd_planes(_p(x), P, C, _p(scale), _p(shift), act, _p(residual), _p(out), _p(planes),
                                              _p(bn_bound), _p(residual_bound), _p(out_bound), _stream()),
           "yolo_bn_act_fwd")
