@@ -468,6 +468,23 @@ __global__ __launch_bounds__(256) void bn_bwd_sum_kernel(int C, double* __restri
   double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
   if (c < C) {
     int r = grp;
+    // eight slots (sixteen loads) in flight per round trip: with two, the 512 slots of a large layer were sixteen
+    // dependent round trips = 8 us of a kernel that moves a few hundred KB
+    for (; r + 112 < nslots; r += 128) {
+      double v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v0[u] = red[(long long)(r + 16 * u) * 2 * C + c];
+        v1[u] = red[(long long)(r + 16 * u) * 2 * C + C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        a0 += v0[u];
+        a1 += v1[u];
+        b0 += v0[u + 1];
+        b1 += v1[u + 1];
+      }
+    }
     for (; r + 16 < nslots; r += 32) {
       a0 += red[(long long)r * 2 * C + c];
       a1 += red[(long long)r * 2 * C + C + c];
