@@ -13,6 +13,8 @@ namespace yolo {
 constexpr int STEM_CO = 32;
 constexpr int STEM_K = 27;
 
+__device__ float g_stem_wt[8 * (STEM_K + 1) * STEM_CO];   // ring of prepared stem filters (launch_stem_fwd)
+
 // the filter as [j = (r*3+s)*3+ci][co] + a bias row, for the kernel that takes it through the SCALAR cache
 __global__ __launch_bounds__(256) void stem_filter_prep_kernel(const float* __restrict__ w, const float* __restrict__ bias,
                                                               float* __restrict__ wt) {
@@ -296,9 +298,10 @@ int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, con
   // YOLO_STEM_SREG=0: the filter broadcast from LDS (round 1's kernel) instead of the scalar cache
   static const bool sreg = [] { const char* e = getenv("YOLO_STEM_SREG"); return !(e && atoi(e) == 0); }();
   static float* wt_ring = nullptr;   // 8 prepared filters (3.5 KB each), used round robin: launches in flight never share one
-  static unsigned wt_next = 0;
-  if (sreg && wt_ring == nullptr && hipMalloc(reinterpret_cast<void**>(&wt_ring), 8 * (STEM_K + 1) * STEM_CO * sizeof(float)) != hipSuccess) {
-    set_error("stem: hipMalloc of the filter scratch failed");
+  static unsigned wt_next = 0;        // (a __device__ array of the library: nothing is allocated at run time)
+  if (sreg && wt_ring == nullptr &&
+      hipGetSymbolAddress(reinterpret_cast<void**>(&wt_ring), HIP_SYMBOL(g_stem_wt)) != hipSuccess) {
+    set_error("stem: hipGetSymbolAddress of the filter scratch failed");
     return YOLO_ERR_LAUNCH;
   }
   static int per_cu[2] = {0, 0};
