@@ -25,6 +25,7 @@ def timeit(f, iters=20):
 
 def main():
     lib = _lib.load()
+    ACT = int(os.environ.get("BN_BENCH_ACT", "1"))    # 1 = LeakyReLU, 2 = Mish
     for P, C in SHAPES:
         x = torch.randn(P, C, device="cuda")
         dout = torch.randn(P, C, device="cuda")
@@ -38,16 +39,16 @@ def main():
         n = P * C
 
         def reduce():
-            ops.check(lib.yolo_bn_act_bwd_reduce_bound(_p(x), _p(dout), P, C, _p(scale), _p(shift), _p(mean), _p(inv), 1,
+            ops.check(lib.yolo_bn_act_bwd_reduce_bound(_p(x), _p(dout), P, C, _p(scale), _p(shift), _p(mean), _p(inv), ACT,
                                                        _p(red), _p(aux), _stream()), "reduce")
 
         def apply():
             ops.check(lib.yolo_bn_act_bwd_apply_planes(_p(x), _p(dout), P, C, _p(scale), _p(scale), _p(shift), _p(mean), _p(inv),
-                                                       1, _p(red), _p(dg), _p(db), None, _p(planes), _p(aux), _stream()), "apply")
+                                                       ACT, _p(red), _p(dg), _p(db), None, _p(planes), _p(aux), _stream()), "apply")
 
         def fwd():
             bound.fill_(0x40800000)
-            ops.bn_act_fwd(x, C, scale, shift, 1, planes=planes, want_out=False, bn_bound=bound)
+            ops.bn_act_fwd(x, C, scale, shift, ACT, planes=planes, want_out=False, bn_bound=bound)
 
         t_r, t_a, t_f = timeit(reduce), timeit(apply), timeit(fwd)
         print(f"P={P:8d} C={C:5d}  reduce+sum {t_r*1e6:7.1f} us {8*n/t_r/1e12:5.2f} TB/s | apply(planes) {t_a*1e6:7.1f} us "
