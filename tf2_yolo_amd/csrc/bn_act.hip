@@ -7,6 +7,7 @@
 //   yolov{1_5,2}/models/backbone.py:9-18.
 #include "planes.hpp"
 #include "act.hpp"
+#include <type_traits>
 
 namespace yolo {
 
@@ -199,32 +200,41 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const long long p_lo = (long long)blockIdx.x * per_block;
     const long long p_hi = (p_lo + per_block < P) ? p_lo + per_block : P;
     const long long stride = rpp;
-    for (long long p = p_lo + row_lane; p < p_hi; p += 4 * stride) {
-      // all 8 loads are issued unconditionally (rows past the end re-read row p and are zeroed afterwards):
-      // a per-load "in range ? load : 0" makes hipcc branch around every load and wait for each in turn
-      f32x4 xv[4], dv[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const long long pu = p + u * stride;
-        const long long pc = pu < p_hi ? pu : p;
-        xv[u] = *reinterpret_cast<const f32x4*>(x + pc * C + c4 * 4);
-        dv[u] = *reinterpret_cast<const f32x4*>(dout + pc * C + c4 * 4);
-      }
-#pragma unroll
-      for (int u = 1; u < 4; ++u)
-        if (p + u * stride >= p_hi) dv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float z = fmaf(sc[e], xv[u][e], sh[e]);
-          const float dz = dv[u][e] * act_grad(z, act);   // dv = 0 for out-of-range rows
-          mdz = fmaxf(mdz, fabsf(dz));
-          const float xh = (xv[u][e] - mu[e]) * iv[e];
-          v[0][e] += (double)dz;
-          v[1][e] += (double)dz * (double)xh;
+    // the activation is a compile-time constant inside the loop (a run-time `act` leaves three scalar branches per
+    // ELEMENT in it): 1-5 % on the BatchNorm passes in same-box A/Bs. (The Mish reduce stays VALU-bound either way --
+    // 230-245 us for a tensor that LeakyReLU streams in 130 -- and its time differs by 40 % from box to box.)
+    auto sweep = [&](auto ACT_) {
+      constexpr int A = decltype(ACT_)::value;
+      for (long long p = p_lo + row_lane; p < p_hi; p += 4 * stride) {
+        // all 8 loads are issued unconditionally (rows past the end re-read row p and are zeroed afterwards):
+        // a per-load "in range ? load : 0" makes hipcc branch around every load and wait for each in turn
+        f32x4 xv[4], dv[4];
+  #pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const long long pu = p + u * stride;
+          const long long pc = pu < p_hi ? pu : p;
+          xv[u] = *reinterpret_cast<const f32x4*>(x + pc * C + c4 * 4);
+          dv[u] = *reinterpret_cast<const f32x4*>(dout + pc * C + c4 * 4);
         }
-    }
+  #pragma unroll
+        for (int u = 1; u < 4; ++u)
+          if (p + u * stride >= p_hi) dv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+  #pragma unroll
+        for (int u = 0; u < 4; ++u)
+  #pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float z = fmaf(sc[e], xv[u][e], sh[e]);
+            const float dz = dv[u][e] * act_grad(z, A);   // dv = 0 for out-of-range rows
+            mdz = fmaxf(mdz, fabsf(dz));
+            const float xh = (xv[u][e] - mu[e]) * iv[e];
+            v[0][e] += (double)dz;
+            v[1][e] += (double)dz * (double)xh;
+          }
+      }
+    };
+    if (act == YOLO_ACT_MISH) sweep(std::integral_constant<int, YOLO_ACT_MISH>{});
+    else if (act == YOLO_ACT_LEAKY) sweep(std::integral_constant<int, YOLO_ACT_LEAKY>{});
+    else sweep(std::integral_constant<int, YOLO_ACT_LINEAR>{});
   }
   block_col_reduce<2, true>(v, cw, rpp, row_lane, col, active, smem, red, C, c4);
   if (aux != nullptr) {   // max |dz| of the tensor (bit patterns of non-negative floats order like integers):
@@ -353,6 +363,11 @@ __global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restric
   const long long rb_lo = (long long)blockIdx.x * blocks_per_wg;
   long long p_hi = (rb_lo + blocks_per_wg) * 16;
   if (p_hi > rows_total) p_hi = rows_total;
+  // (LeakyReLU as a compile-time constant inside the loop, see bn_bwd_reduce_kernel: 1-5 % on this pass. Mish keeps the
+  // run-time value: specialised, its arithmetic differs in the last bit from one instantiation to the next, and the
+  // fused inference epilogue / the planes and plain forms of these kernels are tested to be bit-identical)
+  auto sweep = [&](auto ACT_) {
+    const int A = ACT_;
 #pragma unroll 2
   for (long long p = (rb_lo + wave / wpr) * 16 + (lane & 15); p < p_hi; p += 16 * slots) {
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
@@ -361,8 +376,8 @@ __global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restric
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + e), x1 = *reinterpret_cast<const f32x4*>(x + e + 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        o0[k] = act_fwd(fmaf(sc0[k], x0[k], sh0[k]), act);
-        o1[k] = act_fwd(fmaf(sc1[k], x1[k], sh1[k]), act);
+        o0[k] = act_fwd(fmaf(sc0[k], x0[k], sh0[k]), A);
+        o1[k] = act_fwd(fmaf(sc1[k], x1[k], sh1[k]), A);
       }
       if (res_planes != nullptr) {
         const unsigned char* ru = res_planes + planes_unit_offset(p, g8, C);
@@ -383,6 +398,9 @@ __global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restric
     }
     if (PLANES) store_planes8(planes, p, g8, C, o0, o1, psc);
   }
+  };
+  if (act == YOLO_ACT_LEAKY) sweep(std::integral_constant<int, YOLO_ACT_LEAKY>{});
+  else sweep(act);
 }
 
 // dx = scale * (dz - mean(dz) - xhat * mean(dz * xhat)),  dz = dout * act'(scale*x + shift)
@@ -433,6 +451,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
   const long long rb_lo = (long long)blockIdx.x * blocks_per_wg;
   long long p_hi = (rb_lo + blocks_per_wg) * 16;
   if (p_hi > rows_total) p_hi = rows_total;
+  // (LeakyReLU as a compile-time constant inside the loop, see bn_bwd_reduce_kernel: 1-5 % on this pass. Mish keeps the
+  // run-time value: specialised, its arithmetic differs in the last bit from one instantiation to the next, and the
+  // fused inference epilogue / the planes and plain forms of these kernels are tested to be bit-identical)
+  auto sweep = [&](auto ACT_) {
+    const int A = ACT_;
 #pragma unroll 2
   for (long long p = (rb_lo + wave / wpr) * 16 + (lane & 15); p < p_hi; p += 16 * slots) {
     f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
@@ -442,8 +465,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
       const f32x4 d0 = *reinterpret_cast<const f32x4*>(dout + e), d1 = *reinterpret_cast<const f32x4*>(dout + e + 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float dz0 = d0[k] * act_grad(fmaf(sc[k], x0[k], sh[k]), act);
-        const float dz1 = d1[k] * act_grad(fmaf(sc[4 + k], x1[k], sh[4 + k]), act);
+        const float dz0 = d0[k] * act_grad(fmaf(sc[k], x0[k], sh[k]), A);
+        const float dz1 = d1[k] * act_grad(fmaf(sc[4 + k], x1[k], sh[4 + k]), A);
         o0[k] = fmaf(sc[k], dz0, fmaf(cb[k], x0[k] - mu[k], ck[k]));
         o1[k] = fmaf(sc[4 + k], dz1, fmaf(cb[4 + k], x1[k] - mu[4 + k], ck[4 + k]));
       }
@@ -454,6 +477,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
     }
     if (PLANES) store_planes8(planes, p, g8, C, o0, o1, psc);
   }
+  };
+  if (act == YOLO_ACT_LEAKY) sweep(std::integral_constant<int, YOLO_ACT_LEAKY>{});
+  else sweep(act);
 }
 
 // red layout: [SLOTS replicas][2][C] followed by the final [2][C] sums
