@@ -120,24 +120,49 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
       eshj[j] = (a.epi_scale != nullptr && col < a.Cout) ? a.epi_shift[col] : 0.f;
     }
     const bool fused = a.epi_scale != nullptr;
+    // The loop-invariant choices are made ONCE, outside the 64-value loops (hipcc leaves a scalar branch per value and
+    // choice in them otherwise): the fused inference epilogue rewrites the accumulators in place first (the same
+    // operations in the same order; the common path then sees v = fma(acc, 1, 0) = acc), and the statistics have their
+    // own copy of the staging loop.
+    float us2 = unscale;
+    if (fused) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            acc[i][j][q] = act_fwd(fmaf(escj[j], fmaf(acc[i][j][q], unscale, bvj[j]), eshj[j]), a.epi_act);
+      us2 = 1.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bvj[j] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int hp = 0; hp < 32 / RP; ++hp) {       // RP = 16: registers 0..7 (rows 0..15), then 8..15 (rows 16..31)
         const int row0 = (wm * TM + i) * 32 + hp * RP;          // first tile row of this pass (wave-uniform)
+        if (want_stats) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
+          for (int j = 0; j < TN; ++j) {
 #pragma unroll
-          for (int q = hp * (RP / 2); q < (hp + 1) * (RP / 2); ++q) {
-            const int rl = (q & 3) + 8 * ((q >> 2) - hp * (RP / 8)) + 4 * (lane >> 5);   // row inside the pass
-            float v = fmaf(acc[i][j][q], unscale, bvj[j]);
-            if (fused) v = act_fwd(fmaf(escj[j], v, eshj[j]), a.epi_act);
-            strip[rl * TLD + j * 32 + (lane & 31)] = v;
-            if (want_stats) {
+            for (int q = hp * (RP / 2); q < (hp + 1) * (RP / 2); ++q) {
+              const int rl = (q & 3) + 8 * ((q >> 2) - hp * (RP / 8)) + 4 * (lane >> 5);   // row inside the pass
+              const float v = fmaf(acc[i][j][q], us2, bvj[j]);
+              strip[rl * TLD + j * 32 + (lane & 31)] = v;
               const float vm = (row0 + rl < rows_valid) ? v : 0.f;
               csum[j] += vm;
               csq[j] = fmaf(vm, vm, csq[j]);
               cmx[j] = fmaxf(cmx[j], fabsf(vm));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int q = hp * (RP / 2); q < (hp + 1) * (RP / 2); ++q) {
+              const int rl = (q & 3) + 8 * ((q >> 2) - hp * (RP / 8)) + 4 * (lane >> 5);
+              strip[rl * TLD + j * 32 + (lane & 31)] = fmaf(acc[i][j][q], us2, bvj[j]);
             }
           }
         }
