@@ -1,10 +1,10 @@
-# Builds the gfx950 C-ABI library (libyolo_hip.so) and the oracle's C helpers.
+# Builds the gfx950 C-ABI library (libyolo_hip.so). The oracle is Python (the reference is Python): nothing to compile for it.
 # hipcc cross-compiles without a GPU present.
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := tf2_yolo_amd/csrc
 SRCS  := $(CSRC)/runtime.hip $(CSRC)/conv.hip $(CSRC)/conv_split.hip $(CSRC)/conv_wgrad_split.hip $(CSRC)/conv_planes.hip $(CSRC)/conv_win.hip $(CSRC)/conv_wgrad_planes.hip $(CSRC)/stem.hip $(CSRC)/bn_act.hip $(CSRC)/elementwise.hip \
-         $(CSRC)/labels.hip $(CSRC)/loss.hip $(CSRC)/decode_nms.hip $(CSRC)/measure.hip
+         $(CSRC)/labels.hip $(CSRC)/loss.hip $(CSRC)/decode_nms.hip $(CSRC)/iou.hip $(CSRC)/measure.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := tf2_yolo_amd/libyolo_hip.so
 HIPFLAGS := -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -munsafe-fp-atomics -Wall -Wno-unused-function

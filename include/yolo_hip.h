@@ -410,6 +410,19 @@ int yolo_nms(const double* rows, int n, int class_num, int mode, double nms_thre
              double conf_threshold, double sigma, unsigned char* keep_out,
              void* workspace, size_t workspace_bytes, void* stream);
 
+/* cal_iou as a stand-alone broadcasting kernel -- the reference's two public functions of that name:
+ *   utils/tools.py:630-684       cal_iou(xywh_true, xywh_pred, mode): NumPy float64/float32, mode 1 IoU, 2 DIoU
+ *   yolov3/losses/loss.py:9-37   cal_iou(xywh_true, xywh_pred, grid_shape): x / grid_w, y / grid_h first (same text
+ *                                in yolov1_5 / yolov2); yolov4/losses/loss.py:10-61 return_ciou=True -> mode 3:
+ *                                out = IoU, out2 = CIoU
+ * The output has `ndim` dimensions of extents shape_host[]; operand element e's box starts at
+ * sum_d index_d * strides_host[d] (strides in ELEMENTS, 0 on a broadcast dimension), its x, y, w, h are 4 consecutive
+ * elements. is_f64: 1 = double operands / outputs, 0 = float. Same operation order as the reference, no fused
+ * multiply-adds: the float64 results are bit-identical to utils.tools.cal_iou's (tests/golden/tools_golden.npz). */
+int yolo_cal_iou(const void* xywh_true, const void* xywh_pred, void* out, void* out2, int is_f64, int mode, int ndim,
+                 const long long* shape_host, const long long* true_strides_host, const long long* pred_strides_host,
+                 double grid_w, double grid_h, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Detection evaluation after decode / NMS (replaces the arithmetic of create_score_mat and
  * PRfunc, utils/measurement.py:16-150, 153-337). Rows are the (n,7) float64 arrays of

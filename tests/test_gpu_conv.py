@@ -517,7 +517,7 @@ def test_conv_fused_inference_epilogue(act, with_res, case):
     assert _relerr(y2.double().cpu(), L.conv2d(ref, w2, None, stride=1, padding="same")) < TOL
 
 
-@pytest.mark.parametrize("shape", [(2, 37, 45), (1, 16, 16), (3, 130, 127), (2, 21, 400)])
+@pytest.mark.parametrize("shape", [(2, 37, 45), (1, 16, 16), (3, 130, 127), (2, 21, 400), (1, 50, 50)])
 @pytest.mark.parametrize("act", ["leaky", "mish"])
 def test_stem_backward_fused(shape, act):
     """yolo_stem_bn_bwd_wgrad (csrc/stem.hip): the BatchNorm / activation backward apply and the filter gradient of the

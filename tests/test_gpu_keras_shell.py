@@ -24,15 +24,18 @@ class _Seq:
 
 
 def test_readme_flow_v3():
-    import yolov3
+    # the imports of /root/reference/README.md:207-336, verbatim
     from utils import tools
+    from utils.tools import get_class_weight
+    from utils.measurement import PR_func, create_score_mat  # noqa: F401
+    from yolov3 import Yolo
     from tf2_yolo_amd import labels
     from tf2_yolo_amd.optimizers import Adam
-    yolo = yolov3.Yolo((64, 64, 3), ["a", "b"])
+    yolo = Yolo((64, 64, 3), ["a", "b"])
     yolo.create_model(anchors=A9, pretrained_body=None)
     rng = np.random.default_rng(0)
     x, ys = labels.synthetic_batch(rng, 8, (64, 64), 2)
-    bw = [labels.get_class_weight(y[..., 4:5], "binary")[0] for y in ys]
+    bw = [get_class_weight(y[..., 4:5], "binary")[0] for y in ys]     # README.md:229-233, 248-252
     yolo.model.compile(optimizer=Adam(lr=1e-4), loss=yolo.loss(bw), metrics=yolo.metrics("obj+iou+recall0.5"))
     h = yolo.model.fit(x, ys, batch_size=4, epochs=8, verbose=0)
     losses = h.history["loss"]
@@ -246,3 +249,96 @@ def test_feeder_delivers_every_row_once_in_order():
                 pass
         finally:
             f.close()
+
+
+def test_utils_tools_cal_iou_bit_exact_vs_reference_goldens():
+    """utils.tools.cal_iou (utils/tools.py:630-684) on the device against the reference's own outputs: the pairwise
+    IoU / DIoU matrices of tests/golden/tools_golden.npz, bit for bit; float32 operands stay float32 like NumPy."""
+    import os
+    import sys
+    from utils.tools import cal_iou
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sys.path.insert(0, here)
+    try:
+        import gen_inputs
+    finally:
+        sys.path.remove(here)
+    g = np.load(os.path.join(here, "tools_golden.npz"))
+    boxes = gen_inputs.misc_inputs()["iou_boxes"]
+    a, b = boxes.reshape(-1, 1, 5), boxes.reshape(1, -1, 5)
+    iou = cal_iou(a, b, mode=1)
+    assert iou.dtype == np.float64 and iou.shape == g["iou_mat"].shape
+    assert np.array_equal(iou, g["iou_mat"])
+    diou = cal_iou(a, b, mode=2)
+    assert np.array_equal(diou, g["diou_mat"], equal_nan=True)
+    # CUDA tensors in -> CUDA tensor out, same bits; the NMS call shape (expand_dims 0 / 1, utils/tools.py:712-715)
+    t = torch.from_numpy(boxes).cuda()
+    d = cal_iou(t[None, :, :4], t[:, None, :4], mode=1)
+    assert d.is_cuda and np.array_equal(d.cpu().numpy(), g["iou_mat"].T)
+    # float32 operands: NumPy computes in float32
+    from oracle import tools as OT
+    a32, b32 = a.astype(np.float32), b.astype(np.float32)
+    r32 = cal_iou(a32, b32, mode=2)
+    assert r32.dtype == np.float32 and np.array_equal(r32, OT.cal_iou(a32, b32, 2), equal_nan=True)
+    assert cal_iou(a, b, mode=7) is None            # the reference falls through and returns None
+    assert cal_iou(np.zeros((0, 4)), np.zeros((0, 4))).shape == (0,)
+
+
+@pytest.mark.parametrize("ver", [3, 4])
+def test_loss_side_cal_iou_vs_oracle(ver):
+    """yolovN.losses.cal_iou (yolov3/losses/loss.py:9-37, yolov4/losses/loss.py:10-61) against the restatement the
+    loss oracle uses, on the losses' own call shape (N,S,S,1,4) x (N,S,S,B,4). float32 like TF: 1e-6."""
+    import importlib
+    from oracle import losses as OL
+    cal_iou = importlib.import_module(f"yolov{ver}.losses").cal_iou
+    rng = np.random.default_rng(7)
+    N, S, B = 2, 13, 3
+    t = rng.random((N, S, S, 1, 4)).astype(np.float32)
+    p = rng.random((N, S, S, B, 4)).astype(np.float32)
+    t[..., 2:] = t[..., 2:] * 0.5 + 0.05
+    p[..., 2:] = p[..., 2:] * 0.5 + 0.05
+    t64, p64 = torch.tensor(t, dtype=torch.float64), torch.tensor(p, dtype=torch.float64)
+    if ver == 4:
+        iou, ciou = cal_iou(t, p, (S, S), return_ciou=True)
+        ri, rc = OL.cal_iou(t64, p64, (S, S), return_ciou=True)
+        assert np.abs(ciou.cpu().numpy() - rc.numpy()).max() <= 1e-6
+    else:
+        iou, ri = cal_iou(t, p, (S, S)), OL.cal_iou(t64, p64, (S, S))
+    assert iou.shape == (N, S, S, B) and iou.dtype == torch.float32
+    assert np.abs(iou.cpu().numpy() - ri.numpy()).max() <= 1e-6
+    # a sliced view of a prediction tensor (the loss passes y_pred[..., :4]) needs no copy
+    yp = torch.tensor(rng.random((N, S, S, B, 9)).astype(np.float32)).cuda()
+    v = cal_iou(t, yp[..., :4], (S, S))
+    v = v[0] if isinstance(v, tuple) else v
+    ref = OL.cal_iou(t64, yp[..., :4].double().cpu(), (S, S))
+    assert np.abs(v.cpu().numpy() - ref.numpy()).max() <= 1e-6
+
+
+def test_yolo_body_plus_yolo_head_is_create_model():
+    """the reference's two-call construction (yolov3/__init__.py:122-175): yolo_body(...) then yolo_head(...) gives the
+    model create_model gives; body weights set on the symbolic body arrive in the model"""
+    import yolov3
+    from yolov3.models import yolo_body, yolo_head
+    ref = yolov3.Yolo((64, 64, 3), ["a", "b"])
+    ref.create_model(anchors=A9, pretrained_body=None, seed=5)
+    body = yolo_body((64, 64, 3), pretrained_darknet=ref.model)
+    assert body.output_shape == [(None, 2, 2, 1024), (None, 4, 4, 512), (None, 8, 8, 256)]
+    m = yolo_head(body, class_num=2, anchors=A9, seed=99)
+    assert [tuple(o.shape) for o in m.output] == [(None, 2, 2, 21), (None, 4, 4, 21), (None, 8, 8, 21)]
+    for n in ("conv1_conv", "block3_4_3x3_bn", "last2_3_3x3_conv"):
+        for a, b in zip(m.get_layer(n).get_weights(), ref.model.get_layer(n).get_weights()):
+            assert np.array_equal(a, b)
+    # head weights are the new model's own draw (seed 99), not the donor's
+    assert not np.array_equal(m.get_layer("out1_box1_xy_conv").get_weights()[0],
+                              ref.model.get_layer("out1_box1_xy_conv").get_weights()[0])
+    # Keras-ordered weight list through BodyModel.set_weights
+    body2 = yolo_body((64, 64, 3))
+    names = body2.layer_names()
+    body2.set_weights([w for n in names for w in ref.model.get_layer(n).get_weights()])
+    m2 = yolo_head(body2, class_num=2, anchors=A9)
+    assert np.array_equal(m2.get_layer("block5_4_3x3_conv").get_weights()[0],
+                          ref.model.get_layer("block5_4_3x3_conv").get_weights()[0])
+    x = np.random.default_rng(0).random((2, 64, 64, 3), dtype=np.float32)
+    assert [p.shape for p in m2.predict(x)] == [(2, 2, 2, 21), (2, 4, 4, 21), (2, 8, 8, 21)]
+    with pytest.raises(ValueError, match="multiple"):
+        yolo_head(yolo_body((64, 64, 3)), class_num=2, anchors=A9[:8])

@@ -104,6 +104,8 @@ SIGNATURES = {
                                       c_size_t, _P]),
     "yolo_decode_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "yolo_nms_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "yolo_cal_iou": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, POINTER(c_longlong), POINTER(c_longlong),
+                             POINTER(c_longlong), c_double, c_double, _P]),
     "yolo_match_detections": (c_int, [_P, c_int, _P, c_int, c_int, c_double, _P, _P, _P, _P, _P, _P]),
     "yolo_rank_desc": (c_int, [_P, _P, c_int, _P, _P]),
     "yolo_pr_curve_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -342,13 +342,16 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
     __syncthreads();
     unsigned* lds_word = reinterpret_cast<unsigned*>(smem);
+    // release / acquire at agent scope around the ticket (the slabs cross XCDs, i.e. L2s): every wave's slab stores
+    // have drained and the barrier has ordered them before thread 0's release (which writes this XCD's L2 back);
+    // in the last arriver EVERY wave acquires (invalidates its view) before it reads the other parts
     if (tid == 0)
-      *lds_word = __hip_atomic_fetch_add(&a.sk_tickets[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *lds_word = __hip_atomic_fetch_add(&a.sk_tickets[tile], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     const unsigned ticket = *lds_word;
     finish = (ticket == (unsigned)(nparts - 1));
     if (finish) {
-      if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       const int own = wl - w_first;
@@ -441,12 +444,20 @@ static int win_pixels_needed(const GatherConvArgs& a, int BM) {
     const long long y = rem / a.Ws;
     return (n * (a.Hs + 1) + y + 1) * P1 + (rem - y * a.Ws) + 1;
   };
+  // (a walk over every row tile: 676 iterations for the 52 x 52 bs-32 layers. It is host time on the launch path, so the
+  // answer is remembered per geometry; a handful of distinct layers exist per model)
+  struct Key { long long M; int Hs, Ws, BM, need; };
+  static thread_local Key cache[32];
+  static thread_local int ncache = 0;
+  for (int i = 0; i < ncache; ++i)
+    if (cache[i].M == a.M && cache[i].Hs == a.Hs && cache[i].Ws == a.Ws && cache[i].BM == BM) return cache[i].need;
   long long worst = 0;
   for (long long m0 = 0; m0 < a.M; m0 += BM) {
     const long long ml = (m0 + BM - 1 < a.M) ? m0 + BM - 1 : a.M - 1;
     const long long need = u_of(ml) - u_of(m0) + 2 * P1 + 3;
     if (need > worst) worst = need;
   }
+  if (ncache < 32) cache[ncache++] = Key{a.M, a.Hs, a.Ws, BM, (int)worst};
   return (int)worst;
 }
 

@@ -241,7 +241,9 @@ __global__ __launch_bounds__(256) void stem_bn_bwd_wgrad_kernel(
       while (yy >= H) { yy -= H; ++nn; }
       const int iy = yy + dyo, ix = xx + dxo;
       const bool ok = ncol && (p0 + k < P) && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-      const float* q = img + ((long long)(nn * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3 + ci;
+      // (!ok covers pixels past P in the last block, whose nn would be N: every index is clamped, the load stays
+      // inside the image tensor for any N * H * W)
+      const float* q = img + ((long long)((ok ? nn : 0) * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3 + (ncol ? ci : 0);
       const float v = *q;
       bv[i] = ok ? v : 0.f;
     }

@@ -276,6 +276,10 @@ class Network:
         if not torch.cuda.is_available():
             raise YoloHipError("tf2_yolo_amd needs a HIP device: there is no CPU fallback")
         self.device = torch.device(device)
+        if self.device.index is not None and self.device.index != torch.cuda.current_device():
+            raise YoloHipError(f"Network(device={device!r}): the kernels launch on the current device "
+                               f"(cuda:{torch.cuda.current_device()}); call torch.cuda.set_device first "
+                               "(one process per GPU)")
         self.tensors = builder.tensors
         self.units = builder.units
         self.input = builder.input
@@ -595,7 +599,17 @@ class Network:
         graph.replay()
         return outs
 
+    def before_param_write(self):
+        """Call BEFORE writing `params` / `state` on the current stream: a training-mode forward may still be
+        transposing / splitting the old parameters on the second stream (its events are normally consumed by the first
+        planes convolution and by backward; a forward without backward leaves them pending)."""
+        for ev in (self._wp_event, self._wT_event):
+            if ev is not None:
+                torch.cuda.current_stream().wait_event(ev)
+        self._wp_event = self._wT_event = None
+
     def mark_params_changed(self):
+        self.before_param_write()
         self._infer_graphs = {}
         self._wT_valid = False
         self._wp_valid = False
@@ -985,6 +999,7 @@ class Network:
         return out
 
     def load_named_weights(self, weights, strict=True):
+        self.before_param_write()
         for store in (self.params, self.state):
             for name in store.order:
                 if name not in weights:

@@ -14,8 +14,7 @@ from collections.abc import Iterable
 
 import numpy as np
 
-from . import graphs, losses
-from .model import Model
+from . import bodies, graphs, losses
 
 
 class MetricKind(object):
@@ -104,10 +103,15 @@ class YoloV3(_IOUnavailable):
                 raise ValueError(f"backbone {backbone!r} lives in keras.applications, outside the HIP path "
                                  "(SURVEY.md section 2 row 15)")
             raise ValueError(f"Invalid backbone: {backbone}")
-        builder = graphs.build_yolov3(self.input_shape, self.class_num, anchors, backbone)
-        self.model = Model(builder, version=3, seed=seed, unbiased_moving_var=bn_unbiased_moving_var)
-        if pretrained_body is not None:
-            self.model.set_body_weights(pretrained_body)
+        # the reference's two calls (yolov3/__init__.py:122-175): yolo_body / tiny_yolo_body, then yolo_head
+        if backbone == "full_darknet":
+            model_body = bodies.yolo_body_v3(self.input_shape, pretrained_darknet=pretrained_body)
+        else:
+            model_body = bodies.tiny_yolo_body(self.input_shape)
+            if pretrained_body is not None:
+                model_body._pending.append(("model", pretrained_body))
+        self.model = bodies.yolo_head_v3(model_body, self.class_num, anchors, seed=seed,
+                                         bn_unbiased_moving_var=bn_unbiased_moving_var)
         if pretrained_weights is not None:
             self.model.load_weights(pretrained_weights)
         self.anchors = anchors
@@ -229,10 +233,9 @@ class YoloV4(_IOUnavailable):
             if backbone in ("resnet50", "resnet101", "resnet152", "resnet50v2", "resnet101v2", "resnet152v2"):
                 raise ValueError(f"backbone {backbone!r} lives in keras.applications, outside the HIP path")
             raise ValueError(f"Invalid backbone: {backbone}")
-        builder = graphs.build_yolov4(self.input_shape, self.class_num, anchors)
-        self._model = Model(builder, version=4, seed=seed, unbiased_moving_var=bn_unbiased_moving_var)
-        if pretrained_body is not None:
-            self._model.set_body_weights(pretrained_body)
+        model_body = bodies.yolo_body_v4(self.input_shape, pretrained_darknet=pretrained_body)
+        self._model = bodies.yolo_head_v4(model_body, self.class_num, anchors, seed=seed,
+                                          bn_unbiased_moving_var=bn_unbiased_moving_var)
         if pretrained_weights is not None:
             self._model.load_weights(pretrained_weights)
             if use_arg_anchors:
@@ -291,10 +294,9 @@ class YoloV2(_IOUnavailable):
             raise ValueError(f"Invalid backbone: {backbone}")
         if isinstance(pretrained_backbone, str):
             _offline("pretrained_backbone", pretrained_backbone)
-        builder = graphs.build_yolov2(self.input_shape, self.class_num, anchors)
-        self.model = Model(builder, version=2, seed=seed, unbiased_moving_var=bn_unbiased_moving_var)
-        if pretrained_backbone is not None:
-            self.model.set_body_weights(pretrained_backbone)
+        model_body = bodies.yolo_body_v2(self.input_shape, backbone, pretrained_backbone)
+        self.model = bodies.yolo_head_v2(model_body, self.class_num, anchors, seed=seed,
+                                         bn_unbiased_moving_var=bn_unbiased_moving_var)
         if pretrained_weights is not None:
             self.model.load_weights(pretrained_weights)
         self.anchors = anchors
@@ -324,10 +326,9 @@ class YoloV1_5(_IOUnavailable):
 
     def create_model(self, bbox_num=2, pretrained_weights=None, pretrained_backbone=None, seed=1234,
                      bn_unbiased_moving_var=True):
-        builder = graphs.build_yolov1_5(self.input_shape, self.class_num, bbox_num)
-        self.model = Model(builder, version=1, seed=seed, unbiased_moving_var=bn_unbiased_moving_var)
-        if pretrained_backbone is not None:
-            self.model.set_body_weights(pretrained_backbone)
+        model_body = bodies.yolo_body_v1(self.input_shape, pretrained_backbone)
+        self.model = bodies.yolo_head_v1(model_body, bbox_num, self.class_num, seed=seed,
+                                         bn_unbiased_moving_var=bn_unbiased_moving_var)
         if pretrained_weights is not None:
             self.model.load_weights(pretrained_weights)
         self.bbox_num = bbox_num

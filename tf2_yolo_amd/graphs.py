@@ -51,8 +51,8 @@ def _v3_last_layers(b, x, filters, name):
     return x, out
 
 
-def build_yolov3(input_shape, class_num, anchors=None, backbone="full_darknet"):
-    anchors = V3_DEFAULT_ANCHORS if anchors is None else anchors
+def yolov3_body(input_shape, backbone="full_darknet"):
+    """yolo_body / tiny_yolo_body (yolov3/models/darknet.py:71-135): (builder, [out1, out2(, out3)]) coarse -> fine."""
     b = GraphBuilder(input_shape, kernel_init=he_normal_krsc)
     if backbone == "full_darknet":
         x3, x4, x5 = darknet53_body(b, b.input)
@@ -70,14 +70,25 @@ def build_yolov3(input_shape, class_num, anchors=None, backbone="full_darknet"):
         body_outs = _tiny_v3_body(b)
     else:
         raise ValueError(f"Invalid backbone: {backbone}")
+    return b, body_outs
+
+
+def fpn_head(b, body_outs, class_num, anchors, version):
+    """yolo_head of v3 / v4 (yolov3/models/__init__.py:13-70, yolov4/models/__init__.py:14-71)."""
     tensor_num = len(body_outs)
     if len(anchors) % tensor_num > 0:
         raise ValueError("The total number of anchor boxs should be a multiple of the number "
                          f"{tensor_num} of output tensors")
     abox = len(anchors) // tensor_num
     for i, t in enumerate(body_outs):
-        b.head(t, abox, class_num, 3, anchors[i * abox:(i + 1) * abox], f"out{i + 1}", level=i)
+        b.head(t, abox, class_num, version, anchors[i * abox:(i + 1) * abox], f"out{i + 1}", level=i)
     return b
+
+
+def build_yolov3(input_shape, class_num, anchors=None, backbone="full_darknet"):
+    anchors = V3_DEFAULT_ANCHORS if anchors is None else anchors
+    b, body_outs = yolov3_body(input_shape, backbone)
+    return fpn_head(b, body_outs, class_num, anchors, 3)
 
 
 def _tiny_v3_body(b):
@@ -139,8 +150,8 @@ def _v4_last_layers(b, x, filters, name):
     return b.conv(x, filters, 1, f"{name}_5")
 
 
-def build_yolov4(input_shape, class_num, anchors=None):
-    anchors = V4_DEFAULT_ANCHORS if anchors is None else anchors
+def yolov4_body(input_shape):
+    """yolo_body (yolov4/models/darknet.py:72-146): (builder, [out_s, out_m, out_l])."""
     b = GraphBuilder(input_shape, kernel_init=random_normal_002)
     x3, x4, x5 = csp_darknet53_body(b, b.input)
     s = b.conv(x5, 512, 1, "pan_td1_1")
@@ -173,19 +184,20 @@ def build_yolov4(input_shape, class_num, anchors=None):
     s = b.concat([m_dn, s], "pan_bu2_concat")
     s = _v4_last_layers(b, s, 512, "pan_bu2")
     out_s = b.conv(s, 1024, 3, "pan_out_s")
-    body_outs = [out_s, out_m, out_l]
-    if len(anchors) % 3 > 0:
-        raise ValueError("The total number of anchor boxs should be a multiple of the number 3 of output tensors")
-    abox = len(anchors) // 3
-    for i, t in enumerate(body_outs):
-        b.head(t, abox, class_num, 4, anchors[i * abox:(i + 1) * abox], f"out{i + 1}", level=i)
-    return b
+    return b, [out_s, out_m, out_l]
+
+
+def build_yolov4(input_shape, class_num, anchors=None):
+    anchors = V4_DEFAULT_ANCHORS if anchors is None else anchors
+    b, body_outs = yolov4_body(input_shape)
+    return fpn_head(b, body_outs, class_num, anchors, 4)
 
 
 # ---------------------------------------------------------------------------------------------
 # YOLOv2 (yolov2/models/backbone.py:42-73, yolov2/models/darknet.py:32-106)
 # ---------------------------------------------------------------------------------------------
-def build_yolov2(input_shape, class_num, anchors):
+def yolov2_body(input_shape):
+    """yolo_body, backbone "darknet" (yolov2/models/darknet.py:32-65): (builder, [out])."""
     b = GraphBuilder(input_shape, kernel_init=he_normal_krsc)
 
     def cbl(x, f, k, name):
@@ -221,14 +233,20 @@ def build_yolov2(input_shape, class_num, anchors):
     p = b.space_to_depth(p, "passthrough_s2d")
     x = b.concat([p, x], "passthrough_concat")
     x = cbl(x, 1024, 3, "conv8")
-    b.head(x, len(anchors), class_num, 2, anchors, "out1", level=0)
+    return b, [x]
+
+
+def build_yolov2(input_shape, class_num, anchors):
+    b, (x,) = yolov2_body(input_shape)
+    b.head(x, len(anchors), class_num, 2, anchors, "out1", level=0)   # yolo_head, yolov2/models/darknet.py:68-106
     return b
 
 
 # ---------------------------------------------------------------------------------------------
 # YOLOv1.5 (yolov1_5/models/backbone.py:18-48, yolov1_5/models/darknet.py:26-55)
 # ---------------------------------------------------------------------------------------------
-def build_yolov1_5(input_shape, class_num, bbox_num=2):
+def yolov1_5_body(input_shape):
+    """yolo_body (yolov1_5/models/darknet.py:26-34): (builder, [out])."""
     b = GraphBuilder(input_shape, kernel_init=he_normal_krsc)
 
     def cbl(x, f, k, name, stride=1):
@@ -256,5 +274,10 @@ def build_yolov1_5(input_shape, class_num, bbox_num=2):
     x = cbl(x, 1024, 3, "conv5_6", stride=2)
     x = cbl(x, 1024, 3, "conv6_1")
     x = cbl(x, 1024, 3, "conv6_2")
-    b.head(x, bbox_num, class_num, 1, None, "out1", level=0)
+    return b, [x]
+
+
+def build_yolov1_5(input_shape, class_num, bbox_num=2):
+    b, (x,) = yolov1_5_body(input_shape)
+    b.head(x, bbox_num, class_num, 1, None, "out1", level=0)          # yolo_head, yolov1_5/models/darknet.py:37-55
     return b

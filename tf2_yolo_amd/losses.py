@@ -22,6 +22,27 @@ def _as_f32_cuda(a):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).cuda()
 
 
+def _f32_cuda_view(a):
+    if torch.is_tensor(a):
+        return a.to(device="cuda", dtype=torch.float32)     # slices such as y[..., :4] stay views
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).cuda()
+
+
+def cal_iou_v4(xywh_true, xywh_pred, grid_shape, return_ciou=False):
+    """Calculate IOU of two tensors, loss-side form (yolov4/losses/loss.py:10-61): operands of shape (..., 4) that
+    broadcast (the losses call it with (N,S,S,1,4) against (N,S,S,B,4)); x / y are cell offsets and are divided by
+    grid_shape[::-1] first. float32 on the device like the reference's TF ops. Forward value only: inside the
+    training step the fused loss kernel differentiates its own IoU / CIoU (csrc/loss.hip). Returns a CUDA tensor
+    (two, IoU and CIoU, with return_ciou)."""
+    a, b = _f32_cuda_view(xywh_true), _f32_cuda_view(xywh_pred)
+    return ops.cal_iou(a, b, 3 if return_ciou else 1, grid_wh=(grid_shape[1], grid_shape[0]))
+
+
+def cal_iou_v3(xywh_true, xywh_pred, grid_shape):
+    """yolov3/losses/loss.py:9-37 (the same text in yolov1_5 / yolov2): IoU only."""
+    return cal_iou_v4(xywh_true, xywh_pred, grid_shape)
+
+
 class YoloLoss:
     def __init__(self, version, grid_shape, bbox_num, class_num, anchors=None, **kw):
         self.version = version

@@ -32,6 +32,7 @@ class LayerView:
         return self._get()
 
     def set_weights(self, weights):
+        self.model.net.before_param_write()
         self._set(weights)
         self.model.net.mark_params_changed()
 

@@ -130,6 +130,13 @@ _CONV_WS = None
 def ensure_conv_workspace():
     """scratch of the persistent (stream-K) window kernel: allocated once per process, registered with the library"""
     global _CONV_WS
+    # The library's per-process state (this workspace, cached kernel attributes / occupancy, the stem's filter ring)
+    # belongs to ONE device: one process drives one GPU (SURVEY.md section 8e, torchrun starts a process per GPU).
+    # Launches that use the workspace (split-K / stream-K forward and data-gradient convolutions) must be ordered on
+    # one stream; the executor's second stream only runs filter gradients and filter preparation, which do not.
+    if _CONV_WS is not None and _CONV_WS.device.index != torch.cuda.current_device():
+        raise YoloHipError(f"libyolo_hip.so was initialised on cuda:{_CONV_WS.device.index} and cannot also serve "
+                           f"cuda:{torch.cuda.current_device()}: start one process per GPU")
     if _CONV_WS is None:
         lib = _lib.load()
         n = int(lib.yolo_conv_workspace_bytes())
@@ -805,3 +812,38 @@ def pr_curve(joint, gt_id, matched, num_gts, precision_mode):
     check(lib.yolo_pr_curve(_p(joint.contiguous()), _p(gt_id.contiguous()), _p(matched.contiguous()), n, int(num_gts),
                             int(precision_mode), _p(ws), nbytes, _p(prec), _p(rec), _stream()), "yolo_pr_curve")
     return prec, rec
+
+
+# ---- stand-alone cal_iou (csrc/iou.hip) -------------------------------------------------------------------
+def cal_iou(xywh_true, xywh_pred, mode=1, grid_wh=(1.0, 1.0)):
+    """Broadcasting IoU (mode 1) / DIoU (2) / (IoU, CIoU) (3) of boxes [..., >=4] (x, y, w, h first); both CUDA tensors of
+    ONE float dtype (float32 or float64). The leading dimensions broadcast like NumPy's; nothing is materialised:
+    the kernel walks the operands through their strides. Returns a tensor of the broadcast shape (two for mode 3)."""
+    import ctypes
+    if xywh_true.dtype != xywh_pred.dtype or xywh_true.dtype not in (torch.float32, torch.float64):
+        raise YoloHipError("cal_iou: operands must share one dtype, float32 or float64")
+    if xywh_true.shape[-1] < 4 or xywh_pred.shape[-1] < 4:
+        raise YoloHipError("cal_iou: the last dimension holds x, y, w, h")
+    for t in (xywh_true, xywh_pred):
+        if t.numel() and t.stride(-1) != 1:
+            raise YoloHipError("cal_iou: x, y, w, h must be consecutive in memory")
+    lead_a, lead_b = tuple(xywh_true.shape[:-1]), tuple(xywh_pred.shape[:-1])
+    shape = tuple(torch.broadcast_shapes(lead_a, lead_b))
+    nd = len(shape)
+    if nd > 8:
+        raise YoloHipError("cal_iou: at most 8 leading dimensions")
+
+    def strides(t, lead):
+        out = [0] * nd
+        for i in range(len(lead)):
+            d = nd - len(lead) + i
+            out[d] = 0 if lead[i] == 1 and shape[d] != 1 else int(t.stride(i))
+        return out
+    arr = ctypes.c_longlong * max(nd, 1)
+    out = torch.empty(shape, device=xywh_true.device, dtype=xywh_true.dtype)
+    out2 = torch.empty(shape, device=xywh_true.device, dtype=xywh_true.dtype) if mode == 3 else None
+    check(_lib.load().yolo_cal_iou(_p(xywh_true), _p(xywh_pred), _p(out), _p(out2),
+                                   1 if xywh_true.dtype == torch.float64 else 0, int(mode), nd, arr(*shape),
+                                   arr(*strides(xywh_true, lead_a)), arr(*strides(xywh_pred, lead_b)),
+                                   float(grid_wh[0]), float(grid_wh[1]), _stream()), "yolo_cal_iou")
+    return (out, out2) if mode == 3 else out

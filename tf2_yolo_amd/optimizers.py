@@ -31,6 +31,7 @@ class Adam(Optimizer):
 
     def step(self, grad_scale=1.0):
         self.iterations += 1
+        self.net.before_param_write()
         ops.adam_step(self.net.params.data, self.net.grads, self.m, self.v, self.learning_rate, self.iterations,
                       self.beta_1, self.beta_2, self.epsilon, grad_scale=grad_scale, zero_grad=True)
         if self.net.anchors_trainable and self.net.has_anchors:
@@ -46,6 +47,7 @@ class SGD(Optimizer):
 
     def step(self, grad_scale=1.0):
         self.iterations += 1
+        self.net.before_param_write()
         ops.sgd_step(self.net.params.data, self.net.grads, self.learning_rate, grad_scale=grad_scale, zero_grad=True)
         if self.net.anchors_trainable and self.net.has_anchors:
             ops.sgd_step(self.net.anchors_flat, self.net.anchor_grads, self.learning_rate, grad_scale=grad_scale,

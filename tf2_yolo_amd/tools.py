@@ -2,6 +2,7 @@
 
   decode    utils/tools.py:370-438      nms       utils/tools.py:687-733
   soft_nms  utils/tools.py:736-786      (nms with iou_mode=2 is DIoU-NMS)
+  cal_iou   utils/tools.py:630-684      (broadcasting IoU / DIoU matrix)
 
 Same names, argument meaning, return types (NumPy float64 arrays of shape (n, 7)) and error
 behaviour (ValueError("Invalid version: ...")). Inputs may be NumPy arrays (uploaded) or CUDA
@@ -73,6 +74,21 @@ def decode(*label_datas, class_num=1, threshold=0.5, version=1):
     if out.shape[0] == 0:
         return np.array([], dtype="float")     # what np.array([]) of an empty list gives in the reference
     return out.cpu().numpy()
+
+
+def cal_iou(xywh_true, xywh_pred, mode=1):
+    """Calculate IOU of two tensors (utils/tools.py:630-684): arrays of shape (..., >=4) that broadcast against each
+    other, (x, y) normalised by the image size; mode 1: IoU, 2: DIoU. Computed on the GPU in the operands' NumPy
+    result type (float64 unless both are float32) with the reference's operation order -- bit-identical to the
+    reference's arrays. NumPy in -> NumPy out, CUDA tensors in -> CUDA tensor out."""
+    if mode not in (1, 2):
+        return None   # the reference falls through both branches and returns None
+    was_numpy = not (torch.is_tensor(xywh_true) or torch.is_tensor(xywh_pred))
+    a, b = _to_dev(xywh_true), _to_dev(xywh_pred)
+    if a.dtype != b.dtype:
+        a, b = a.double(), b.double()
+    out = ops.cal_iou(a, b, mode)
+    return out.cpu().numpy() if was_numpy else out
 
 
 def _nms_impl(xywhcp, class_num, mode, nms_threshold, conf_threshold=0.5, sigma=0.5):

@@ -1,0 +1,3 @@
+"""Drop-in for the reference package `yolov3.losses` (yolov3/losses/__init__.py:3): same names, HIP backend."""
+from tf2_yolo_amd.losses import cal_iou_v3 as cal_iou  # noqa: F401  (yolov3/losses/loss.py:9-37)
+from tf2_yolo_amd.losses import wrap_yolo_loss_v3 as wrap_yolo_loss  # noqa: F401
