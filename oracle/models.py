@@ -16,6 +16,9 @@ import torch
 from . import layers as L
 
 
+KEEP_ACTS = True    # module switch read by every forward: False = do not retain per-unit activations (full-batch runs)
+
+
 class _Ctx:
     def __init__(self, weights, training, dtype, unbiased_moving_var=False, leaky_masks=None):
         self.w = {k: torch.as_tensor(v, dtype=dtype) if not torch.is_tensor(v) else v for k, v in weights.items()}
@@ -24,7 +27,9 @@ class _Ctx:
         self.unbiased = unbiased_moving_var
         self.leaky_masks = leaky_masks      # {unit name: bool tensor}: see layers.leaky_masked
         self.mask_disagree = {}             # unit name -> largest |z| where the forced branch differs
+        self.pool_disagree = {}             # max-pool unit name -> largest (true max - forced winner)
         self.acts = {}                      # unit name -> activation (debug / per-layer parity)
+        self.keep_acts = KEEP_ACTS          # False: memory-light runs at full batch (tests/test_gpu_fullsize.py)
 
     def conv(self, x, name, stride=1, padding="same", bias=False):
         b = self.w[f"{name}/1"] if bias else None
@@ -41,6 +46,20 @@ class _Ctx:
             return y
         return L.batchnorm_infer(x, gamma, beta, mm, mv)
 
+    def pool(self, x, name, k, stride, padding="valid"):
+        """MaxPooling2D. With a device argmax pattern under `name` in leaky_masks (flat NHWC offsets into x, what
+        yolo_maxpool_fwd records) the maximum is taken WHERE THE DEVICE TOOK IT -- the max-pool twin of leaky_masked:
+        two executions legitimately pick different winners among values within rounding of each other (a 13x13 SPP
+        window holds 169 candidates), and one different winner reroutes a gradient entry. pool_disagree[name] = the
+        largest amount by which a forced winner is below the true maximum (the caller asserts it is rounding-sized)."""
+        y = L.maxpool(x, k, stride, padding)
+        if self.leaky_masks is None or name not in self.leaky_masks:
+            return y
+        idx = self.leaky_masks[name].reshape(-1).long()
+        forced = x.reshape(-1)[idx].reshape(y.shape)
+        self.pool_disagree[name] = float((y.detach() - forced.detach()).abs().max())
+        return forced
+
     def cbl(self, x, name, stride=1, padding="same", act="leaky", bias=False):
         """conv -> BatchNormalization -> LeakyReLU(0.1) | Mish"""
         x = self.conv(x, f"{name}_conv", stride, padding, bias)
@@ -54,7 +73,8 @@ class _Ctx:
             out = L.leaky_masked(x, m)
         else:
             out = L.leaky(x)
-        self.acts[name] = out.detach()
+        if self.keep_acts:
+            self.acts[name] = out.detach()
         return out
 
 
@@ -118,11 +138,11 @@ def yolov3_tiny_forward(weights, x, anchors, training=False, unbiased_moving_var
     t = x
     for i, _f in enumerate((16, 32, 64, 128), start=1):
         t = c.cbl(t, f"tiny_c{i}")
-        t = L.maxpool(t, 2, 2, "same")
+        t = c.pool(t, f"tiny_p{i}", 2, 2, "same")
     t1 = c.cbl(t, "tiny_c5")
-    t = L.maxpool(t1, 2, 2, "same")
+    t = c.pool(t1, "tiny_p5", 2, 2, "same")
     t = c.cbl(t, "tiny_c6")
-    t = L.maxpool(t, 2, 1, "same")
+    t = c.pool(t, "tiny_p6", 2, 1, "same")
     t = c.cbl(t, "tiny_c7")
     t2 = c.cbl(t, "tiny_c8")
     o1 = c.cbl(t2, "tiny_out1")
@@ -165,7 +185,8 @@ def yolov4_forward(weights, x, anchors, training=False, unbiased_moving_var=Fals
     s = c.cbl(t5, "pan_td1_1")
     s = c.cbl(s, "pan_td1_2")
     s = c.cbl(s, "pan_td1_spp_pre")
-    s = torch.cat([L.maxpool(s, 13, 1, "same"), L.maxpool(s, 9, 1, "same"), L.maxpool(s, 5, 1, "same"), s], dim=-1)
+    s = torch.cat([c.pool(s, "pan_td1_spp_pool1", 13, 1, "same"), c.pool(s, "pan_td1_spp_pool2", 9, 1, "same"),
+                   c.pool(s, "pan_td1_spp_pool3", 5, 1, "same"), s], dim=-1)
     s = c.cbl(s, "pan_td1_3")
     s = c.cbl(s, "pan_td1_4")
     s = c.cbl(s, "pan_td1_5")
@@ -201,19 +222,19 @@ def yolov2_forward(weights, x, anchors, training=False, unbiased_moving_var=Fals
         return c.cbl(t, name, bias=True)
 
     t = cbl(x, "conv1")
-    t = L.maxpool(t, 2, 2)
+    t = c.pool(t, "pool1", 2, 2)
     t = cbl(t, "conv2")
-    t = L.maxpool(t, 2, 2)
+    t = c.pool(t, "pool2", 2, 2)
     for n in ("conv3_1", "conv3_2", "conv3_3"):
         t = cbl(t, n)
-    t = L.maxpool(t, 2, 2)
+    t = c.pool(t, "pool3", 2, 2)
     for n in ("conv4_1", "conv4_2", "conv4_3"):
         t = cbl(t, n)
-    t = L.maxpool(t, 2, 2)
+    t = c.pool(t, "pool4", 2, 2)
     for n in ("conv5_1", "conv5_2", "conv5_3", "conv5_4", "conv5_5"):
         t = cbl(t, n)
     passthrough = t
-    t = L.maxpool(t, 2, 2)
+    t = c.pool(t, "pool5", 2, 2)
     for n in ("conv6_1", "conv6_2", "conv6_3", "conv6_4", "conv6_5", "conv7_1", "conv7_2"):
         t = cbl(t, n)
     p = L.space_to_depth2(cbl(passthrough, "passthrough_conv"))
@@ -229,15 +250,15 @@ def yolov1_5_forward(weights, x, training=False, unbiased_moving_var=False, leak
         return c.cbl(t, name, stride=stride, bias=True)
 
     t = cbl(x, "conv1", 2)
-    t = L.maxpool(t, 2, 2)
+    t = c.pool(t, "pool1", 2, 2)
     t = cbl(t, "conv2")
-    t = L.maxpool(t, 2, 2)
+    t = c.pool(t, "pool2", 2, 2)
     for n in ("conv3_1", "conv3_2", "conv3_3", "conv3_4"):
         t = cbl(t, n)
-    t = L.maxpool(t, 2, 2)
+    t = c.pool(t, "pool3", 2, 2)
     for i in range(1, 10):
         t = cbl(t, f"conv4_{i}")
-    t = L.maxpool(t, 2, 2)
+    t = c.pool(t, "pool4", 2, 2)
     for n in ("conv5_1", "conv5_2", "conv5_3", "conv5_4", "conv5_5"):
         t = cbl(t, n)
     t = cbl(t, "conv5_6", 2)

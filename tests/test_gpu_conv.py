@@ -319,6 +319,71 @@ def test_conv_window_kernel_fwd_dgrad(case, win, sk):
         ops.reset_options()
 
 
+# ---- window kernel on 2-D patches (conv_win.hip GEO = 1): rows longer than 64 pixels, 64-column tiles ----
+PATCH_CASES = [
+    (2, 76, 76, 32, 128, 3, 1, "same", False),     # YOLOv4-608 stage 3 rows: 9.5 x 4.75 patches per image (ragged both ways)
+    (1, 104, 104, 64, 128, 3, 1, "same", True),    # YOLOv3-416 block 2 rows, bias
+    (1, 152, 152, 32, 64, 3, 1, "same", False),    # Cout = 64: 256 x 64 tiles on 16 x 16 patches (9.5 x 9.5 per image)
+    (2, 208, 24, 32, 64, 3, 1, "same", True),      # 208-pixel columns, 1.5 patches across; bias; Cin = 32 (two channel blocks)
+    (3, 9, 21, 48, 160, 3, 1, "same", False),      # images smaller than a patch row count, ragged column tile (160 = 128 + 32)
+    (1, 37, 130, 16, 64, 3, 1, "same", False),     # ONE channel block (9 stages), odd sizes
+    (2, 40, 72, 128, 64, 3, 1, "same", False),     # data gradient with 128 columns (128 x 128 tiles), forward with 64
+]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv_patch_window_kernel_fwd_dgrad(case):
+    """conv_win_kernel<..., GEO = 1>: the tile is an 8 x 16 (Cout > 64) or 16 x 16 (Cout <= 64) patch of output pixels,
+    the window its halo patch. Forced with yolo_set_option(5, 2) so that the small cases reach it; against the float64
+    oracle (1e-4) and the per-tap kernel (1e-5): forward with BatchNorm statistics and per-channel max|y| (rows of a ragged
+    patch that lie outside the image must not count), data gradient plain and accumulating."""
+    from tf2_yolo_amd import ops
+    ops.ensure_conv_workspace()
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=31)
+    x.requires_grad_(True)
+    ref = L.conv2d(x, wk, b, stride=s, padding=pad)
+    g = torch.Generator().manual_seed(32)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    xd, wd = x.detach().float().cuda(), _krsc(wk).float().cuda()
+    bd = None if b is None else b.float().cuda()
+    xp = ops.split_planes(xd, n * h * w, cin)
+    wp = ops.split_planes(wd, cout, k * k * cin)
+    stats = torch.zeros(ops.BN_STAT_SLOTS * 2 * cout, device="cuda", dtype=torch.float64)
+    amax = torch.zeros(cout, device="cuda", dtype=torch.int32)
+    ops.set_option(ops.OPT_CONV_WIN, 0)
+    y0 = ops.conv2d_fwd_planes(d, xp, wp, bd)
+    ops.set_option(ops.OPT_CONV_WIN, 1)
+    ops.set_option(ops.OPT_CONV_PATCH, 2)
+    try:
+        y = ops.conv2d_fwd_planes(d, xp, wp, bd, stats=stats, absmax=amax)
+        torch.cuda.synchronize()
+        assert _relerr(y.double().cpu(), ref.detach()) < TOL
+        assert _relerr(y.double(), y0.double()) < 1e-5
+        assert torch.equal(amax.view(torch.float32), y.reshape(-1, cout).abs().max(0).values)
+        got = stats.cpu().reshape(ops.BN_STAT_SLOTS, 2, cout).sum(0)
+        r2 = ref.detach().reshape(-1, cout)
+        assert _relerr(got[0], r2.sum(0)) < 1e-5 and _relerr(got[1], (r2 * r2).sum(0)) < 1e-5
+        # no statistics asked for (inference / data gradients take this path through the epilogue)
+        y1 = ops.conv2d_fwd_planes(d, xp, wp, bd)
+        assert torch.equal(y1, y)
+        if cin >= 64:
+            wT = ops.filter_transpose(wd, cout, k * k, cin)
+            dyp = ops.split_planes(dy.float().cuda(), n * d.Ho * d.Wo, cout)
+            wTp = ops.split_planes(wT, cin, k * k * cout)
+            dx = ops.conv2d_dgrad_planes(d, dyp, wTp)
+            torch.cuda.synchronize()
+            assert _relerr(dx.double().cpu(), x.grad) < TOL
+            dx2 = dx.clone()
+            ops.conv2d_dgrad_planes(d, dyp, wTp, dx=dx2, accumulate=True)
+            torch.cuda.synchronize()
+            assert _relerr(dx2.double().cpu(), 2 * x.grad) < TOL
+    finally:
+        ops.reset_options()
+
+
 # ---- split-K of launches that leave most of the chip idle (bs-1 inference; conv_win.hip: conv_split_reduce_kernel) ----
 @pytest.mark.parametrize("case", [
     (1, 13, 13, 512, 1024, 3, 1, "same", False),       # window kernel: 16 tiles x 16 parts

@@ -99,3 +99,45 @@ def test_decode_nms_properties_full_size():
     assert torch.equal(again, kept)                                  # idempotent
     soft = tools.soft_nms(rows, 80, 0.5, 0.5, 0.5)
     assert soft.shape[0] <= rows.shape[0]
+
+
+@pytest.mark.parametrize("config", ["C3", "C4"])
+def test_headline_configs_at_their_true_batch_vs_fp64_oracle(config):
+    """BASELINE.json's headline configurations at their TRUE per-GPU batch against the float64 oracle:
+    C3 = YOLOv3 416x416 bs 32, C4 = YOLOv4 608x608 bs 16 -- training-mode forward (BatchNorm statistics over
+    32 x 416 x 416 = 5.5 M pixels per channel through the 64-slot fp64 atomics), the head outputs and the three
+    losses; the oracle runs under torch.no_grad() without retaining activations. Tolerance as the bs-2 end-to-end
+    case (tests/test_gpu_model.py): 1e-4, or 3x the error of the float32 CPU execution of the same oracle."""
+    import test_gpu_model as T
+    from oracle import models as OM
+    version, hw, N = (3, 416, 32) if config == "C3" else (4, 608, 16)
+    y, model, fwd, loss_o, loss_g, x, ys = T._setup(version, hw=hw, N=N)
+    net = model.net
+    w = T._weights_dict(model)
+    outs = net.forward(torch.tensor(x).cuda(), training=True)
+    dev_losses = [float(lf(torch.tensor(yt).cuda(), o).item()) for lf, o, yt in zip(loss_g, outs, ys)]
+    dev = [o.cpu().numpy() for o in outs]
+    OM.KEEP_ACTS = False
+    try:
+        with torch.no_grad():
+            ref, ctx = fwd({k: torch.tensor(v, dtype=torch.float64) for k, v in w.items()},
+                           torch.tensor(x, dtype=torch.float64), True)
+            ref_losses = [float(lf(torch.tensor(yt, dtype=torch.float64), o)) for lf, yt, o in zip(loss_o, ys, ref)]
+            o32, _ = fwd({k: torch.tensor(v) for k, v in w.items()}, torch.tensor(x), True)
+            l32 = [float(lf(torch.tensor(yt), o)) for lf, yt, o in zip(loss_o, ys, o32)]
+    finally:
+        OM.KEEP_ACTS = True
+    floor = max(T._rel(b32.numpy(), b.numpy()) for b, b32 in zip(ref, o32))
+    errs = [T._rel(a, b.numpy()) for a, b in zip(dev, ref)]
+    print(config, "forward errors", errs, "fp32-CPU floor", floor, "losses", dev_losses, ref_losses)
+    for e in errs:
+        assert e < max(1e-4, 3 * floor), (errs, floor)
+    for dl, rl, c32 in zip(dev_losses, ref_losses, l32):
+        tol = max(1e-4, 3 * abs(c32 - rl) / max(abs(rl), 1.0))
+        assert abs(dl - rl) < tol * max(abs(rl), 1.0), (dl, rl, c32)
+    # moving statistics after the training forward (Keras update, momentum 0.99)
+    worst = 0.0
+    for bn_name, (mm, mv) in ctx.moving.items():
+        got = model.get_layer(bn_name).get_weights()
+        worst = max(worst, T._rel(got[2], mm.numpy()), T._rel(got[3], mv.numpy()))
+    assert worst < 1e-4, worst

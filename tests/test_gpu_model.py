@@ -157,6 +157,11 @@ def _gpu_leaky_masks(net):
             scale, shift = net._bn_bufs(u)[0:2]
             z = u.y.double() * scale.double() + shift.double()
             masks[u.name] = (z > 0).cpu()
+        elif u.kind == "maxpool":
+            # the winner of every pooling window (flat NHWC offset into the pool's input, yolo_maxpool_fwd): the oracle takes
+            # the maximum where the device took it (oracle/models.py:_Ctx.pool) -- near-ties among the 25 / 81 / 169
+            # candidates of an SPP window reroute gradient entries exactly as a LeakyReLU sign flip does
+            masks[u.name] = u.argmax.reshape(-1).long().cpu()
     return masks
 
 
@@ -221,6 +226,8 @@ def test_model_parity(version, unbiased, true_c1):
     fwd_floor = max(_rel(b32.detach().numpy(), b.detach().numpy()) for b, b32 in zip(ref_tr, out32))
     # the branch patterns may only differ where the pre-activation is within fp32 error of zero
     assert max(ctx.mask_disagree.values(), default=0.0) < max(1e-4, 10 * fwd_floor), ctx.mask_disagree
+    # ... and a forced max-pool winner may only be below the true maximum by rounding
+    assert max(ctx.pool_disagree.values(), default=0.0) < max(1e-4, 10 * fwd_floor), ctx.pool_disagree
 
     for a, b in zip(outs, ref_tr):
         assert _rel(a.cpu().numpy(), b.detach().numpy()) < max(1e-4, 3 * fwd_floor)

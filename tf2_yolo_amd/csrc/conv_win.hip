@@ -54,21 +54,34 @@ namespace yolo {
 // kernel because the slab path inside the production instantiation tripled its scratch (152 -> 440-496 bytes per lane)
 // and made every window launch of the training step 10-40 % slower.
 // SK: the stream-K instantiation (a.sk_grid > 0: unit shares, slabs, tickets); the production kernel carries none of it.
-template <int WGM, int NCH, bool STAMPS = false, bool SPLIT = false, bool SK = false>
-__global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConvArgs a) {
-  constexpr int WGN = 2;
-  constexpr int BM = 64 * WGM, BN = 128;
+//
+// GEO = 1: PATCH geometry (round 3). The tile is a 2-D patch of BM / 16 rows x 16 columns of output pixels of ONE image
+// and the window its (rows + 2) x 18 halo patch of the input -- 180 window pixels for a 128-pixel tile whatever the row
+// length, where the linear window of a W-pixel row needs 2 (W + 1) + BM + 3 (549 for W = 208). Only the prologue differs
+// (which source pixel each window slot fetches, where a lane's fragment starts, the tap offsets in the window) and the
+// epilogue's row -> pixel map (planes_epilogue<..., PATCH>); the main loop is the same code. Used for rows longer than
+// 64 pixels (104 / 208 in YOLOv3-416, 76 / 152 / 304 in YOLOv4-608).
+// WGN = 1: 64 filter columns per tile (BN = 64) with WGM = 4 waves of 64 x 64 stacked in M (256 output pixels = a
+// 16 x 16 patch): the Cout = 64 layers, which would waste half of a 128-column tile.
+template <int WGM, int NCH, bool STAMPS = false, bool SPLIT = false, bool SK = false, int WGN = 2, int GEO = 0>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_win_kernel(const GatherConvArgs a) {
+  constexpr int BM = 64 * WGM, BN = 64 * WGN;
   constexpr int NW = WGM * WGN;
   constexpr int TM = 2, TN = 2;
-  constexpr int NB = 8 / NW;                       // filter DMAs per wave and stage (8 x 1 KB per stage)
+  constexpr int NB = 4 * WGN / NW;                 // filter DMAs per wave and stage (2 WGN blocks x 2 planes x 1 KB per stage)
   constexpr int NWS = (NCH * 4) / NW;              // window DMAs per wave and channel block, one per stage
   static_assert(NW == 4 || NW == 8, "4 or 8 waves");
+  static_assert(NB == 1 || NB == 2, "filter loader roles: one (block, plane) or one block with both planes per wave");
   static_assert((NCH * 4) % NW == 0 && NWS <= 7, "window chunks: NCH*4 DMAs spread evenly, at most 7 stages");
+  static_assert(GEO == 0 || (!SPLIT && !SK), "patch geometry: one workgroup per tile");
   constexpr int WIN_BYTES = NCH * 4096;            // one window buffer: 2 planes x 2 halves x NCH*64 px x 16 B
   constexpr int PLANE_STRIDE = 2 * NCH * 1024;
-  constexpr int BSTAGE = 8192;                     // 4 blocks of 32 filters x 2 planes x 1 KB
+  constexpr int BSTAGE = 4096 * WGN;               // 2 WGN blocks of 32 filters x 2 planes x 1 KB
   constexpr int BRING = 2 * WIN_BYTES;
   constexpr int LDS_TOTAL = 2 * WIN_BYTES + 3 * BSTAGE;
+  // patch geometry: PH x 16 output pixels, window (PH + 2) x 18 slots
+  constexpr int PH = BM / 16, PITCH = 18;
+  static_assert(GEO == 0 || (PH + 2) * PITCH <= NCH * 64, "patch window does not fit the chunks");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds_base = (unsigned)(size_t)smem;
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
     t_start = __builtin_amdgcn_s_memtime();
   }
 
-  const int H = a.Hs, W = a.Ws, P1 = W + 1;
+  const int H = a.Hs, W = a.Ws, P1 = GEO == 0 ? W + 1 : PITCH;
   const int HW = H * W;
   const int cpt = a.Cs >> 4;                       // 16-channel blocks
 
@@ -138,6 +151,15 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
   const int tile_m = a.tile_order ? tile % tiles_m : tile / a.tiles_n;
   const long long m0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
+  // patch geometry: tile_m -> (image pn, patch row py0, patch column px0) of the output (= input: stride 1, same size)
+  [[maybe_unused]] int pn = 0, py0 = 0, px0 = 0;
+  if constexpr (GEO == 1) {
+    const int tx = (W + 15) >> 4, ty = (H + PH - 1) / PH;
+    pn = tile_m / (tx * ty);
+    const int rem = tile_m - pn * (tx * ty);
+    py0 = (rem / tx) * PH;
+    px0 = (rem % tx) * 16;
+  }
 
   // padded linear index of a pixel m
   auto u_of = [&](long long m) -> int {
@@ -146,7 +168,7 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
     const int y = rem / W;
     return (n * (H + 1) + y + 1) * P1 + (rem - y * W) + 1;
   };
-  const int u_m0 = __builtin_amdgcn_readfirstlane(u_of(m0));
+  const int u_m0 = GEO == 0 ? __builtin_amdgcn_readfirstlane(u_of(m0)) : 0;
   const int u_lo = u_m0 - P1 - 1;
 
   // ---- window loader role: (plane, k-half) of this wave, NWS chunks; voffW = source unit of my pixel ----
@@ -158,6 +180,16 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
     chunkW[s] = (NW == 4) ? s : 2 * s + (wave >> 2);
     const int u = u_lo + chunkW[s] * 64 + lane;
     unsigned v = (unsigned)a.zero_blk_src * blkstrideA;
+    if constexpr (GEO == 1) {
+      // window slot -> (row, column) of the halo patch -> source pixel (py0 - 1 + row, px0 - 1 + column) of image pn
+      const int sl = chunkW[s] * 64 + lane;
+      const int wy = sl / PITCH, wx = sl - wy * PITCH;
+      const int sy = py0 - 1 + wy, sx = px0 - 1 + wx;
+      if (wy < PH + 2 && (unsigned)sy < (unsigned)H && (unsigned)sx < (unsigned)W) {
+        const int pix = (pn * H + sy) * W + sx;
+        v = ((unsigned)pix >> 4) * blkstrideA + (unsigned)(pix & 15) * 16;
+      }
+    } else
     if (u >= 0) {
       const int vrow = u / P1, xc = u - vrow * P1;
       const int n = vrow / (H + 1), vr = vrow - n * (H + 1);
@@ -173,7 +205,7 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
 
   // ---- filter loader role: 32-filter block rb, plane(s) ----
   const int r = lane & 31, hf = lane >> 5;
-  const int rbB = (NW == 4) ? wave : (wave >> 1);
+  const int rbB = (NB == 2) ? wave : (wave >> 1);
   unsigned voffB;
   {
     const int co = n0 + rbB * 32 + r;
@@ -186,7 +218,13 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const long long m = m0 + (wm * TM + i) * 32 + r;
-    const int wi = (m < a.M) ? (u_of(m) - u_m0) : 0;
+    int wi;
+    if constexpr (GEO == 1) {
+      const int rr = (wm * TM + i) * 32 + r;        // tile row -> (patch row, column); its window origin is that slot
+      wi = (rr >> 4) * PITCH + (rr & 15);
+    } else {
+      wi = (m < a.M) ? (u_of(m) - u_m0) : 0;
+    }
     abase[i] = (unsigned)(hf * NCH * 1024 + wi * 16);
   }
 
@@ -200,7 +238,7 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
   // filter DMA number d (0..NB-1) of stage (cb, t) into ring buffer rb3
   auto issue_filter = [&](int d, int cb, int t, int rb3) {
     const int cbe = cb < cpt ? cb : cpt - 1;
-    const int plane = (NW == 4) ? d : (wave & 1);
+    const int plane = (NB == 2) ? d : (wave & 1);
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(t * cpt + cbe) * PL_RECORD + (unsigned)plane * 512);
     const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(BRING + rb3 * BSTAGE + (rbB * 2 + plane) * 1024));
     dma16(rsrcB, voffB, so, l);
@@ -400,6 +438,9 @@ __global__ __launch_bounds__(128 * WGM, 2) void conv_win_kernel(const GatherConv
       epi_sum[5] += es[5] - es[4];     // stores, half 1
       ++epi_count;
     }
+  } else if constexpr (GEO == 1) {
+    const EpiGeom pg = EpiGeom{a.M, a.Hg, a.Wg, 0, 0, pn, py0, px0};
+    planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL, 0, NoStamp, true>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid, NoStamp(), &pg);
   } else if constexpr (!SPLIT) {
     if (finish) planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
   }
@@ -718,9 +759,66 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
   return check_launch("conv_win_kernel");
 }
 
+// ---- patch geometry (GEO = 1): rows longer than 64 pixels, and 64-column tiles for Cout <= 64 ----
+static bool conv_patch_supported(const GatherConvArgs& a) {
+  if (a.ntaps != 9 || a.sy != 1 || a.sx != 1 || a.Hg != a.Hs || a.Wg != a.Ws) return false;
+  if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0 || a.Hd != a.Hg || a.Wd != a.Wg) return false;
+  if ((a.Cs % 16) != 0 || a.Cout < 64 || a.ldw != 9 * a.Cs) return false;
+  for (int t = 0; t < 9; ++t)
+    if (a.taps[t].oy < -1 || a.taps[t].oy > 1 || a.taps[t].ox < -1 || a.taps[t].ox > 1 || a.taps[t].woff != t * a.Cs)
+      return false;
+  return true;
+}
+
+template <int WGM, int NCH, int WGN>
+static int launch_patch(GatherConvArgs& a, hipStream_t st) {
+  constexpr int BM = 64 * WGM, BN = 64 * WGN, PH = BM / 16;
+  const long long tiles_m = (long long)a.N * ((a.Hg + PH - 1) / PH) * ((a.Wg + 15) / 16);
+  a.tiles_n = (a.Cout + BN - 1) / BN;
+  const long long nb = tiles_m * a.tiles_n;
+  if (nb <= 0 || nb > 0x7fffffffLL) {
+    set_error("conv(patch window): bad grid %lld", nb);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  a.nblocks = (int)nb;
+  constexpr size_t lds = 2 * NCH * 4096 + 3 * 4096 * WGN;
+  auto kern = &conv_win_kernel<WGM, NCH, false, false, false, WGN, 1>;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  a.tile_order = 0;   // column tile fastest: the column tiles of a patch share its window in L2
+  a.sk_grid = 0;
+  a.split_parts = 1;
+  a.dbg = g_opt[OPT_DBG];
+  hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
+  return check_launch("conv_win_kernel(patch)");
+}
+
+// Policy of the patch form (YOLO_CONV_PATCH / yolo_set_option key 5): 0 = off, 1 = automatic (rows longer than 64
+// pixels; Cout <= 64 at any row length; launches of at least 256 tiles -- smaller ones keep the per-tap kernel and its
+// split-K), 2 = wherever the shape allows (tests, benchmarks).
+static int launch_conv_patch(GatherConvArgs& a, hipStream_t st) {
+  const int mode = g_opt[OPT_CONV_PATCH];
+  if (mode == 0 || !conv_patch_supported(a)) return 1;
+  const bool narrow = a.Cout <= 64;
+  if (mode == 1) {
+    if (!narrow && a.Ws <= 64) return 1;   // the linear window covers these
+    const long long tiles = narrow ? (long long)a.N * ((a.Hg + 15) / 16) * ((a.Wg + 15) / 16)
+                                   : (long long)a.N * ((a.Hg + 7) / 8) * ((a.Wg + 15) / 16) * ((a.Cout + 127) / 128);
+    if (tiles < 256) return 1;
+  }
+  return narrow ? launch_patch<4, 6, 1>(a, st) : launch_patch<2, 3, 2>(a, st);
+}
+
 // variant: 0 = automatic, 2 = 128x128 tiles (4 waves), 4 = 256x128 tiles (8 waves). Returns 1 when no window
 // kernel covers the shape (the caller then uses the per-tap streaming kernel), 0 on success, < 0 on error.
 int launch_conv_win(GatherConvArgs& a, int variant, hipStream_t st) {
+  if (variant != 2 && variant != 4) {
+    const int rc = launch_conv_patch(a, st);
+    if (rc <= 0) return rc;
+  }
   if (!conv_win_supported(a)) return 1;
   int wgm = variant;
   if (wgm != 2 && wgm != 4) {

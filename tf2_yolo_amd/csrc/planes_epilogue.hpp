@@ -17,8 +17,12 @@ struct NoStamp {
 struct EpiGeom {
   long long M;
   int Hg, Wg, ooy, oox;
+  // PATCH tiles (conv_win.hip, 2-D patch geometry): tile row rr is output pixel (pn, py0 + rr / 16, px0 + rr % 16)
+  int pn, py0, px0;
 };
-__device__ __forceinline__ EpiGeom epi_geom_of(const GatherConvArgs& a) { return EpiGeom{a.M, a.Hg, a.Wg, a.ooy, a.oox}; }
+__device__ __forceinline__ EpiGeom epi_geom_of(const GatherConvArgs& a) {
+  return EpiGeom{a.M, a.Hg, a.Wg, a.ooy, a.oox, 0, 0, 0};
+}
 
 // split-K (GatherConvArgs::split_parts > 1): a part's accumulators go to its slab in accumulator order --
 // 16-byte piece ((wave * TM + i) * TN + j) * 4 + q4 of lane l at byte (piece * 64 + l) * 16 -- for
@@ -41,7 +45,10 @@ __device__ __forceinline__ void store_split_slab(const GatherConvArgs& a, f32x16
       }
 }
 
-template <int BM, int BN, int WGM, int WGN, int LDS_BYTES, int DBG = 0, class STAMP = NoStamp>
+// PATCH: the tile's rows are a 2-D patch of output pixels, BM / 16 rows of 16 (EpiGeom::pn / py0 / px0), not BM consecutive
+// pixels: rows outside the image do not exist, and "which rows count for the statistics" is a per-lane bit mask
+// instead of a prefix of the tile.
+template <int BM, int BN, int WGM, int WGN, int LDS_BYTES, int DBG = 0, class STAMP = NoStamp, bool PATCH = false>
 __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
                                                 unsigned char* smem, const long long m0, const int n0, const int tile_m,
                                                 const int wm, const int wn, const int lane, const int tid,
@@ -62,7 +69,10 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
     for (int rr = tid; rr < BM; rr += NT) {
       const long long m = m0 + rr;
       long long off = -1;
-      if (m < G.M) {
+      if constexpr (PATCH) {
+        const int y = G.py0 + (rr >> 4), x = G.px0 + (rr & 15);
+        if (y < G.Hg && x < G.Wg) off = (((long long)G.pn * a.Hd + y) * a.Wd + x) * a.Cd;
+      } else if (m < G.M) {
         if (dense) {
           off = m * a.Cd;
         } else {
@@ -90,8 +100,23 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
   asm volatile("" ::"v"(unscale));
   stampf(1);
   // rows of this tile that exist (the last row tile of a tensor is partial): row r of the tile is real iff r < rows_valid
-  const int rows_valid = (G.M - m0 < (long long)BM) ? (int)(G.M - m0) : BM;
+  const int rows_valid = PATCH ? BM : ((G.M - m0 < (long long)BM) ? (int)(G.M - m0) : BM);
   const bool want_stats = a.stats != nullptr || a.absmax != nullptr;   // (data gradients, inference: none)
+  // PATCH: bit (i * 16 + q) = "row (wm * TM + i) * 32 + (q & 3) + 8 (q >> 2) + 4 (lane >> 5) exists" (this lane's 16 rows
+  // of each of its 32-row blocks), read once from the row offsets
+  [[maybe_unused]] unsigned long long rowmask = ~0ull;
+  if constexpr (PATCH) {
+    static_assert(BM / WGM / 32 <= 4, "row mask: at most 4 row blocks per wave");
+    rowmask = 0;
+    if (want_stats) {
+#pragma unroll
+      for (int i = 0; i < BM / WGM / 32; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q)
+          if (rowoff[(wm * (BM / WGM / 32) + i) * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5)] >= 0)
+            rowmask |= 1ull << (i * 16 + q);
+    }
+  }
   // Vector path. The C/D layout of the 32x32 MFMA leaves a lane with ONE column and 16 scattered rows of its
   // sub-tile (64 dword stores per lane, 128-B row pieces); every wave instead transposes its own sub-tile through a
   // PRIVATE strip of LDS, RP rows at a time, and stores dwordx4 (whole 128..512-B row pieces per lane group): no
@@ -150,7 +175,7 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
               const int rl = (q & 3) + 8 * ((q >> 2) - hp * (RP / 8)) + 4 * (lane >> 5);   // row inside the pass
               const float v = fmaf(acc[i][j][q], us2, bvj[j]);
               strip[rl * TLD + j * 32 + (lane & 31)] = v;
-              const float vm = (row0 + rl < rows_valid) ? v : 0.f;
+              const float vm = (PATCH ? ((rowmask >> (i * 16 + q)) & 1) != 0 : (row0 + rl < rows_valid)) ? v : 0.f;
               csum[j] += vm;
               csq[j] = fmaf(vm, vm, csq[j]);
               cmx[j] = fmaxf(cmx[j], fabsf(vm));

@@ -28,6 +28,9 @@ static void options_from_env() {
   // tickets, the last arriver combines), > 1 = stream-K with that many workgroups (benchmarks, tests)
   e = getenv("YOLO_CONV_SK");
   g_opt[OPT_CONV_SK] = e ? atoi(e) : 1;
+  // 3x3 stride-1 window kernel on 2-D patches (conv_win.hip, GEO = 1): 0 off, 1 automatic, 2 wherever the shape allows
+  e = getenv("YOLO_CONV_PATCH");
+  g_opt[OPT_CONV_PATCH] = e ? atoi(e) : 1;
 }
 void init_options() {
   static bool done = false;

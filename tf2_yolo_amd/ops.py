@@ -84,13 +84,22 @@ _PLANES_WAVES = int(_os.environ.get("YOLO_PLANES_WAVES", "0") or 0)   # 0: the l
 
 
 CONV_WIN = int(_os.environ.get("YOLO_CONV_WIN", "1"))
+CONV_PATCH = int(_os.environ.get("YOLO_CONV_PATCH", "1"))
 
 
 def _planes_variant(cout, win=None, k1=False):
     """mirrors launch_gather_planes() in csrc/conv_planes.hip and launch_conv_win() in csrc/conv_win.hip;
     win = (W of the source, M rows) of a 3x3 stride-1 layer, None otherwise; k1 = 1x1 stride-1 layer (8-wave tile)"""
+    if win is not None and CONV_WIN not in (0, 2, 4) and CONV_PATCH and cout >= 64:
+        # launch_conv_patch() in csrc/conv_win.hip: rows longer than 64 pixels or Cout <= 64, at least 256 tiles
+        ws, m, hs, n = win
+        narrow = cout <= 64
+        tiles = (n * ((hs + 15) // 16) * ((ws + 15) // 16) if narrow
+                 else n * ((hs + 7) // 8) * ((ws + 15) // 16) * ((cout + 127) // 128))
+        if CONV_PATCH == 2 or ((narrow or ws > 64) and tiles >= 256):
+            return "conv_patch_planes_kernel<%s>" % ("256,64" if narrow else "128,128")
     if win is not None and CONV_WIN and cout >= 128:
-        ws, m = win
+        ws, m = win[:2]
         wgm = CONV_WIN if CONV_WIN in (2, 4) else (0 if ws > 64 else 2)
         if wgm:
             return "conv_win_planes_kernel<%d,128>" % (64 * wgm)
@@ -106,7 +115,7 @@ def _win_key(d, hs, ws, cs):
     """(W, M) when the window kernel covers the layer: 3x3, stride 1, 'same', 16-channel blocks"""
     if d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.pad_t == 1 and d.pad_l == 1 and cs % 16 == 0 \
             and d.H == d.Ho and d.W == d.Wo:
-        return (ws, d.N * hs * ws)
+        return (ws, d.N * hs * ws, hs, d.N)
     return None
 
 
@@ -124,6 +133,7 @@ def _gather_variant(cout, flat, m=None):
 
 OPT_CONV_WIN = 0   # include/yolo_hip.h YOLO_OPT_CONV_WIN
 OPT_CONV_SK = 2
+OPT_CONV_PATCH = 5   # include/yolo_hip.h YOLO_OPT_CONV_PATCH
 _CONV_WS = None
 
 
@@ -842,6 +852,8 @@ def cal_iou(xywh_true, xywh_pred, mode=1, grid_wh=(1.0, 1.0)):
     arr = ctypes.c_longlong * max(nd, 1)
     out = torch.empty(shape, device=xywh_true.device, dtype=xywh_true.dtype)
     out2 = torch.empty(shape, device=xywh_true.device, dtype=xywh_true.dtype) if mode == 3 else None
+    if out.numel() == 0:
+        return (out, out2) if mode == 3 else out
     check(_lib.load().yolo_cal_iou(_p(xywh_true), _p(xywh_pred), _p(out), _p(out2),
                                    1 if xywh_true.dtype == torch.float64 else 0, int(mode), nd, arr(*shape),
                                    arr(*strides(xywh_true, lead_a)), arr(*strides(xywh_pred, lead_b)),
