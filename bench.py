@@ -4,9 +4,11 @@
 One "step" = forward (training-mode BN) + the three fused loss/gradient kernels + backward +
 gradient all-reduce (N > 1, RCCL over xGMI, overlapped) + Adam, on a synthetic batch that is
 already resident in HBM. Prints ONE JSON line (rank 0) with the `roofline` of the dominant kernel
-(the fp32 MFMA implicit-GEMM conv) measured with HIP events inside the timed region, and, at
-N = 1, a `cpu_baseline` (the torch-CPU restatement of the same training step on the host cores;
-tf.keras is not installable here).
+(the conv kernel variant with the most device time: fp16x3 "planes" MFMA implicit GEMM) measured with
+HIP events inside the timed region -- beside the spec-peak fraction it carries `held_clock_ceiling`, the raw
+fp16 MFMA rate a bare MFMA loop sustains on random data on THIS box right after the timed region
+(yolo_mfma_probe) -- and, at N = 1, a `cpu_baseline` (the torch-CPU restatement of the same training step on
+the host cores; tf.keras is not installable here).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -243,20 +245,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # W untimed steps (at least three: the step is captured into hipGraphs after two eager steps of a configuration,
+    # tf2_yolo_amd/capture.py, and the capture itself must not fall into the timed region)
+    warm_run = max(args.warmup, 3)
+    for _ in range(warm_run):
         model.train_step_device(x, ys)
     barrier()
-    log("warmup done")
-    timer = None if args.no_kernel_timer else ops.KernelTimer()
-    ops.TIMER = timer
+    captured = getattr(model, "_step_graphs", None) is not None
+    log(f"warmup done ({warm_run} steps; step launch mode: {'hipGraph replay' if captured else 'eager'})")
+    # ---- THE timed region: exactly K steps between barriers ----
     t0 = time.perf_counter()
     for _ in range(args.steps):
         bufs, _ = model.train_step_device(x, ys)
     barrier()
     dt = time.perf_counter() - t0
-    ops.TIMER = None
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     loss_val = float(sum(b[0].item() for b in bufs))
+    # ---- the same K steps once more with every launch enqueued from Python and bracketed by HIP events on its stream
+    # (ops.KernelTimer): per-launch events cannot be recorded inside a graph replay, so the roofline block is measured
+    # here, over K steps timed exactly like the region above (every rank runs it: the collectives must match) ----
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    dt_eager = None
+    if timer is not None:
+        ops.TIMER = timer
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            model.train_step_device(x, ys)
+        barrier()
+        dt_eager = time.perf_counter() - t1
+        ops.TIMER = None
+        log(f"eager + per-launch events region done: {dt_eager / args.steps * 1e3:.2f} ms/step")
+
+    # Outside the timed region, right behind it (the chip is as warm as it was inside): what a bare fp16 MFMA loop on
+    # random register operands sustains on THIS box -- the ceiling any fp16 MFMA kernel has at the clock the chip holds
+    ceiling = None
+    if rank == 0 and world == 1:
+        try:
+            ceiling = ops.mfma_ceiling(0.15)
+        except Exception as e:   # informational
+            ceiling = {"error": repr(e)}
 
     # Outside the timed region (rank 0, informational): the same step with the filter-gradient stream
     # switched off, so that every conv kernel has the chip to itself. In the timed region the filter gradient
@@ -305,10 +332,11 @@ def main():
                "raw_fp16_mfma_tflops_conv": round(PLANES_PASSES * sum(v["flops"] for k, v in fa.items() if "planes" in k)
                                                   / 2 / kms / 1e9, 1)}
 
-    t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    t = torch.tensor([dt, dt_eager if dt_eager is not None else 0.0], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = float(t[0].item())
+    dt_eager = float(t[1].item()) if dt_eager is not None else None
 
     dp_in_sync = None
     if world > 1 or force_dp:   # outside the timed region: every replica must hold bit-identical weights after K steps
@@ -333,6 +361,13 @@ def main():
                                    "bf16 MFMA dense peak 2500 TFLOP/s / 6 passes per fp32 product (exact 3-way split)"
                                    if "split" in name else "fp32-input MFMA peak (v_mfma_f32_32x32x2_f32)"),
                     "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                    "held_clock_ceiling": None if not ceiling or "error" in ceiling else dict(
+                        ceiling, algorithmic_tflops=round(ceiling["raw_fp16_mfma_tflops"] / PLANES_PASSES, 1),
+                        what="bare v_mfma_f32_32x32x16_f16 loops on random fp16 register operands, 2 x 8 waves per CU, no "
+                             "memory traffic, ONE launch right behind the timed region (csrc/probe.hip); algorithmic = raw / 3 "
+                             "passes per product"),
+                    "frac_of_held_clock_ceiling": (None if not ceiling or "error" in ceiling or "planes" not in name else
+                                                   round(achieved / (ceiling["raw_fp16_mfma_tflops"] / PLANES_PASSES), 4)),
                     "traffic": hbm_traffic_from_profile(name),
                     "pmc": pmc_from_profile(name),
                     "ratio_to_fp32_input_mfma_peak_NOT_a_roofline_fraction": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
@@ -344,6 +379,10 @@ def main():
                                           "2 extra steps outside the timed region",
                                   "achieved": round(iso[name]["flops"] / (iso[name]["ms"] * 1e-3) / 1e12, 2),
                                   "frac": round(iso[name]["flops"] / (iso[name]["ms"] * 1e-3) / 1e12 / peak, 4),
+                                  "frac_of_held_clock_ceiling": (
+                                      None if not ceiling or "error" in ceiling or "planes" not in name else
+                                      round(iso[name]["flops"] / (iso[name]["ms"] * 1e-3) / 1e12
+                                            / (ceiling["raw_fp16_mfma_tflops"] / PLANES_PASSES), 4)),
                                   "avg_launch_us": round(iso[name]["ms"] * 1e3 / iso[name]["launches"], 2)}),
                     "flops_per_launch": a["flops"] / a["launches"],
                     "all_conv_kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3),
@@ -359,8 +398,20 @@ def main():
                                       "forward (batch-stat BN) + 3 fused loss/grad kernels + backward + "
                                       "gradient all-reduce + Adam",
                           "global_batch": world * args.batch, "per_gpu_batch": args.batch,
-                          "parallelism": f"dp{world}", "loss": round(loss_val, 4), "replicas_in_sync": dp_in_sync},
+                          "parallelism": f"dp{world}", "loss": round(loss_val, 4), "replicas_in_sync": dp_in_sync,
+                          "step_launch_mode": ("hipGraph replay: forward + losses + backward + Adam captured once, cut at the "
+                                               "gradient buckets in data-parallel jobs (tf2_yolo_amd/capture.py)" if captured
+                                               else "eager: every launch enqueued from Python"),
+                          "warmup_steps_run": warm_run},
+               "eager_region": (None if dt_eager is None else
+                                {"what": "the same K steps again, every launch enqueued from Python and bracketed by HIP events on "
+                                         "its stream (the roofline block's measurements come from here: a graph replay cannot "
+                                         "carry per-launch events)",
+                                 "ms_per_step": round(dt_eager / args.steps * 1e3, 3),
+                                 "images_per_s": round(world * args.batch * args.steps / dt_eager, 2)}),
                "roofline": roof, "forward": fwd}
+        if fwd is not None and ceiling and "error" not in ceiling:
+            fwd["conv_frac_of_held_clock_ceiling"] = round(fwd["raw_fp16_mfma_tflops_conv"] / ceiling["raw_fp16_mfma_tflops"], 4)
         if world == 1:
             try:
                 out["decode_nms"] = decode_nms_block()

@@ -48,6 +48,13 @@ const char* yolo_last_error(void);
 int yolo_abi_version(void);
 /* 1 if a HIP device is visible to the calling process, 0 otherwise (never throws) */
 int yolo_device_available(void);
+/* Yardstick for the roofline report (no reference counterpart): ONE launch of bare v_mfma_f32_32x32x16_f16 loops (`iters`
+ * iterations of 6 MFMAs per wave, `workgroups` workgroups of 8 waves) on the caller's fp16 operands -- operands_f16 holds
+ * workgroups * 512 * 32 halves (random data: the clock a chip holds depends on the switching activity), sink
+ * workgroups * 512 floats. *flops_host (optional, HOST pointer) receives the MFMA FLOPs of the launch; the caller times it
+ * with events on `stream`. */
+int yolo_mfma_probe(const void* operands_f16, float* sink, int workgroups, int iters, double* flops_host, void* stream);
+
 /* Run-time tuning / diagnostic switches of the library (no reference counterpart). key 0 = YOLO_OPT_CONV_WIN:
  * kernel used by yolo_conv2d_fwd_planes / _dgrad_planes for 3x3 stride-1 layers: 0 = per-tap streaming kernel,
  * 1 = input-window kernel with automatic tile choice, 2 / 4 = window kernel with 128x128 / 256x128 tiles.
@@ -184,6 +191,16 @@ int yolo_split_planes_absmax(const float* x, long long rows, int C, const unsign
 int yolo_conv2d_wgrad_planes(const yolo_conv_desc* d, const void* x_planes, const void* dy_planes,
                              float* dw, void* stream);
 
+/* Reproducible filter / bias gradients (no reference counterpart; SURVEY.md section 5 asks for atomics-free reductions where
+ * determinism matters). With a workspace registered, yolo_conv2d_wgrad_planes stores every workgroup's partial tile to a
+ * slab and a second kernel adds the splits of the pixel contraction IN ORDER into dw; yolo_conv2d_wgrad_bias does the same
+ * with its per-block partial sums: bit-identical results from run to run. Without one (p == NULL) both combine their
+ * partials with fp32 atomics (last bits depend on the arrival order). The workspace is caller-owned, yolo_wgrad_workspace_bytes()
+ * is the size that never shortens a launch's split; launches that use it must be ordered on ONE stream. YOLO_WGRAD_DETERMINISTIC=0
+ * in the environment keeps the atomics even with a workspace (A/B timing). */
+size_t yolo_wgrad_workspace_bytes(void);
+int yolo_set_wgrad_workspace(void* p, size_t bytes);
+
 /* ------------------------------------------------------------------------------------
  * BatchNormalization (training and inference) + activation (+ residual add)
  * (replaces BatchNormalization + LeakyReLU / Mish + Add at
@@ -251,6 +268,16 @@ int yolo_bn_finalize_bound(double* stats, long long P, int C, const float* gamma
                            float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var,
                            float* scale, float* shift, float* save_mean, float* save_invstd,
                            const unsigned* absmax, unsigned* bound, void* stream);
+/* The same with `mean_offset` [C] (optional): the statistics in `stats` are those of y - mean_offset. Keras puts a bias on the
+ * convolution in front of BatchNormalization in YOLOv1.5 / v2 (yolov2/models/backbone.py:11-18, Conv2D's use_bias default); in
+ * training mode that bias cancels in (y - mean) exactly, so the executor leaves it out of the convolution -- the statistics
+ * then carry no bias-sized mean (var = E[y^2] - mean^2 would lose mean^2 / var of its digits) -- and passes it here, where
+ * only the moving mean needs it: moving_mean <- momentum * moving_mean + (1 - momentum) * (mean + mean_offset).
+ * scale / shift / save_mean stay those of the offset-free tensor the convolution wrote. */
+int yolo_bn_finalize_offset(double* stats, long long P, int C, const float* gamma, const float* beta, float eps,
+                            float momentum, int unbiased_moving_var, float* moving_mean, float* moving_var, float* scale,
+                            float* shift, float* save_mean, float* save_invstd, const unsigned* absmax, unsigned* bound,
+                            const float* mean_offset, void* stream);
 /* inference (folded scale / shift, no batch statistics): *bound = bit pattern of
  * max_c |scale_c| max|x_c| + |shift_c| from the conv epilogue's per-channel absmax */
 int yolo_bn_infer_bound(int C, const float* scale, const float* shift, const unsigned* absmax,
@@ -383,6 +410,11 @@ int yolo_metrics(const yolo_loss_cfg* cfg, const float* y_true, const float* y_p
  * ------------------------------------------------------------------------------------ */
 int yolo_adam_step(float* p, float* g, float* m, float* v, long long n, float lr, float beta1,
                    float beta2, float eps, int step, float grad_scale, int zero_grad, void* stream);
+/* The same update with its five scalars read from DEVICE memory: hyper = {lr_t, beta1, beta2, eps, grad_scale}, lr_t = the
+ * bias-corrected rate of this step, yolo_adam_lr_t(lr, beta1, beta2, step) (computed in double exactly as yolo_adam_step does).
+ * This is the form a captured hipGraph of the training step replays: the host refreshes `hyper` before every replay. */
+float yolo_adam_lr_t(float lr, float beta1, float beta2, int step);
+int yolo_adam_step_dev(float* p, float* g, float* m, float* v, long long n, const float* hyper, int zero_grad, void* stream);
 int yolo_sgd_step(float* p, float* g, long long n, float lr, float grad_scale, int zero_grad,
                   void* stream);
 int yolo_fill(float* p, long long n, float value, void* stream);

@@ -342,3 +342,44 @@ def test_yolo_body_plus_yolo_head_is_create_model():
     assert [p.shape for p in m2.predict(x)] == [(2, 2, 2, 21), (2, 4, 4, 21), (2, 8, 8, 21)]
     with pytest.raises(ValueError, match="multiple"):
         yolo_head(yolo_body((64, 64, 3)), class_num=2, anchors=A9[:8])
+
+
+def test_captured_step_is_bit_identical_to_eager_steps():
+    """tf2_yolo_amd/capture.py: from the third step on train_step_device replays captured hipGraphs. Same seed, same data:
+    five steps with the capture (two eager + three replays) against five eager steps -- every loss equal (to the fp64
+    atomics' order, 1e-12) and the weights, BatchNorm moving statistics and Adam moments BIT-identical (the filter-gradient
+    reductions are atomics-free). Then a different batch through the same graphs, and a changed learning rate."""
+    import yolov3
+    from tf2_yolo_amd import labels
+    from tf2_yolo_amd.optimizers import Adam
+
+    def make(graphs):
+        y = yolov3.Yolo((96, 96, 3), ["a", "b", "c"])
+        y.create_model(anchors=A9, pretrained_body=None, seed=11)
+        y.model.compile(optimizer=Adam(learning_rate=1e-3), loss=y.loss())
+        y.model._graphs_failed = not graphs        # eager reference: the switch a failed capture would flip
+        return y.model
+    rng = np.random.default_rng(3)
+    x1, ys1 = labels.synthetic_batch(rng, 4, (96, 96), 3)
+    x2, ys2 = labels.synthetic_batch(rng, 4, (96, 96), 3)
+    dev = lambda x, ys: (torch.from_numpy(x).cuda(), [torch.from_numpy(a).cuda() for a in ys])
+    b1, b2 = dev(x1, ys1), dev(x2, ys2)
+    seq = [b1, b1, b1, b2, b1, b2]
+    res = {}
+    for graphs in (False, True):
+        m = make(graphs)
+        losses = []
+        for i, (x, ys) in enumerate(seq):
+            if i == 4:
+                m.optimizer.learning_rate = 3e-4          # read by refresh_hyper / the eager step alike
+            bufs, _ = m.train_step_device(x, ys)
+            losses.append([float(b[0].item()) for b in bufs])
+        if graphs:
+            assert m._step_graphs is not None and len(m._step_graphs.segments) == 1      # no data parallelism: one graph
+        res[graphs] = (losses, m.net.params.data.clone(), m.net.state.data.clone(), m.optimizer.m.clone(), m.optimizer.v.clone())
+    for la, lb in zip(res[False][0], res[True][0]):
+        for a, b in zip(la, lb):
+            assert abs(a - b) <= 1e-12 * max(abs(a), 1.0), (res[False][0], res[True][0])
+    for a, b in zip(res[False][1:], res[True][1:]):
+        assert torch.equal(a, b)
+    assert res[True][0][0] != res[True][0][3]       # (the second batch really went through the graphs)

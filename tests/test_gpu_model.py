@@ -169,7 +169,7 @@ def _gpu_leaky_masks(net):
 @pytest.mark.parametrize("version,unbiased,true_c1", [(3, True, False), (2, True, False), (1, True, False), (4, True, False),
                                                       (3, False, False), (1, True, True), (3, True, "tiny"),
                                                       (3, True, "416"), (4, True, "608"), (2, True, "416"),
-                                                      (3, True, "tiny416")])
+                                                      (3, True, "tiny416"), (4, True, "608bs1")])
 def test_model_parity(version, unbiased, true_c1):
     from tf2_yolo_amd import optimizers
     if true_c1 == "tiny416":   # tiny-YOLOv3 at its usual resolution: 416x416, grids 13 and 26 (bs 2)
@@ -184,6 +184,14 @@ def test_model_parity(version, unbiased, true_c1):
     elif true_c1 == "416":   # BASELINE.json's headline graph at its true resolution (bs 2): 13 / 26 / 52 grids, the
         y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=416, N=2, unbiased=unbiased)   # window kernels' real shapes
         assert [tuple(o.shape[1:3]) for o in model.output] == [(13, 13), (26, 26), (52, 52)]
+    elif true_c1 == "608bs1":
+        # YOLOv4-608 at bs ONE: the case round 2 moved to bs 2 because single BN tensors were 3-5x the fp32-CPU error on
+        # every conv path. Cause (scripts/grad_excess.py, profiles/r03_grad_excess_*.json): near-ties among the 25 / 81 /
+        # 169 candidates of the SPP max-pool windows -- the device and the oracle picked different winners, and ONE
+        # rerouted gradient entry at pan_td1_spp propagates into the whole backbone in front of it. With the oracle taking
+        # the maximum where the device took it (oracle/models.py:_Ctx.pool, the max-pool twin of leaky_masked) the device
+        # is at 0.9x (median) / 1.1x (90 %) / 1.8x (99 %) of the fp32-CPU error per tensor: bound 2x here.
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(4, hw=608, N=1, unbiased=unbiased)
     elif true_c1 == "608":   # configs[2]: YOLOv4 CSPDarknet-53 + SPP + PAN at 608x608 (bs 2): 19 / 38 / 76 grids
         y, model, fwd, loss_o, loss_g, x, ys = _setup(4, hw=608, N=2, unbiased=unbiased)
         assert sorted(tuple(o.shape[1:3]) for o in model.output) == [(19, 19), (38, 38), (76, 76)]
@@ -259,6 +267,8 @@ def test_model_parity(version, unbiased, true_c1):
             e = _rel(got, r.numpy())
             e32 = _rel(w32[f"{n}/{i}"].grad.numpy(), r.numpy())
             worst = max(worst, (n, e, e32), key=lambda t: t[1])
+            if true_c1 == "608bs1":
+                assert e < max(2 * e32, 1e-4), (n, i, e, e32)      # at most twice the fp32-CPU error
             assert e < max(1e-3, 4 * e32, 3 * fwd_floor), (n, i, e, e32, fwd_floor)
     print("worst gradient error", worst)
 

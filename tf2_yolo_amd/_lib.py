@@ -42,6 +42,7 @@ SIGNATURES = {
     "yolo_abi_version": (c_int, []),
     "yolo_device_available": (c_int, []),
     "yolo_set_option": (c_int, [c_int, c_int]),
+    "yolo_mfma_probe": (c_int, [_P, _P, c_int, c_int, POINTER(c_double), _P]),
     "yolo_set_debug_buffer": (c_int, [_P, c_size_t]),
     "yolo_encode_labels": (c_int, [_P, _P, _P, c_int, c_double, c_double, c_int, c_int, c_int, _P, _P, _P]),
     "yolo_down2xlabel": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, _P]),
@@ -65,6 +66,8 @@ SIGNATURES = {
     "yolo_conv2d_fwd_absmax": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "yolo_conv2d_dgrad_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P]),
     "yolo_conv2d_wgrad_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P]),
+    "yolo_wgrad_workspace_bytes": (c_size_t, []),
+    "yolo_set_wgrad_workspace": (c_int, [_P, c_size_t]),
     "yolo_bn_stats": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_bn_finalize": (c_int, [_P, _LL, c_int, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P]),
     "yolo_bn_fold_inference": (c_int, [c_int, _P, _P, _P, _P, c_float, _P, _P, _P]),
@@ -78,6 +81,8 @@ SIGNATURES = {
     "yolo_bn_infer_bound": (c_int, [c_int, _P, _P, _P, _P, _P]),
     "yolo_bn_finalize_bound": (c_int, [_P, _LL, c_int, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
                                        _P, _P]),
+    "yolo_bn_finalize_offset": (c_int, [_P, _LL, c_int, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
+                                        _P, _P, _P]),
     "yolo_bn_act_bwd_reduce_bound": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "yolo_act_fwd": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_act_bwd": (c_int, [_P, _P, _LL, c_int, _P, _P]),
@@ -97,6 +102,8 @@ SIGNATURES = {
     "yolo_loss_fwd_bwd": (c_int, [POINTER(LossCfg), _P, _P, _P, _P, c_float, _P, c_size_t, _P]),
     "yolo_metrics": (c_int, [POINTER(LossCfg), _P, _P, c_float, _P, _P]),
     "yolo_adam_step": (c_int, [_P, _P, _P, _P, _LL, c_float, c_float, c_float, c_float, c_int, c_float, c_int, _P]),
+    "yolo_adam_lr_t": (c_float, [c_float, c_float, c_float, c_int]),
+    "yolo_adam_step_dev": (c_int, [_P, _P, _P, _P, _LL, _P, c_int, _P]),
     "yolo_sgd_step": (c_int, [_P, _P, _LL, c_float, c_float, c_int, _P]),
     "yolo_fill": (c_int, [_P, _LL, c_float, _P]),
     "yolo_decode_level": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_float, _P, c_int, _P, _P, c_size_t, _P]),

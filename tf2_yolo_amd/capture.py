@@ -1,0 +1,127 @@
+"""The training step as replayed hipGraphs: forward + losses + backward + optimizer captured ONCE, then a handful of graph
+launches per step instead of ~700 kernel launches enqueued from Python (20 ms of host time per 32 ms step; DESIGN.md
+section 5). One process per GPU keeps that host time off the critical path only while a core is free for it; eight ranks on
+one host should not depend on that.
+
+Segments. In a data-parallel job the gradient buckets are all-reduced WHILE backward runs (dp.GradReducer). Collectives
+are not captured (gloo cannot be, and RCCL captures are not worth the risk on a path nobody can rehearse here): the
+step is cut into graph segments at the points where a bucket becomes complete, and the all-reduce of that bucket is
+issued eagerly between two replays:
+
+    [ forward, losses, backward down to bucket 0 ] -> all-reduce(bucket 0) on the communication stream
+    [ backward down to bucket 1 ]                 -> all-reduce(bucket 1)
+    ...
+    [ rest of backward ]                          -> wait for the communication stream
+    [ Adam ]
+
+Without data parallelism the whole step is ONE graph. The executor's second stream (filter gradients) is forked and
+joined inside every segment, so a cut costs one join of the two streams. The optimizer's step-dependent scalars (the
+bias-corrected rate, 1/world) live in device memory and are refreshed before each replay (Adam.refresh_hyper), so the
+captured launches never change. Results are bit-identical to the eager step (same kernels, same order, same operands;
+the filter-gradient reductions are atomics-free: ops.ensure_wgrad_workspace).
+"""
+import torch
+
+from ._lib import YoloHipError
+
+
+class StepGraphs:
+    """Captured training step of one Model for one (batch size, loss list, optimizer, reducer) configuration."""
+
+    def __init__(self, model, x, y_list):
+        self.model = model
+        self.key = self.key_of(model, x)
+        net = model.net
+        opt = model.optimizer
+        if not getattr(opt, "capturable", False):
+            raise YoloHipError("this optimizer has no capturable form")
+        # static inputs of the graphs: the caller's batch is copied into them before every replay
+        self.x = x.clone()
+        self.ys = [y.clone() for y in y_list]
+        self.segments = []          # (graph, action): action = ("reduce", bucket) | ("finish",) | None
+        self._capture(net, opt)
+
+    @staticmethod
+    def key_of(model, x):
+        return (tuple(x.shape), getattr(model.net, "alloc_gen", 0), tuple(id(l) for l in model.loss), id(model.optimizer),
+                id(model._reducer), model.net.anchors_trainable)
+
+    def _capture(self, net, opt):
+        model = self.model
+        red = model._reducer if (model._reducer is not None and model._reducer.active) else None
+        pool = torch.cuda.graph_pool_handle()
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+        state = {"g": None}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            g.capture_begin(pool=pool)
+            state["g"] = g
+
+        def end(action):
+            state["g"].capture_end()
+            self.segments.append((state["g"], action))
+            state["g"] = None
+
+        old_hook = net.grad_ready_hook
+        if red is not None:
+            index = model._dp_unit_index
+
+            def cut_hook(u):
+                for b in red.closes[index[id(u)]]:
+                    # a bucket is complete: join the filter-gradient stream, close this segment; the all-reduce of the
+                    # bucket is issued between this replay and the next
+                    net._join_wgrad()
+                    net._dyp_events = [None, None]
+                    end(("reduce", b))
+                    begin()
+            net.grad_ready_hook = cut_hook
+        try:
+            with torch.cuda.stream(stream):
+                begin()
+                outs = net.forward(self.x, training=True)
+                for i, (o, yt) in enumerate(zip(outs, self.ys)):
+                    model.loss[i].fwd_bwd(yt, o, grad_scale=1.0, dpred=model._dpred[i], loss_out=model._loss_bufs[i])
+                net.backward(model._dpred)
+                net._dyp_events = [None, None]
+                if red is not None:
+                    end(("finish",))
+                    begin()
+                opt.step_captured()
+                end(None)
+        except Exception:
+            if state["g"] is not None:
+                try:
+                    state["g"].capture_end()
+                except Exception:
+                    pass
+            raise
+        finally:
+            net.grad_ready_hook = old_hook
+        torch.cuda.current_stream().wait_stream(stream)
+        # the capture pass executed nothing, but it ran the host side of a step: leave the host flags as after a step
+        net.mark_params_changed()
+
+    def replay(self, x, y_list):
+        model, net, opt = self.model, self.model.net, self.model.optimizer
+        red = model._reducer if (model._reducer is not None and model._reducer.active) else None
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        for dst, src in zip(self.ys, y_list):
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        opt.refresh_hyper(grad_scale=(1.0 / red.world) if red is not None else 1.0)
+        for g, action in self.segments:
+            g.replay()
+            if action is None:
+                continue
+            if action[0] == "reduce":
+                red.reduce_bucket(action[1])
+            else:
+                if net.anchors_trainable and red.world > 1:
+                    import torch.distributed as dist
+                    dist.all_reduce(net.anchor_grads, group=red.pg)
+                red.finish()
+        net.mark_params_changed()
+        return model._loss_bufs

@@ -108,7 +108,7 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
                                    float momentum, int unbiased, float* __restrict__ mmean, float* __restrict__ mvar,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
                                    float* __restrict__ sinv, const unsigned* __restrict__ absmax,
-                                   unsigned* __restrict__ bound) {
+                                   unsigned* __restrict__ bound, const float* __restrict__ mean_offset) {
   // one wave per channel: lane r reads replica slot r, shuffle-reduce (128 dependent loads per thread before)
   const int lane = threadIdx.x & 63;
   const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -138,7 +138,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, long long P
   if (mmean != nullptr) {
     double fed = var;
     if (unbiased && P > 1) fed = var * (double)P / (double)(P - 1);
-    mmean[c] = (float)((double)momentum * mmean[c] + (1.0 - (double)momentum) * mean);
+    // mean_offset: the statistics are those of y - offset (a conv bias left out of the convolution: it cancels in
+    // training-mode BatchNormalization, so the conv + BN unit never adds it; only the moving mean has to know about it)
+    const double mean_full = mean + (mean_offset != nullptr ? (double)mean_offset[c] : 0.0);
+    mmean[c] = (float)((double)momentum * mmean[c] + (1.0 - (double)momentum) * mean_full);
     mvar[c] = (float)((double)momentum * mvar[c] + (1.0 - (double)momentum) * fed);
   }
   }
@@ -616,18 +619,27 @@ extern "C" int yolo_bn_stats(const float* x, long long P, int C, double* stats, 
   return check_launch("bn_stats_kernel");
 }
 
-extern "C" int yolo_bn_finalize_bound(double* stats, long long P, int C, const float* gamma, const float* beta,
-                                      float eps, float momentum, int unbiased_moving_var, float* moving_mean,
-                                      float* moving_var, float* scale, float* shift, float* save_mean,
-                                      float* save_invstd, const unsigned* absmax, unsigned* bound, void* stream) {
+extern "C" int yolo_bn_finalize_offset(double* stats, long long P, int C, const float* gamma, const float* beta,
+                                       float eps, float momentum, int unbiased_moving_var, float* moving_mean,
+                                       float* moving_var, float* scale, float* shift, float* save_mean,
+                                       float* save_invstd, const unsigned* absmax, unsigned* bound,
+                                       const float* mean_offset, void* stream) {
   YOLO_REQUIRE(stats && gamma && beta && scale && shift && save_mean && save_invstd && P > 0 && C > 0,
                "bn_finalize: bad args");
   YOLO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must come in pairs");
   static_assert(YOLO_BN_STAT_SLOTS == 64, "bn_finalize_kernel: one lane per replica slot");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, as_stream(stream), stats, P, C, gamma,
                      beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var, scale, shift, save_mean,
-                     save_invstd, absmax, bound);
+                     save_invstd, absmax, bound, mean_offset);
   return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int yolo_bn_finalize_bound(double* stats, long long P, int C, const float* gamma, const float* beta,
+                                      float eps, float momentum, int unbiased_moving_var, float* moving_mean,
+                                      float* moving_var, float* scale, float* shift, float* save_mean,
+                                      float* save_invstd, const unsigned* absmax, unsigned* bound, void* stream) {
+  return yolo_bn_finalize_offset(stats, P, C, gamma, beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var,
+                                 scale, shift, save_mean, save_invstd, absmax, bound, nullptr, stream);
 }
 
 extern "C" int yolo_bn_finalize(double* stats, long long P, int C, const float* gamma, const float* beta, float eps,

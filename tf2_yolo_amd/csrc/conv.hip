@@ -712,15 +712,26 @@ __global__ void filter_transpose_kernel(const float* __restrict__ w, float* __re
   }
 }
 
-// column sums of dy[P][C] into out[C] (fp32 atomics); used for conv bias gradients
-__global__ void colsum_kernel(const float* __restrict__ x, long long P, int C, float* __restrict__ out) {
+// column sums of dy[P][C] into out[C]; used for conv bias gradients. part == nullptr: fp32 atomics straight into out.
+// Otherwise (reproducible form, yolo_set_wgrad_workspace): every (block, pixel-row lane) stores its partial to
+// part[(blockIdx.x * blockDim.y + threadIdx.y) * C + c] and colsum_finish_kernel adds them in that order.
+__global__ void colsum_kernel(const float* __restrict__ x, long long P, int C, float* __restrict__ out,
+                              float* __restrict__ part) {
   // block: 256 threads = (256/cw) pixel rows x cw channel lanes, cw = min(C,256) rounded to pow2<=256
   const int c = blockIdx.y * blockDim.x + threadIdx.x;
   if (c >= C) return;
   float s = 0.f;
   for (long long p = (long long)blockIdx.x * blockDim.y + threadIdx.y; p < P; p += (long long)gridDim.x * blockDim.y)
     s += x[p * C + c];
-  atomicAdd(&out[c], s);
+  if (part != nullptr) part[((long long)blockIdx.x * blockDim.y + threadIdx.y) * C + c] = s;
+  else atomicAdd(&out[c], s);
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int i = 0; i < nparts; ++i) s += part[(long long)i * C + c];
+  out[c] += s;
 }
 
 }  // namespace yolo
@@ -1031,8 +1042,22 @@ extern "C" int yolo_conv2d_wgrad_bias(const float* dy, long long P, int Cout, fl
   long long gx = (P + block.y * 64 - 1) / (block.y * 64);
   if (gx > 1024) gx = 1024;
   if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx, gy), block, 0, as_stream(stream), dy, P, Cout, dbias);
-  return check_launch("colsum_kernel");
+  // reproducible form: partials in the first MiB of the wgrad workspace, summed in order (fewer blocks if they do not fit)
+  size_t ws_bytes = 0;
+  float* part = reinterpret_cast<float*>(wgrad_workspace(&ws_bytes));
+  if (part != nullptr) {
+    const long long cap = (long long)(WGRAD_WS_COLSUM_BYTES / 4) / ((long long)block.y * Cout);
+    if (cap < 1) part = nullptr;
+    else if (gx > cap) gx = cap;
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx, gy), block, 0, as_stream(stream), dy, P, Cout, dbias, part);
+  if (int rc = check_launch("colsum_kernel")) return rc;
+  if (part != nullptr) {
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((Cout + 63) / 64), dim3(64), 0, as_stream(stream), part,
+                       (int)(gx * block.y), Cout, dbias);
+    return check_launch("colsum_finish_kernel");
+  }
+  return YOLO_OK;
 }
 
 extern "C" int yolo_filter_transpose(const float* w, float* wT, int Cout, int taps, int Cin, void* stream) {

@@ -94,6 +94,10 @@ struct WgradArgs {
   // planes kernel (conv_wgrad_planes.hip): src / dy point to fp16 planes
   unsigned src_bytes, dy_bytes;
   int zero_blk_src, zero_blk_dy;
+  // planes kernel, reproducible form (yolo_set_wgrad_workspace): every workgroup stores its BM x BN partial to slab
+  // `split * tiles + tile` (accumulator order) and wgrad_reduce_kernel adds the splits IN ORDER into dw; nullptr = fp32 atomics
+  float* slabs;
+  int splits;
 };
 
 // conv_split.hip
@@ -125,6 +129,9 @@ void init_options();
 // conv_wgrad_planes.hip
 int launch_wgrad_planes(WgradArgs& a, hipStream_t st);
 bool wgrad_planes_supported(const WgradArgs& a);
+// workspace of the reproducible (atomics-free) filter / bias gradient reductions: [colsum partials: 1 MiB][slabs]
+constexpr size_t WGRAD_WS_COLSUM_BYTES = 1 << 20;
+void* wgrad_workspace(size_t* bytes);
 // stem.hip (direct fp32 kernel for the 3-channel 3x3 stem)
 bool stem_fwd_supported(const yolo_conv_desc* d);
 size_t stem_bwd_scratch_bytes();

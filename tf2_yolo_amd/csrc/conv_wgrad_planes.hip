@@ -245,6 +245,22 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   const float unscale =
       reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.dy) + a.dy_bytes - PL_HEADER)[2] *
       reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2];
+  if (a.slabs != nullptr) {
+    // reproducible form: the partial goes to this workgroup's slab in accumulator order -- 16-byte piece
+    // ((wave * TM + i) * TN + j) * 4 + q4 of lane l at float (piece * 64 + l) * 4 -- as plain dwordx4 stores (one
+    // instruction = 1 KiB contiguous); wgrad_reduce_kernel adds the splits of a tile in split order
+    float* mine = a.slabs + (size_t)lid * (BM * BN);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+          const f32x4 f = {acc[i][j][4 * q4], acc[i][j][4 * q4 + 1], acc[i][j][4 * q4 + 2], acc[i][j][4 * q4 + 3]};
+          *reinterpret_cast<f32x4*>(mine + ((((wave * TM + i) * TN + j) * 4 + q4) * 64 + lane) * 4) = f;
+        }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int cj = j0 + (wn * TN + j) * 32 + (lane & 31);
@@ -258,6 +274,52 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
       }
     }
   }
+}
+
+// dw[co][cj] += unscale * sum over splits (in split order) of the slabs' partials: one thread per 16-byte accumulator piece
+// (4 rows x 1 column), up to 8 split loads in flight, the 32 lanes of a half-wave write 128 contiguous bytes of a dw row.
+// No atomics anywhere: the filter gradient is bit-identical from run to run.
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradArgs a) {
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  constexpr int PER_TILE = BM * BN / 4;            // 16-byte pieces per tile
+  const int tiles = a.tiles_co * a.tiles_j;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int tile = (int)(idx / PER_TILE);
+  if (tile >= tiles) return;
+  const int q = (int)(idx - (long long)tile * PER_TILE);
+  const int lane = q & 63, piece = q >> 6;
+  const int q4 = piece & 3, j = (piece >> 2) % TN, i = (piece / (4 * TN)) % TM, wave = piece / (4 * TN * TM);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int co0 = (tile % a.tiles_co) * BM, j0 = (tile / a.tiles_co) * BN;
+  const int cj = j0 + (wn * TN + j) * 32 + (lane & 31);
+  const int co = co0 + (wm * TM + i) * 32 + 8 * q4 + 4 * (lane >> 5);
+  if (cj >= a.ntaps * a.Cs || co >= a.Cout) return;
+  const f32x4* sl = reinterpret_cast<const f32x4*>(a.slabs) + (size_t)tile * PER_TILE + q;
+  const size_t sstride = (size_t)tiles * PER_TILE;
+  f32x4 t = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= a.splits; s += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(sl + (size_t)(s + u) * sstride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t = t + v[u];
+  }
+  for (; s < a.splits; ++s) t = t + __builtin_nontemporal_load(sl + (size_t)s * sstride);
+  const float unscale =
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.dy) + a.dy_bytes - PL_HEADER)[2] *
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (co + e < a.Cout) a.dw[(long long)(co + e) * a.ldw + cj] += t[e] * unscale;
+}
+
+static void* g_wgrad_ws = nullptr;
+static size_t g_wgrad_ws_bytes = 0;
+void* wgrad_workspace(size_t* bytes) {
+  if (bytes != nullptr) *bytes = g_wgrad_ws_bytes;
+  return g_wgrad_ws;
 }
 
 template <int BM, int BN, int WGM, int WGN>
@@ -296,10 +358,21 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   if (splits > max_splits) splits = max_splits;
   if (splits > 65535) splits = 65535;
   if (splits < 1) splits = 1;
+  // reproducible form: the slabs of all workgroups must fit the registered workspace (fewer, longer splits otherwise)
+  a.slabs = nullptr;
+  static const bool det_env = [] { const char* e = getenv("YOLO_WGRAD_DETERMINISTIC"); return !(e && atoi(e) == 0); }();
+  if (det_env && g_wgrad_ws != nullptr && g_wgrad_ws_bytes > WGRAD_WS_COLSUM_BYTES) {
+    const long long cap = (long long)((g_wgrad_ws_bytes - WGRAD_WS_COLSUM_BYTES) / ((size_t)BM * BN * 4));
+    if (cap >= tiles) {
+      if (tiles * splits > cap) splits = cap / tiles;
+      a.slabs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(g_wgrad_ws) + WGRAD_WS_COLSUM_BYTES);
+    }
+  }
   long long chunk = (a.M + splits - 1) / splits;
   chunk = (chunk + 15) / 16 * 16;
   splits = (a.M + chunk - 1) / chunk;
   a.chunk = chunk;
+  a.splits = (int)splits;
   if (tiles * splits > 0x7fffffffLL || splits > 65535) {
     set_error("wgrad(planes): bad grid %lld x %lld", tiles, splits);
     return YOLO_ERR_INVALID_ARG;
@@ -314,7 +387,13 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   }
   hipLaunchKernelGGL((wgrad_planes_kernel<BM, BN, WGM, WGN>), dim3((unsigned)(tiles * splits)), dim3(64 * WGM * WGN), lds,
                      st, a);
-  return check_launch("wgrad_planes_kernel");
+  if (int rc = check_launch("wgrad_planes_kernel")) return rc;
+  if (a.slabs != nullptr) {
+    const long long pieces = tiles * (BM * BN / 4);
+    hipLaunchKernelGGL((wgrad_reduce_kernel<BM, BN, WGM, WGN>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, a);
+    return check_launch("wgrad_reduce_kernel");
+  }
+  return YOLO_OK;
 }
 
 bool wgrad_planes_supported(const WgradArgs& a) {
@@ -344,3 +423,14 @@ int launch_wgrad_planes(WgradArgs& a, hipStream_t st) {
 }
 
 }  // namespace yolo
+
+extern "C" size_t yolo_wgrad_workspace_bytes(void) {
+  // 1 MiB of bias-gradient partials + slabs for two rounds of 768 resident workgroups of 128 x 128 fp32
+  return yolo::WGRAD_WS_COLSUM_BYTES + (size_t)1536 * 128 * 128 * 4;
+}
+
+extern "C" int yolo_set_wgrad_workspace(void* p, size_t bytes) {
+  yolo::g_wgrad_ws = (p != nullptr && bytes > yolo::WGRAD_WS_COLSUM_BYTES) ? p : nullptr;
+  yolo::g_wgrad_ws_bytes = yolo::g_wgrad_ws != nullptr ? bytes : 0;
+  return YOLO_OK;
+}

@@ -298,9 +298,19 @@ __global__ void head_danchor_kernel(const float* __restrict__ y, const float* __
 }
 
 // ---- optimizers ------------------------------------------------------------------------------
+// hyper != nullptr: lr_t, beta1, beta2, eps, grad_scale come from device memory (5 floats) instead of the kernel
+// arguments -- the form a captured hipGraph replays with a new bias-corrected learning rate every step
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long long n,
-                                                   float lr_t, float b1, float b2, float eps, float gs, int zero) {
+                                                   float lr_t, float b1, float b2, float eps, float gs, int zero,
+                                                   const float* __restrict__ hyper) {
+  if (hyper != nullptr) {
+    lr_t = hyper[0];
+    b1 = hyper[1];
+    b2 = hyper[2];
+    eps = hyper[3];
+    gs = hyper[4];
+  }
   const long long n4 = n >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     f32x4 pv = reinterpret_cast<f32x4*>(p)[i];
@@ -503,7 +513,19 @@ extern "C" int yolo_adam_step(float* p, float* g, float* m, float* v, long long 
   // Keras Adam: lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t); p -= lr_t * m / (sqrt(v) + eps)
   const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step));
   hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n / 4 + 1, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, n,
-                     (float)lr_t, beta1, beta2, eps, grad_scale, zero_grad);
+                     (float)lr_t, beta1, beta2, eps, grad_scale, zero_grad, (const float*)nullptr);
+  return check_launch("adam_kernel");
+}
+
+extern "C" float yolo_adam_lr_t(float lr, float beta1, float beta2, int step) {
+  return (float)((double)lr * sqrt(1.0 - pow((double)beta2, (double)step)) / (1.0 - pow((double)beta1, (double)step)));
+}
+
+extern "C" int yolo_adam_step_dev(float* p, float* g, float* m, float* v, long long n, const float* hyper, int zero_grad,
+                                  void* stream) {
+  YOLO_REQUIRE(p && g && m && v && hyper && n > 0, "adam_step_dev: bad args");
+  hipLaunchKernelGGL(adam_kernel, dim3(stream_grid(n / 4 + 1, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, n, 0.f,
+                     0.f, 0.f, 0.f, 0.f, zero_grad, hyper);
   return check_launch("adam_kernel");
 }
 

@@ -65,20 +65,26 @@ class GradReducer:
         if not self.active:
             return
         for b in self.closes[i]:
-            lo, hi = self.buckets[b]
-            view = self.flat[lo:hi]
-            if self.on_gpu:
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream())
-                self.comm_stream.wait_event(ev)
-                for st in (self.extra_streams() if self.extra_streams is not None else ()):
-                    ev2 = torch.cuda.Event()
-                    ev2.record(st)
-                    self.comm_stream.wait_event(ev2)
-                with torch.cuda.stream(self.comm_stream):
-                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
-            else:
+            self.reduce_bucket(b, self.extra_streams() if self.extra_streams is not None else ())
+
+    def reduce_bucket(self, b, extra_streams=()):
+        """all-reduce bucket b on the communication stream, ordered after everything enqueued so far on the current
+        stream (and on `extra_streams`). The captured step (capture.py) calls this between two graph replays: the
+        replayed segment has joined the filter-gradient stream itself, so there are no extra streams."""
+        lo, hi = self.buckets[b]
+        view = self.flat[lo:hi]
+        if self.on_gpu:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            for st in extra_streams:
+                ev2 = torch.cuda.Event()
+                ev2.record(st)
+                self.comm_stream.wait_event(ev2)
+            with torch.cuda.stream(self.comm_stream):
                 self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        else:
+            self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
     def finish(self):
         """Make the compute stream wait for every outstanding bucket. Returns 1/world."""

@@ -328,6 +328,7 @@ class Network:
         self.grad_ready_hook = None   # called as hook(unit) after a unit's parameter grads are enqueued
         self._infer_scale_valid = False
         ops.ensure_conv_workspace()   # scratch of the persistent (stream-K) window kernel: small-batch launches
+        ops.ensure_wgrad_workspace()  # slabs of the atomics-free filter / bias gradient reductions
         # consumers per tensor decide whether a tensor needs a gradient at all
         self._needs_grad = self._compute_needs_grad()
         # pre-split ("planes") copies of the filters for the LDS-DMA conv kernels: [Cout][taps*Cin] for
@@ -466,6 +467,7 @@ class Network:
                                    f"4 GiB a planes operand may span; the largest batch for this model is "
                                    f"{((1 << 32) - (1 << 20)) // worst - 1} (or set YOLO_CONV_PLANES=0)")
         self.batch = N
+        self.alloc_gen = getattr(self, "alloc_gen", 0) + 1   # captured step graphs (capture.py) belong to one allocation
         self._infer_graphs = {}   # captured graphs point into the buffers re-allocated below
         self.act = {}
         dev = self.device
@@ -669,12 +671,15 @@ class Network:
                     scale, shift, smean, sinv, stats, _ = self._bn_bufs(u)
                     gamma, beta = P.view(u.p_gamma.name), P.view(u.p_beta.name)
                     if training:
-                        self._conv_fwd(u, xin, w, bias, u.y, stats)
+                        # a conv bias in front of BatchNormalization (YOLOv1.5 / v2) cancels in (y - mean): the convolution
+                        # runs WITHOUT it -- u.y, the statistics and the saved mean are those of the bias-free tensor, so a
+                        # large bias cannot eat the digits of var = E[y^2] - mean^2 -- and only the moving mean adds it back
+                        self._conv_fwd(u, xin, w, None, u.y, stats)
                         ops.bn_finalize(stats, u.y.numel() // u.cout, u.cout, gamma, beta,
                                         self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
                                         scale, shift, smean, sinv, unbiased=self.unbiased_moving_var,
                                         bound=self._aux[u.aux_off:u.aux_off + 1],
-                                        absmax=self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout])
+                                        absmax=self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout], mean_offset=bias)
                     elif self._fuse_infer and self._fused_infer_unit(u, bias, gamma, beta, scale, shift):
                         continue
                     else:
@@ -824,9 +829,10 @@ class Network:
                     # the gradient of the conv output goes straight into the planes the filter / data gradient
                     # kernels read; the fp32 copy is written only if an fp32-path kernel still needs it
                     need_pl = u.planes_wgrad or u.planes_dgrad
-                    need_f32 = ((not u.planes_wgrad) or u.p_bias is not None
-                                or (self._needs_grad[u.src.tid] and not u.planes_dgrad))
-                    if (self._stem_fused and not need_pl and not self._needs_grad[u.src.tid] and u.p_bias is None
+                    # (a conv bias in front of BatchNormalization has the exact gradient 0 -- it cancels in y - mean -- so
+                    # nothing is computed for it: its slice of `grads` stays zero and no fp32 dy is needed on its account)
+                    need_f32 = (not u.planes_wgrad) or (self._needs_grad[u.src.tid] and not u.planes_dgrad)
+                    if (self._stem_fused and not need_pl and not self._needs_grad[u.src.tid]
                             and ops.stem_bn_bwd_supported(u.desc)):
                         # the stem: BN / activation backward apply + filter gradient in one pass, no 32-channel dy tensor
                         ops.stem_bn_bwd_wgrad(u.desc, xin, u.y, dout, scale, shift, smean, sinv, u.act, red,
@@ -842,13 +848,13 @@ class Network:
                 else:
                     dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
                     dyp = self._dyp(u, dy)
+                dbias = self._gview(u.p_bias) if (u.p_bias is not None and not u.bn) else None
                 with self._beside_backward(dy):
                     if u.planes_wgrad:
                         ops.conv2d_wgrad_planes(u.desc, self._xplanes[u.src.tid], dyp, self._gview(u.p_kernel), dy=dy,
-                                                dbias=self._gview(u.p_bias) if u.p_bias is not None else None)
+                                                dbias=dbias)
                     else:
-                        ops.conv2d_wgrad(u.desc, xin, dy, self._gview(u.p_kernel),
-                                         self._gview(u.p_bias) if u.p_bias is not None else None)
+                        ops.conv2d_wgrad(u.desc, xin, dy, self._gview(u.p_kernel), dbias)
                 self._dgrad(grads, u, dy, u.cout * u.k * u.k * u.src.c, dyp)
             elif u.kind == "head":
                 xin = self.act[u.src.tid]

@@ -288,12 +288,15 @@ class Model:
         self.metrics = [list(m) for m in metrics]
         self._loss_bufs = [torch.zeros(8, device="cuda", dtype=torch.float64) for _ in range(nout)]
         self._dpred = None
+        self._drop_step_graphs()
 
     def enable_data_parallel(self, process_group=None, bucket_bytes=48 << 20):
         """Call after compile() in a torch.distributed job (one process per GPU)."""
         segs, units = dp_mod.network_segments(self.net)
         self._reducer = dp_mod.GradReducer(self.net.grads, segs, process_group, bucket_bytes)
         index = {id(u): i for i, u in enumerate(units)}
+        self._dp_unit_index = index
+        self._drop_step_graphs()
         self.net.grad_ready_hook = lambda u: self._reducer.segment_done(index[id(u)])
         net = self.net
         self._reducer.extra_streams = lambda: [net._wgrad_stream] if net._wgrad_stream is not None else []
@@ -310,11 +313,53 @@ class Model:
                 out.append(torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32))).cuda())
         return out
 
+    # ---- the step as replayed hipGraphs (capture.py) ----
+    def _drop_step_graphs(self):
+        self._step_graphs = None
+        self._eager_steps = {}
+
+    def _captured_step(self, x, y_list):
+        """Replay the captured step if there is one for this configuration; capture it after two eager steps of the same
+        configuration (allocations, lazy initialisation and filter preparation have then happened). YOLO_STEP_GRAPH=0
+        keeps every step eager. A failed capture is reported once and switches the feature off for this model."""
+        import os
+        if os.environ.get("YOLO_STEP_GRAPH", "1") == "0" or getattr(self, "_graphs_failed", False):
+            return None
+        if not getattr(self.optimizer, "capturable", False):
+            return None
+        if self.net.grad_ready_hook is not None and self._reducer is None:
+            return None          # a foreign gradient hook: its host side would not run during replays
+        from .capture import StepGraphs
+        key = StepGraphs.key_of(self, x)
+        g = self._step_graphs
+        if g is not None and g.key == key:
+            return g.replay(x, y_list)
+        n = self._eager_steps.get(key, 0)
+        if n < 2 or self._dpred is None:
+            self._eager_steps = {key: n + 1}
+            self._step_graphs = None
+            return None
+        try:
+            self._step_graphs = StepGraphs(self, x, y_list)
+        except Exception as e:   # e.g. a runtime that cannot capture some call: stay eager, say so once
+            import sys
+            print(f"[tf2_yolo_amd] step capture failed ({e!r}); training continues with eager launches", file=sys.stderr)
+            self._graphs_failed = True
+            self._step_graphs = None
+            return None
+        return self._step_graphs.replay(x, y_list)
+
     def train_step_device(self, x, y_list, with_metrics=False):
         """One optimizer step on device-resident float32 tensors. Returns the per-output loss
-        buffers (device float64[8], element 0 = loss) without synchronising."""
+        buffers (device float64[8], element 0 = loss) without synchronising. From the third step of a configuration on
+        the step is a replay of captured hipGraphs (capture.py) unless metrics are asked for or an ops.TIMER is active."""
         if self.optimizer is None:
             raise YoloHipError("compile() the model before training")
+        from . import ops as _ops
+        if not with_metrics and _ops.TIMER is None:
+            bufs = self._captured_step(x, y_list)
+            if bufs is not None:
+                return bufs, None
         outs = self.net.forward(x, training=True)
         if self._dpred is None or self._dpred[0].shape != outs[0].shape:
             self._dpred = [torch.empty_like(o) for o in outs]

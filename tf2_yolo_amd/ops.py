@@ -27,18 +27,19 @@ class KernelTimer:
     def __init__(self):
         self.pending = []
 
-    def bracket(self, name, flops, launches, fn):
+    def bracket(self, name, flops, launches, fn, layer=None):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         fn()
         e.record()
-        self.pending.append((name, flops, launches, s, e))
+        self.pending.append((name, flops, launches, s, e, layer))
 
-    def summary(self):
+    def summary(self, by_layer=False):
+        """per kernel variant (default) or per (kernel variant, layer) -- layer = (pass, H, W, Cin, Cout, k, stride, N)"""
         torch.cuda.synchronize()
         agg = {}
-        for name, flops, launches, s, e in self.pending:
-            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+        for name, flops, launches, s, e, layer in self.pending:
+            a = agg.setdefault((name, layer) if by_layer else name, {"launches": 0, "ms": 0.0, "flops": 0.0})
             a["launches"] += launches
             a["ms"] += s.elapsed_time(e)
             a["flops"] += flops
@@ -51,6 +52,10 @@ TIMER = None
 
 def _conv_flops(d):
     return 2.0 * d.N * d.Ho * d.Wo * d.Cout * d.kh * d.kw * d.Cin
+
+
+def _layer_key(d, which):
+    return (which, d.H, d.W, d.Cin, d.Cout, d.kh, d.sh, d.N)
 
 
 import os as _os
@@ -153,6 +158,22 @@ def ensure_conv_workspace():
         _CONV_WS = torch.empty(n, dtype=torch.uint8, device="cuda")
         check(lib.yolo_set_conv_workspace(_p(_CONV_WS), n, _stream()), "yolo_set_conv_workspace")
     return _CONV_WS
+
+
+_WGRAD_WS = None
+
+
+def ensure_wgrad_workspace():
+    """scratch of the reproducible (atomics-free) filter / bias gradient reductions (csrc/conv_wgrad_planes.hip): allocated
+    once per process, registered with the library. Launches that use it must be ordered on one stream (the executor runs
+    every filter gradient on its second stream, or all of them on the main stream)."""
+    global _WGRAD_WS
+    if _WGRAD_WS is None:
+        lib = _lib.load()
+        n = int(lib.yolo_wgrad_workspace_bytes())
+        _WGRAD_WS = torch.empty(n, dtype=torch.uint8, device="cuda")
+        check(lib.yolo_set_wgrad_workspace(_p(_WGRAD_WS), n), "yolo_set_wgrad_workspace")
+    return _WGRAD_WS
 
 
 def set_option(key, value):
@@ -313,7 +334,8 @@ def conv2d_fwd_planes(d, xp, wp, bias=None, out=None, stats=None, absmax=None):
         check(_lib.load().yolo_conv2d_fwd_planes(byref(d), _p(xp), _p(wp), _p(bias), _p(out), _p(stats), _p(absmax),
                                                  _stream()), "yolo_conv2d_fwd_planes")
     if TIMER is not None:
-        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin), d.kh * d.kw == 1), _conv_flops(d), 1, run)
+        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin), d.kh * d.kw == 1), _conv_flops(d), 1, run,
+                      _layer_key(d, "fwd"))
     else:
         run()
     return out
@@ -337,7 +359,8 @@ def conv2d_fwd_planes_epi(d, xp, wp, bias, epilogue, scale, shift, residual=None
                                                      _p(residual), _p(out), _p(absmax), _stream()),
               "yolo_conv2d_fwd_planes_epi")
     if TIMER is not None:
-        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin), d.kh * d.kw == 1), _conv_flops(d), 1, run)
+        TIMER.bracket(_planes_variant(d.Cout, _win_key(d, d.H, d.W, d.Cin), d.kh * d.kw == 1), _conv_flops(d), 1, run,
+                      _layer_key(d, "fwd"))
     else:
         run()
     return out
@@ -364,7 +387,8 @@ def conv2d_dgrad_planes(d, dyp, wTp, dx=None, accumulate=False):
         check(_lib.load().yolo_conv2d_dgrad_planes(byref(d), _p(dyp), _p(wTp), _p(dx), int(bool(accumulate)), _stream()),
               "yolo_conv2d_dgrad_planes")
     if TIMER is not None:
-        TIMER.bracket(_planes_variant(d.Cin, _win_key(d, d.Ho, d.Wo, d.Cout), d.kh * d.kw == 1 and d.sh * d.sw == 1), _conv_flops(d), 1, run)
+        TIMER.bracket(_planes_variant(d.Cin, _win_key(d, d.Ho, d.Wo, d.Cout), d.kh * d.kw == 1 and d.sh * d.sw == 1), _conv_flops(d), 1, run,
+                      _layer_key(d, "dgrad"))
     else:
         run()
     return dx
@@ -381,7 +405,7 @@ def conv2d_wgrad_planes(d, xp, dyp, dw, dy=None, dbias=None):
         check(_lib.load().yolo_conv2d_wgrad_planes(byref(d), _p(xp), _p(dyp), _p(dw), _stream()),
               "yolo_conv2d_wgrad_planes")
     if TIMER is not None:
-        TIMER.bracket(_wgrad_planes_variant(d.Cout, d.kh * d.kw * d.Cin), _conv_flops(d), 1, run)
+        TIMER.bracket(_wgrad_planes_variant(d.Cout, d.kh * d.kw * d.Cin), _conv_flops(d), 1, run, _layer_key(d, "wgrad"))
     else:
         run()
     if dbias is not None:
@@ -455,13 +479,15 @@ def bn_stats(x, C, stats):
 
 
 def bn_finalize(stats, P, C, gamma, beta, moving_mean, moving_var, scale, shift, save_mean, save_invstd,
-                eps=BN_EPS, momentum=BN_MOMENTUM, unbiased=False, bound=None, absmax=None):
+                eps=BN_EPS, momentum=BN_MOMENTUM, unbiased=False, bound=None, absmax=None, mean_offset=None):
     """bound: optional int32 CUDA tensor (1 word, zeroed) that receives the bit pattern of an upper bound of
     max|act(BN(x))| (needed by bn_act_fwd(planes=...)); absmax: optional int32 [C] per-channel max|x| bit patterns
-    from the conv epilogue (makes the bound tight)"""
-    check(_lib.load().yolo_bn_finalize_bound(_p(stats), P, C, _p(gamma), _p(beta), eps, momentum, int(unbiased),
-                                             _p(moving_mean), _p(moving_var), _p(scale), _p(shift), _p(save_mean),
-                                             _p(save_invstd), _p(absmax), _p(bound), _stream()), "yolo_bn_finalize")
+    from the conv epilogue (makes the bound tight); mean_offset: optional [C] conv bias that was left out of the
+    convolution (it cancels in training-mode BN; only the moving mean adds it back)"""
+    check(_lib.load().yolo_bn_finalize_offset(_p(stats), P, C, _p(gamma), _p(beta), eps, momentum, int(unbiased),
+                                              _p(moving_mean), _p(moving_var), _p(scale), _p(shift), _p(save_mean),
+                                              _p(save_invstd), _p(absmax), _p(bound), _p(mean_offset), _stream()),
+          "yolo_bn_finalize")
 
 
 def bn_infer_bound(C, scale, shift, absmax, bound):
@@ -740,6 +766,16 @@ def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale
                                      float(grad_scale), int(bool(zero_grad)), _stream()), "yolo_adam_step")
 
 
+def adam_lr_t(lr, step, beta1=0.9, beta2=0.999):
+    return float(_lib.load().yolo_adam_lr_t(float(lr), float(beta1), float(beta2), int(step)))
+
+
+def adam_step_dev(p, g, m, v, hyper, zero_grad=True):
+    """Adam with {lr_t, beta1, beta2, eps, grad_scale} read from the device tensor `hyper` (float32[5]): the capturable form"""
+    check(_lib.load().yolo_adam_step_dev(_p(p), _p(g), _p(m), _p(v), p.numel(), _p(hyper), int(zero_grad), _stream()),
+          "yolo_adam_step_dev")
+
+
 def sgd_step(p, g, lr, grad_scale=1.0, zero_grad=True):
     check(_lib.load().yolo_sgd_step(_p(p), _p(g), p.numel(), lr, float(grad_scale), int(bool(zero_grad)), _stream()),
           "yolo_sgd_step")
@@ -859,3 +895,30 @@ def cal_iou(xywh_true, xywh_pred, mode=1, grid_wh=(1.0, 1.0)):
                                    arr(*strides(xywh_true, lead_a)), arr(*strides(xywh_pred, lead_b)),
                                    float(grid_wh[0]), float(grid_wh[1]), _stream()), "yolo_cal_iou")
     return (out, out2) if mode == 3 else out
+
+
+# ---- roofline yardstick (csrc/probe.hip) --------------------------------------------------------------------
+def mfma_ceiling(seconds=0.15, workgroups=512):
+    """Raw fp16 MFMA TFLOP/s this chip sustains on random register operands with nothing else in the loop
+    (yolo_mfma_probe, timed with events on the current stream): the held-clock ceiling of bench.py's roofline block.
+    Runs a short calibration launch, then ONE launch sized for about `seconds`."""
+    import ctypes
+    lib = _lib.load()
+    n = workgroups * 512
+    g = torch.Generator(device="cuda").manual_seed(1)
+    ops_ = (torch.rand(n * 32, device="cuda", generator=g) * 2 - 1).to(torch.float16)
+    sink = torch.empty(n, device="cuda", dtype=torch.float32)
+    fl = ctypes.c_double(0.0)
+
+    def run(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        check(lib.yolo_mfma_probe(_p(ops_), _p(sink), workgroups, iters, ctypes.byref(fl), _stream()), "yolo_mfma_probe")
+        e.record()
+        e.synchronize()
+        return s.elapsed_time(e) * 1e-3, fl.value
+    run(200)
+    t, f = run(2000)
+    iters = max(2000, int(2000 * seconds / max(t, 1e-6)))
+    t, f = run(iters)
+    return {"raw_fp16_mfma_tflops": round(f / t / 1e12, 1), "seconds": round(t, 4), "workgroups": workgroups, "iters": iters}

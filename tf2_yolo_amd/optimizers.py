@@ -40,6 +40,32 @@ class Adam(Optimizer):
         self.net.mark_params_changed()
 
 
+    # ---- the form a captured hipGraph replays (capture.py): the five scalars live in device memory ----
+    capturable = True
+
+    def _hyper_buffers(self):
+        if getattr(self, "_hyper_dev", None) is None:
+            self._hyper_host = torch.zeros(5, dtype=torch.float32).pin_memory()
+            self._hyper_dev = torch.zeros(5, dtype=torch.float32, device="cuda")
+        return self._hyper_host, self._hyper_dev
+
+    def refresh_hyper(self, grad_scale=1.0):
+        """host side of one captured step: advance the step counter, upload {lr_t, beta1, beta2, eps, grad_scale}
+        (lr_t computed exactly as yolo_adam_step computes it) on the current stream, ahead of the replay that reads it"""
+        self.iterations += 1
+        host, dev = self._hyper_buffers()
+        host[0] = ops.adam_lr_t(self.learning_rate, self.iterations, self.beta_1, self.beta_2)
+        host[1], host[2], host[3], host[4] = self.beta_1, self.beta_2, self.epsilon, float(grad_scale)
+        dev.copy_(host, non_blocking=True)
+
+    def step_captured(self):
+        """enqueue (inside a stream capture) the update with the scalars read from the device"""
+        _, dev = self._hyper_buffers()
+        ops.adam_step_dev(self.net.params.data, self.net.grads, self.m, self.v, dev, zero_grad=True)
+        if self.net.anchors_trainable and self.net.has_anchors:
+            ops.adam_step_dev(self.net.anchors_flat, self.net.anchor_grads, self.am, self.av, dev, zero_grad=True)
+
+
 class SGD(Optimizer):
     def __init__(self, learning_rate=0.01, lr=None, **_):
         self.learning_rate = float(lr if lr is not None else learning_rate)
