@@ -25,6 +25,9 @@ import torch
 from ._lib import YoloHipError
 
 
+_LEAKED = []   # graph objects of failed captures (see StepGraphs._capture)
+
+
 class StepGraphs:
     """Captured training step of one Model for one (batch size, loss list, optimizer, reducer) configuration."""
 
@@ -64,6 +67,11 @@ class StepGraphs:
             self.segments.append((state["g"], action))
             state["g"] = None
 
+        # events recorded by the eager steps before (the dy-planes double buffer's) belong to uncaptured work: a captured
+        # stream must not wait for them, and need not -- `stream` is ordered after everything enqueued so far, and the
+        # second stream was joined at the end of the last backward
+        net._dyp_events = [None, None]
+        net._wp_event = net._wT_event = None
         old_hook = net.grad_ready_hook
         if red is not None:
             index = model._dp_unit_index
@@ -91,11 +99,21 @@ class StepGraphs:
                 opt.step_captured()
                 end(None)
         except Exception:
+            # end the broken capture as far as the runtime lets us and keep every graph object of this attempt alive for
+            # the life of the process: destroying a graph whose capture was invalidated aborts inside the runtime
+            _LEAKED.extend(g for g, _ in self.segments)
             if state["g"] is not None:
+                _LEAKED.append(state["g"])
                 try:
+                    if net._wgrad_stream is not None:
+                        torch.cuda.current_stream().wait_stream(net._wgrad_stream)
                     state["g"].capture_end()
                 except Exception:
                     pass
+            self.segments = []
+            net._dyp_events = [None, None]
+            net._wp_event = net._wT_event = None
+            net._wgrad_pending = False
             raise
         finally:
             net.grad_ready_hook = old_hook
