@@ -443,6 +443,12 @@ size_t yolo_nms_workspace_bytes(int n, int class_num);
 int yolo_nms(const double* rows, int n, int class_num, int mode, double nms_threshold,
              double conf_threshold, double sigma, unsigned char* keep_out,
              void* workspace, size_t workspace_bytes, void* stream);
+/* yolo_nms followed by the gather the reference does on the host (utils/tools.py:730-732): rows_out [<= n][7] receives the
+ * kept rows, classes ascending and in their original order inside a class, *count_out (device int) their number; rows whose
+ * class id is outside [0, class_num) are dropped, as the reference's per-class loop drops them. keep_out as yolo_nms. */
+int yolo_nms_select(const double* rows, int n, int class_num, int mode, double nms_threshold, double conf_threshold,
+                    double sigma, unsigned char* keep_out, double* rows_out, int* count_out, void* workspace,
+                    size_t workspace_bytes, void* stream);
 
 /* cal_iou as a stand-alone broadcasting kernel -- the reference's two public functions of that name:
  *   utils/tools.py:630-684       cal_iou(xywh_true, xywh_pred, mode): NumPy float64/float32, mode 1 IoU, 2 DIoU

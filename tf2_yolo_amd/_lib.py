@@ -118,6 +118,7 @@ SIGNATURES = {
     "yolo_pr_curve_workspace_bytes": (c_size_t, [c_int, c_int]),
     "yolo_pr_curve": (c_int, [_P, _P, _P, c_int, c_int, c_int, _P, c_size_t, _P, _P, _P]),
     "yolo_nms": (c_int, [_P, c_int, c_int, c_int, c_double, c_double, c_double, _P, _P, c_size_t, _P]),
+    "yolo_nms_select": (c_int, [_P, c_int, c_int, c_int, c_double, c_double, c_double, _P, _P, _P, _P, c_size_t, _P]),
 }
 
 _lib = None

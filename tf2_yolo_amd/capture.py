@@ -42,6 +42,8 @@ class StepGraphs:
         self.x = x.clone()
         self.ys = [y.clone() for y in y_list]
         self.segments = []          # (graph, action): action = ("reduce", bucket) | ("finish",) | None
+        opt._hyper_buffers()        # (pinned host + device scalars: allocated here, never inside a capture)
+        torch.cuda.synchronize()
         self._capture(net, opt)
 
     @staticmethod

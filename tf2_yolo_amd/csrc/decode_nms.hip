@@ -162,6 +162,9 @@ struct NmsWs {
   int* class_cnt;    // [class_num + 1]
   int* class_off;    // [class_num + 1]
   unsigned char* removed;  // [n] by sorted position
+  int* fill;         // [class_num + 1] rows placed so far per class (bucket kernel)
+  int* bidx;         // [n] rows grouped by class (any order inside a class)
+  double* bscore;    // [n] their scores
 };
 
 static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -184,6 +187,9 @@ static size_t nms_carve(int n, int class_num, void* base, NmsWs* ws) {
   w.class_cnt = (int*)take(sizeof(int) * (class_num + 1));
   w.class_off = (int*)take(sizeof(int) * (class_num + 1));
   w.removed = (unsigned char*)take(n);
+  w.fill = (int*)take(sizeof(int) * (class_num + 1));
+  w.bidx = (int*)take(sizeof(int) * n);
+  w.bscore = (double*)take(sizeof(double) * n);
   if (ws) *ws = w;
   return off;
 }
@@ -213,43 +219,49 @@ __global__ void nms_class_scan_kernel(int class_num, NmsWs ws) {
   }
 }
 
-__global__ __launch_bounds__(256) void nms_rank_kernel(const double* __restrict__ rows, int n, NmsWs ws) {
-  __shared__ double s_score[256];
-  __shared__ int s_cls[256];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool valid = i < n;
-  const int ci = valid ? ws.cls[i] : -2;
-  const double si = valid ? ws.score[i] : 0.0;
+// rows grouped by class: slot = class_off[c] + (arrival order inside the class). The order inside a class is whatever the
+// atomics give -- the rank below does not depend on it.
+__global__ void nms_bucket_kernel(int n, NmsWs ws) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int c = ws.cls[i];
+  if (c < 0) return;
+  const int slot = ws.class_off[c] + atomicAdd(&ws.fill[c], 1);
+  ws.bidx[slot] = i;
+  ws.bscore[slot] = ws.score[i];
+}
+
+// rank of every row inside its class by (score descending, ties: higher original index first -- np.argsort leaves ties
+// undefined, utils/tools.py:717) = the number of rows of the class that come before it: one thread per bucket slot,
+// walking ITS CLASS's slots only (sum n_c^2 comparisons instead of n^2: 80 classes of 1641 rows = 2.2e8 instead of
+// 1.7e10); the threads of a wave share a class almost always, so the loads are broadcasts
+__global__ __launch_bounds__(256) void nms_rank_kernel(const double* __restrict__ rows, int n, int class_num, NmsWs ws) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= ws.class_off[class_num]) return;
+  const int i = ws.bidx[e];
+  const double si = ws.bscore[e];
+  const int ci = ws.cls[i];
+  const int beg = ws.class_off[ci], end = ws.class_off[ci + 1];
   int rank = 0;
-  for (int base = 0; base < n; base += 256) {
-    const int j = base + threadIdx.x;
-    s_score[threadIdx.x] = (j < n) ? ws.score[j] : 0.0;
-    s_cls[threadIdx.x] = (j < n) ? ws.cls[j] : -3;
-    __syncthreads();
-    const int lim = (n - base < 256) ? (n - base) : 256;
-    for (int t = 0; t < lim; ++t) {
-      const int j2 = base + t;
-      const double sj = s_score[t];
-      const bool before = (sj > si) || (sj == si && j2 > i);
-      rank += (s_cls[t] == ci && before) ? 1 : 0;
-    }
-    __syncthreads();
+  for (int j = beg; j < end; ++j) {
+    const double sj = ws.bscore[j];
+    const int jj = ws.bidx[j];
+    rank += ((sj > si) || (sj == si && jj > i)) ? 1 : 0;
   }
-  if (valid && ci >= 0) {
-    const int pos = ws.class_off[ci] + rank;
-    ws.sorted_idx[pos] = i;
-    ws.pos_of[i] = pos;
-    const double* r = rows + (long long)i * 7;
-    ws.box[(long long)pos * 4 + 0] = r[0];
-    ws.box[(long long)pos * 4 + 1] = r[1];
-    ws.box[(long long)pos * 4 + 2] = r[2];
-    ws.box[(long long)pos * 4 + 3] = r[3];
-    ws.sscore[pos] = si;
-  }
+  const int pos = beg + rank;
+  ws.sorted_idx[pos] = i;
+  ws.pos_of[i] = pos;
+  const double* r = rows + (long long)i * 7;
+  ws.box[(long long)pos * 4 + 0] = r[0];
+  ws.box[(long long)pos * 4 + 1] = r[1];
+  ws.box[(long long)pos * 4 + 2] = r[2];
+  ws.box[(long long)pos * 4 + 3] = r[3];
+  ws.sscore[pos] = si;
 }
 
 // utils/tools.py:630-684 in fp64; a = "true" (visited box), b = "pred"
 __device__ __forceinline__ double pair_score(const double* a, const double* b, bool diou) {
+#pragma clang fp contract(off)   // NumPy rounds every product: no fused multiply-adds in the threshold comparisons
   const double ahx = a[2] / 2., ahy = a[3] / 2., bhx = b[2] / 2., bhy = b[3] / 2.;
   const double aminx = a[0] - ahx, amaxx = a[0] + ahx, aminy = a[1] - ahy, amaxy = a[1] + ahy;
   const double bminx = b[0] - bhx, bmaxx = b[0] + bhx, bminy = b[1] - bhy, bmaxy = b[1] + bhy;
@@ -268,10 +280,35 @@ __device__ __forceinline__ double pair_score(const double* a, const double* b, b
   return iou - rho2 / c2;
 }
 
-// one workgroup per class: greedy walk over the sorted segment
+// one workgroup per class: greedy walk over the sorted segment. Classes of up to NMS_LDS_BOXES rows keep their boxes and
+// "removed" flags in LDS (every step of the walk is then one barrier and a few LDS reads, ~0.1 us, instead of a round
+// trip to memory: 1641 steps per class on BASELINE.md's 131 304-row input); larger classes use the global arrays.
+constexpr int NMS_LDS_BOXES = 4096;
 __global__ __launch_bounds__(1024) void nms_hard_kernel(NmsWs ws, double thr, int diou) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char nms_smem[];
   const int c = blockIdx.x;
   const int beg = ws.class_off[c], end = ws.class_off[c + 1];
+  const int nc = end - beg;
+  if (nc <= NMS_LDS_BOXES) {
+    double* sbox = reinterpret_cast<double*>(nms_smem);                    // [nc][4]
+    unsigned char* srem = nms_smem + (size_t)NMS_LDS_BOXES * 32;            // [nc]
+    for (int t = threadIdx.x; t < nc * 4; t += 1024) sbox[t] = ws.box[(long long)beg * 4 + t];
+    for (int t = threadIdx.x; t < nc; t += 1024) srem[t] = 0;
+    __syncthreads();
+    for (int p = 0; p < nc; ++p) {
+      if (!srem[p]) {    // (last written before the barrier that ended the previous iteration)
+        const double a[4] = {sbox[p * 4], sbox[p * 4 + 1], sbox[p * 4 + 2], sbox[p * 4 + 3]};
+        for (int q = p + 1 + threadIdx.x; q < nc; q += 1024) {
+          if (srem[q]) continue;
+          const double b[4] = {sbox[q * 4], sbox[q * 4 + 1], sbox[q * 4 + 2], sbox[q * 4 + 3]};
+          if (pair_score(a, b, diou != 0) >= thr) srem[q] = 1;
+        }
+      }
+      __syncthreads();
+    }
+    for (int t = threadIdx.x; t < nc; t += 1024) ws.removed[beg + t] = srem[t];
+    return;
+  }
   for (int p = beg; p < end; ++p) {
     // removed[p] was last written before the barrier that ended the previous iteration
     if (!ws.removed[p]) {
@@ -317,6 +354,43 @@ __global__ void nms_finish_kernel(int n, NmsWs ws, unsigned char* __restrict__ k
   if (i >= n) return;
   const int pos = ws.pos_of[i];
   keep[i] = (pos >= 0 && !ws.removed[pos]) ? 1 : 0;
+}
+
+// ---- kept rows in the reference's output order: classes ascending, original order inside a class (utils/tools.py:730-732) ----
+__global__ void nms_kept_count_kernel(int n, NmsWs ws, const unsigned char* __restrict__ keep) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || !keep[i]) return;
+  atomicAdd(&ws.fill[ws.cls[i]], 1);     // (fill was zeroed again after the bucket kernel used it)
+}
+__global__ void nms_kept_scan_kernel(int class_num, NmsWs ws, int* __restrict__ count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int acc = 0;
+    for (int c = 0; c < class_num; ++c) {
+      const int k = ws.fill[c];
+      ws.class_cnt[c] = acc;             // (class_cnt is free by now: first output position of the class)
+      acc += k;
+    }
+    *count = acc;
+  }
+}
+// one thread per bucket slot: a kept row's place inside its class = the kept rows of the class with a smaller index
+__global__ __launch_bounds__(256) void nms_gather_kernel(const double* __restrict__ rows, int class_num, NmsWs ws,
+                                                         const unsigned char* __restrict__ keep, double* __restrict__ out) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= ws.class_off[class_num]) return;
+  const int i = ws.bidx[e];
+  if (!keep[i]) return;
+  const int c = ws.cls[i];
+  const int beg = ws.class_off[c], end = ws.class_off[c + 1];
+  int r = 0;
+  for (int j = beg; j < end; ++j) {
+    const int jj = ws.bidx[j];
+    r += (jj < i && keep[jj]) ? 1 : 0;
+  }
+  const double* src = rows + (long long)i * 7;
+  double* dst = out + (long long)(ws.class_cnt[c] + r) * 7;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) dst[k] = src[k];
 }
 
 }  // namespace yolo
@@ -387,16 +461,53 @@ extern "C" int yolo_nms(const double* rows, int n, int class_num, int mode, doub
     set_error("nms: memset failed");
     return YOLO_ERR_LAUNCH;
   }
+  if (hipMemsetAsync(ws.fill, 0, sizeof(int) * (class_num + 1), st) != hipSuccess) {
+    set_error("nms: memset failed");
+    return YOLO_ERR_LAUNCH;
+  }
   const int nb = (n + 255) / 256;
   hipLaunchKernelGGL(nms_prepare_kernel, dim3(nb), dim3(256), 0, st, rows, n, class_num, ws);
   hipLaunchKernelGGL(nms_class_scan_kernel, dim3(1), dim3(64), 0, st, class_num, ws);
-  hipLaunchKernelGGL(nms_rank_kernel, dim3(nb), dim3(256), 0, st, rows, n, ws);
+  hipLaunchKernelGGL(nms_bucket_kernel, dim3(nb), dim3(256), 0, st, n, ws);
+  hipLaunchKernelGGL(nms_rank_kernel, dim3(nb), dim3(256), 0, st, rows, n, class_num, ws);
   if (mode == YOLO_NMS_SOFT) {
     hipLaunchKernelGGL(nms_soft_kernel, dim3(nb), dim3(256), 0, st, n, class_num, ws, nms_threshold, conf_threshold, sigma);
   } else {
-    hipLaunchKernelGGL(nms_hard_kernel, dim3(class_num), dim3(1024), 0, st, ws, nms_threshold,
+    constexpr size_t lds = (size_t)NMS_LDS_BOXES * 33;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_hard_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(nms_hard_kernel, dim3(class_num), dim3(1024), lds, st, ws, nms_threshold,
                        mode == YOLO_NMS_DIOU ? 1 : 0);
   }
   hipLaunchKernelGGL(nms_finish_kernel, dim3(nb), dim3(256), 0, st, n, ws, keep_out);
   return check_launch("nms kernels");
+}
+
+extern "C" int yolo_nms_select(const double* rows, int n, int class_num, int mode, double nms_threshold,
+                               double conf_threshold, double sigma, unsigned char* keep_out, double* rows_out,
+                               int* count_out, void* workspace, size_t workspace_bytes, void* stream) {
+  YOLO_REQUIRE(count_out != nullptr, "nms_select: null pointer");
+  hipStream_t st = as_stream(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(count_out, 0, sizeof(int), st) != hipSuccess) return YOLO_ERR_LAUNCH;
+    return YOLO_OK;
+  }
+  YOLO_REQUIRE(rows_out != nullptr, "nms_select: null pointer");
+  if (int rc = yolo_nms(rows, n, class_num, mode, nms_threshold, conf_threshold, sigma, keep_out, workspace, workspace_bytes,
+                        stream))
+    return rc;
+  NmsWs ws;
+  nms_carve(n, class_num, workspace, &ws);
+  if (hipMemsetAsync(ws.fill, 0, sizeof(int) * (class_num + 1), st) != hipSuccess) {
+    set_error("nms_select: memset failed");
+    return YOLO_ERR_LAUNCH;
+  }
+  const int nb = (n + 255) / 256;
+  hipLaunchKernelGGL(nms_kept_count_kernel, dim3(nb), dim3(256), 0, st, n, ws, keep_out);
+  hipLaunchKernelGGL(nms_kept_scan_kernel, dim3(1), dim3(64), 0, st, class_num, ws, count_out);
+  hipLaunchKernelGGL(nms_gather_kernel, dim3(nb), dim3(256), 0, st, rows, class_num, ws, keep_out, rows_out);
+  return check_launch("nms gather kernels");
 }

@@ -651,9 +651,9 @@ class Network:
                 self._wT_event.record(side)
         else:
             self._refresh_wplanes()
-        self._aux.zero_()   # bounds / per-channel maxima of this pass
+        ops.zero_bytes(self._aux)   # bounds / per-channel maxima of this pass
         if training:
-            self._bn_f64[:self._bn_stats_total].zero_()
+            ops.zero_bytes(self._bn_f64[:self._bn_stats_total])
             self._infer_scale_valid = False  # moving statistics (and the shared scale/shift) change
             # captured inference graphs were recorded with the folded scale/shift valid (no bn_fold_inference
             # inside): a training-mode forward overwrites those buffers with batch statistics, so drop them
@@ -864,9 +864,9 @@ class Network:
                     rows = N * u.out.h * u.out.w
                     dtp = ops.split_planes_padded(dt, rows, u.out.c, out=self._next_dyp_buffer())
                     with self._beside_backward(dt):
-                        u.dw_pad.zero_()
+                        ops.zero_bytes(u.dw_pad)
                         ops.conv2d_wgrad_planes(u.desc_pad, self._xplanes[u.src.tid], dtp, u.dw_pad)
-                        self._gview(u.p_kernel).add_(u.dw_pad[:u.out.c * u.src.c])
+                        ops.axpy(self._gview(u.p_kernel), u.dw_pad[:u.out.c * u.src.c])
                         ops.conv2d_wgrad_bias(dt, rows, u.out.c, self._gview(u.p_bias))
                     if self._needs_grad[u.src.tid]:
                         wTp = self._wplanes[u.wTp_pad_off:u.wTp_pad_off + u.wTp_pad_bytes]
@@ -911,7 +911,8 @@ class Network:
                 if self._needs_grad[u.src.tid]:
                     cur = grads.get(u.src.tid)
                     if cur is None:
-                        cur = torch.zeros((N, u.src.h, u.src.w, u.src.c), device=self.device, dtype=torch.float32)
+                        cur = torch.empty((N, u.src.h, u.src.w, u.src.c), device=self.device, dtype=torch.float32)
+                        ops.zero_bytes(cur)
                         grads[u.src.tid] = cur
                     ops.maxpool_bwd(dout, N, u.out.h, u.out.w, u.out.c, u.out.c, 0, u.argmax, cur)
             elif u.kind == "space_to_depth":

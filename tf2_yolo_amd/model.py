@@ -343,7 +343,9 @@ class Model:
             self._step_graphs = StepGraphs(self, x, y_list)
         except Exception as e:   # e.g. a runtime that cannot capture some call: stay eager, say so once
             import sys
-            print(f"[tf2_yolo_amd] step capture failed ({e!r}); training continues with eager launches", file=sys.stderr)
+            import traceback
+            print(f"[tf2_yolo_amd] step capture failed ({e!r}); training continues with eager launches\n"
+                  + "".join(traceback.format_exc().splitlines(True)[-12:]), file=sys.stderr)
             self._graphs_failed = True
             self._step_graphs = None
             return None

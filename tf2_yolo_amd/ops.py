@@ -638,6 +638,16 @@ def fill(t, value):
     check(_lib.load().yolo_fill(_p(t), t.numel(), float(value), _stream()), "yolo_fill")
 
 
+def zero_bytes(t):
+    """all-zero bit pattern over a contiguous tensor of any 4- or 8-byte dtype (the library's own fill kernel: no torch
+    operator runs on the product path)"""
+    n = t.numel() * t.element_size()
+    if n % 4:
+        raise YoloHipError("zero_bytes: size must be a multiple of 4 bytes")
+    if n:
+        check(_lib.load().yolo_fill(_p(t), n // 4, 0.0, _stream()), "yolo_fill")
+
+
 def maxpool_fwd(x, k, s, pad_t, pad_l, Ho, Wo, y, Cy, c_off, argmax):
     n, h, w, c = x.shape
     if y.numel() != n * Ho * Wo * Cy or (argmax is not None and argmax.numel() != n * Ho * Wo * c):
@@ -812,6 +822,23 @@ def nms_keep(rows, class_num, mode, nms_threshold, conf_threshold=0.5, sigma=0.5
     check(lib.yolo_nms(_p(rows), n, class_num, mode, float(nms_threshold), float(conf_threshold), float(sigma),
                        _p(keep), _p(ws), nbytes, _stream()), "yolo_nms")
     return keep
+
+
+def nms_select(rows, class_num, mode, nms_threshold, conf_threshold=0.5, sigma=0.5):
+    """rows: float64 CUDA tensor [n,7]; returns the kept rows in the reference's output order (classes ascending, original
+    order inside a class) as a float64 CUDA tensor [m,7] -- NMS and the ordered gather in one call, one host sync (m)."""
+    n = rows.shape[0]
+    if n == 0:
+        return rows.reshape(0, 7)
+    lib = _lib.load()
+    nbytes = int(lib.yolo_nms_workspace_bytes(n, class_num))
+    ws = torch.empty(nbytes, device=rows.device, dtype=torch.uint8)
+    keep = torch.empty(n, device=rows.device, dtype=torch.uint8)
+    out = torch.empty((n, 7), device=rows.device, dtype=torch.float64)
+    count = torch.empty(1, device=rows.device, dtype=torch.int32)
+    check(lib.yolo_nms_select(_p(rows), n, class_num, mode, float(nms_threshold), float(conf_threshold), float(sigma),
+                              _p(keep), _p(out), _p(count), _p(ws), nbytes, _stream()), "yolo_nms_select")
+    return out[:int(count.item())]
 
 
 # ---- evaluation after decode / NMS (csrc/measure.hip) ---------------------------------------------------

@@ -98,12 +98,9 @@ def _nms_impl(xywhcp, class_num, mode, nms_threshold, conf_threshold=0.5, sigma=
         rows = rows.double()
     if rows.numel() == 0:
         rows = rows.reshape(0, 7)
-    keep = ops.nms_keep(rows, class_num, mode, nms_threshold, conf_threshold, sigma).bool()
-    # reference output order: classes ascending, original order inside a class (utils/tools.py:730-732)
-    idx = torch.nonzero(keep).reshape(-1)
-    cls = rows[idx, 5].to(torch.int64)
-    order = torch.argsort(cls, stable=True)
-    out = rows[idx[order]]
+    # NMS + the reference's output order (classes ascending, original order inside a class: utils/tools.py:730-732) on the
+    # device: the kept rows arrive gathered
+    out = ops.nms_select(rows.contiguous(), class_num, mode, nms_threshold, conf_threshold, sigma)
     return out.cpu().numpy() if was_numpy else out
 
 
