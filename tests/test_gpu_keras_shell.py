@@ -354,14 +354,17 @@ def test_captured_step_is_bit_identical_to_eager_steps():
     from tf2_yolo_amd.optimizers import Adam
 
     def make(graphs):
-        y = yolov3.Yolo((96, 96, 3), ["a", "b", "c"])
+        # (8 classes: 39 head channels, so the head filter gradients run on the planes kernels like the 255-channel
+        # heads of the benchmark; heads narrower than 32 channels fall to the fp32-input kernel, whose split-K still ends
+        # in fp32 atomics)
+        y = yolov3.Yolo((96, 96, 3), list("abcdefgh"))
         y.create_model(anchors=A9, pretrained_body=None, seed=11)
         y.model.compile(optimizer=Adam(learning_rate=1e-3), loss=y.loss())
         y.model._graphs_failed = not graphs        # eager reference: the switch a failed capture would flip
         return y.model
     rng = np.random.default_rng(3)
-    x1, ys1 = labels.synthetic_batch(rng, 4, (96, 96), 3)
-    x2, ys2 = labels.synthetic_batch(rng, 4, (96, 96), 3)
+    x1, ys1 = labels.synthetic_batch(rng, 4, (96, 96), 8)
+    x2, ys2 = labels.synthetic_batch(rng, 4, (96, 96), 8)
     dev = lambda x, ys: (torch.from_numpy(x).cuda(), [torch.from_numpy(a).cuda() for a in ys])
     b1, b2 = dev(x1, ys1), dev(x2, ys2)
     seq = [b1, b1, b1, b2, b1, b2]
