@@ -252,7 +252,12 @@ def main():
         model.train_step_device(x, ys)
     barrier()
     captured = getattr(model, "_step_graphs", None) is not None
-    log(f"warmup done ({warm_run} steps; step launch mode: {'hipGraph replay' if captured else 'eager'})")
+    launch_mode = ("eager: every launch enqueued from Python" if not captured else
+                   "launch tape: the recorded C-ABI calls of one step re-issued on the same two HIP streams, none of the Python "
+                   "(tf2_yolo_amd/tape.py)" if type(model._step_graphs).__name__ == "StepTape" else
+                   "hipGraph replay: forward + losses + backward + Adam captured once, cut at the gradient buckets in "
+                   "data-parallel jobs (tf2_yolo_amd/capture.py)")
+    log(f"warmup done ({warm_run} steps; step launch mode: {launch_mode.split(':')[0]})")
     # ---- THE timed region: exactly K steps between barriers ----
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -262,7 +267,7 @@ def main():
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     loss_val = float(sum(b[0].item() for b in bufs))
     # ---- the same K steps once more with every launch enqueued from Python and bracketed by HIP events on its stream
-    # (ops.KernelTimer): per-launch events cannot be recorded inside a graph replay, so the roofline block is measured
+    # (ops.KernelTimer): per-launch events are not part of a replayed step, so the roofline block is measured
     # here, over K steps timed exactly like the region above (every rank runs it: the collectives must match) ----
     timer = None if args.no_kernel_timer else ops.KernelTimer()
     dt_eager = None
@@ -399,14 +404,12 @@ def main():
                                       "gradient all-reduce + Adam",
                           "global_batch": world * args.batch, "per_gpu_batch": args.batch,
                           "parallelism": f"dp{world}", "loss": round(loss_val, 4), "replicas_in_sync": dp_in_sync,
-                          "step_launch_mode": ("hipGraph replay: forward + losses + backward + Adam captured once, cut at the "
-                                               "gradient buckets in data-parallel jobs (tf2_yolo_amd/capture.py)" if captured
-                                               else "eager: every launch enqueued from Python"),
+                          "step_launch_mode": launch_mode,
                           "warmup_steps_run": warm_run},
                "eager_region": (None if dt_eager is None else
                                 {"what": "the same K steps again, every launch enqueued from Python and bracketed by HIP events on "
-                                         "its stream (the roofline block's measurements come from here: a graph replay cannot "
-                                         "carry per-launch events)",
+                                         "its stream (the roofline block's measurements come from here: a replayed step "
+                                         "carries no per-launch events)",
                                  "ms_per_step": round(dt_eager / args.steps * 1e3, 3),
                                  "images_per_s": round(world * args.batch * args.steps / dt_eager, 2)}),
                "roofline": roof, "forward": fwd}

@@ -11,6 +11,7 @@ which = set(sys.argv[1:]) or {"c1", "c2", "c4", "c5"}
 
 
 def train_bench(name, yolo, loss, batch, levels, finest_stride, steps=8, warmup=3):
+    warmup = max(warmup, 3)   # the step is captured into hipGraphs during the third call (tf2_yolo_amd/capture.py)
     m = yolo.model
     m.compile(optimizer=optimizers.Adam(learning_rate=1e-4), loss=loss)
     rng = np.random.default_rng(1234)
@@ -28,6 +29,7 @@ def train_bench(name, yolo, loss, batch, levels, finest_stride, steps=8, warmup=
     dt = (time.perf_counter() - t0) / steps
     loss_v = float(sum(b[0].item() for b in bufs))
     print(json.dumps({"config": name, "batch": batch, "ms_per_step": round(dt * 1e3, 3),
+                      "launch_mode": "hipGraph replay" if getattr(m, "_step_graphs", None) is not None else "eager",
                       "images_per_s": round(batch / dt, 2), "loss": round(loss_v, 4),
                       "finite": bool(np.isfinite(loss_v))}), flush=True)
 

@@ -24,6 +24,16 @@ for _ in range(steps):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+solo = []
+for _ in range(steps):      # the same with an idle device in front of every step: pure host cost of producing the launches
+    torch.cuda.synchronize()
+    a = time.perf_counter()
+    m.train_step_device(x, ys)
+    solo.append(time.perf_counter() - a)
+torch.cuda.synchronize()
+print(f"step launch mode: {type(getattr(m, '_step_graphs', None)).__name__ if getattr(m, '_step_graphs', None) is not None else 'eager'} "
+      f"(YOLO_STEP_MODE={os.environ.get('YOLO_STEP_MODE', 'tape')}); host time per step with an idle device in front: "
+      f"median {np.median(solo)*1e3:.2f} ms (min {min(solo)*1e3:.2f})")
 print(f"host enqueue per step: median {np.median(host)*1e3:.1f} ms (min {min(host)*1e3:.1f}, max {max(host)*1e3:.1f}); "
       f"loop returned after {(t1-t0)*1e3:.0f} ms, device drained after {(t2-t0)*1e3:.0f} ms "
       f"({(t2-t0)/steps*1e3:.1f} ms/step)")

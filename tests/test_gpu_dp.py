@@ -31,23 +31,27 @@ def _env(**kw):
     return env
 
 
-def test_rccl_single_rank_runs_every_collective_of_the_dp_step():
-    plain = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, cwd=ROOT, env=_env(),
+@pytest.mark.parametrize("mode", ["tape", "graph", "eager"])
+def test_rccl_single_rank_runs_every_collective_of_the_dp_step(mode):
+    plain = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, cwd=ROOT, env=_env(YOLO_STEP_MODE=mode),
                            capture_output=True, text=True, timeout=600)
     assert plain.returncode == 0, plain.stderr[-3000:]
     forced = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + ARGS, cwd=ROOT,
-                            env=_env(YOLO_DP_FORCE="1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"),
+                            env=_env(YOLO_DP_FORCE="1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+                                     YOLO_STEP_MODE=mode),
                             capture_output=True, text=True, timeout=600)
     assert forced.returncode == 0, forced.stderr[-3000:]
     a, b = _json_line(plain.stdout), _json_line(forced.stdout)
+    assert b["config"]["step_launch_mode"].startswith({"tape": "launch tape", "graph": "hipGraph", "eager": "eager"}[mode])
     assert b["config"]["replicas_in_sync"] is True and b["n_gpus"] == 1
     assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-3 * abs(a["config"]["loss"])
 
 
-def test_two_ranks_on_one_gpu_stay_in_sync_over_gloo():
+@pytest.mark.parametrize("mode", ["tape", "graph"])
+def test_two_ranks_on_one_gpu_stay_in_sync_over_gloo(mode):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", "29543", "bench.py", "--gpus", "2"] + ARGS
-    r = subprocess.run(cmd, cwd=ROOT, env=_env(YOLO_BENCH_SINGLE_DEVICE="1", YOLO_DIST_BACKEND="gloo"),
+    r = subprocess.run(cmd, cwd=ROOT, env=_env(YOLO_BENCH_SINGLE_DEVICE="1", YOLO_DIST_BACKEND="gloo", YOLO_STEP_MODE=mode),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _json_line(r.stdout)

@@ -344,11 +344,14 @@ def test_yolo_body_plus_yolo_head_is_create_model():
         yolo_head(yolo_body((64, 64, 3)), class_num=2, anchors=A9[:8])
 
 
-def test_captured_step_is_bit_identical_to_eager_steps():
-    """tf2_yolo_amd/capture.py: from the third step on train_step_device replays captured hipGraphs. Same seed, same data:
-    five steps with the capture (two eager + three replays) against five eager steps -- every loss equal (to the fp64
-    atomics' order, 1e-12) and the weights, BatchNorm moving statistics and Adam moments BIT-identical (the filter-gradient
-    reductions are atomics-free). Then a different batch through the same graphs, and a changed learning rate."""
+@pytest.mark.parametrize("mode", ["tape", "graph"])
+def test_captured_step_is_bit_identical_to_eager_steps(mode, monkeypatch):
+    """From the third step on train_step_device replays the recorded step: the launch tape (tape.py, the default) or
+    captured hipGraphs (capture.py, YOLO_STEP_MODE=graph). Same seed, same data: six steps with the recording (two eager,
+    the recording / capture, three replays) against six eager steps -- every loss equal (to the fp64 atomics' order,
+    1e-12) and the weights, BatchNorm moving statistics and Adam moments BIT-identical (the filter-gradient reductions
+    are atomics-free). A different batch goes through the same recording, and the learning rate changes on the way."""
+    monkeypatch.setenv("YOLO_STEP_MODE", mode)
     import yolov3
     from tf2_yolo_amd import labels
     from tf2_yolo_amd.optimizers import Adam
@@ -378,7 +381,11 @@ def test_captured_step_is_bit_identical_to_eager_steps():
             bufs, _ = m.train_step_device(x, ys)
             losses.append([float(b[0].item()) for b in bufs])
         if graphs:
-            assert m._step_graphs is not None and len(m._step_graphs.segments) == 1      # no data parallelism: one graph
+            assert m._step_graphs is not None
+            if mode == "graph":
+                assert len(m._step_graphs.segments) == 1      # no data parallelism: one graph
+            else:
+                assert len(m._step_graphs.tape.entries) > 500
         res[graphs] = (losses, m.net.params.data.clone(), m.net.state.data.clone(), m.optimizer.m.clone(), m.optimizer.v.clone())
     for la, lb in zip(res[False][0], res[True][0]):
         for a, b in zip(la, lb):

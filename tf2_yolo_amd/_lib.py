@@ -9,6 +9,8 @@ import os
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_longlong,
                     c_size_t, c_void_p)
 
+from . import tape as _tape
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libyolo_hip.so")
 
@@ -123,6 +125,40 @@ SIGNATURES = {
 
 _lib = None
 
+# functions that only answer a question on the host: never part of a recorded step (tape.py)
+_QUERIES = {"yolo_last_error", "yolo_abi_version", "yolo_device_available", "yolo_conv_workspace_bytes", "yolo_planes_bytes",
+            "yolo_stem_bwd_scratch_bytes", "yolo_loss_workspace_bytes", "yolo_decode_workspace_bytes",
+            "yolo_nms_workspace_bytes", "yolo_pr_curve_workspace_bytes", "yolo_wgrad_workspace_bytes", "yolo_adam_lr_t",
+            "yolo_set_option", "yolo_set_debug_buffer", "yolo_set_conv_workspace", "yolo_set_wgrad_workspace"}
+
+
+class _Recorded:
+    """a library function that, while a launch tape records (tape.ACTIVE), remembers (function, arguments) of every call"""
+    __slots__ = ("f", "name")
+
+    def __init__(self, f, name):
+        self.f, self.name = f, name
+
+    def __call__(self, *a):
+        rc = self.f(*a)
+        if _tape.ACTIVE is not None:
+            _tape.ACTIVE.c(self.f, a, self.name)
+        return rc
+
+
+class _Lib:
+    """attribute access like the ctypes.CDLL it wraps; enqueueing functions are recordable"""
+
+    def __init__(self, cdll):
+        self._cdll = cdll
+
+    def __getattr__(self, name):
+        f = getattr(self._cdll, name)
+        if name not in _QUERIES and name in SIGNATURES:
+            f = _Recorded(f, name)
+        setattr(self, name, f)
+        return f
+
 
 def load():
     """Load libyolo_hip.so and declare every prototype. Raises YoloHipError if absent."""
@@ -148,8 +184,8 @@ def load():
             raise YoloHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    _lib = lib
-    return lib
+    _lib = _Lib(lib)
+    return _lib
 
 
 def check(rc, what=""):

@@ -145,3 +145,53 @@ class StepGraphs:
                 red.finish()
         net.mark_params_changed()
         return model._loss_bufs
+
+
+class StepTape:
+    """The recorded training step of one Model (tape.py): same key, same replay interface as StepGraphs. Recording
+    EXECUTES the step (it is an ordinary eager step whose library calls are remembered), so `record` returns its losses."""
+
+    def __init__(self, model, x, y_list):
+        from . import tape as tape_mod
+        self.model = model
+        self.key = StepGraphs.key_of(model, x)
+        opt, net = model.optimizer, model.net
+        if not getattr(opt, "capturable", False):
+            raise YoloHipError("this optimizer has no capturable form")
+        self.x = x.clone()
+        self.ys = [y.clone() for y in y_list]
+        opt._hyper_buffers()
+        red = model._reducer if (model._reducer is not None and model._reducer.active) else None
+        # (events of the eager steps before: the recorded step must not wait for objects no replay will ever re-record;
+        # the two streams were joined at the end of the last backward)
+        net._dyp_events = [None, None]
+        self.tape = tape_mod.Tape()
+        opt.refresh_hyper(grad_scale=(1.0 / red.world) if red is not None else 1.0)
+        tape_mod.ACTIVE = self.tape
+        try:
+            outs = net.forward(self.x, training=True)
+            for i, (o, yt) in enumerate(zip(outs, self.ys)):
+                model.loss[i].fwd_bwd(yt, o, grad_scale=1.0, dpred=model._dpred[i], loss_out=model._loss_bufs[i])
+            net.backward(model._dpred)
+            if red is not None:
+                if net.anchors_trainable and red.world > 1:
+                    import torch.distributed as dist
+                    tape_mod.host_call(lambda: dist.all_reduce(net.anchor_grads, group=red.pg))
+                tape_mod.host_call(red.finish)
+            opt.step_captured()
+        finally:
+            tape_mod.ACTIVE = None
+        net.mark_params_changed()
+
+    def replay(self, x, y_list):
+        model, net, opt = self.model, self.model.net, self.model.optimizer
+        red = model._reducer if (model._reducer is not None and model._reducer.active) else None
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        for dst, src in zip(self.ys, y_list):
+            if src.data_ptr() != dst.data_ptr():
+                dst.copy_(src, non_blocking=True)
+        opt.refresh_hyper(grad_scale=(1.0 / red.world) if red is not None else 1.0)
+        self.tape.replay()
+        net.mark_params_changed()
+        return model._loss_bufs

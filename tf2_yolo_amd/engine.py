@@ -25,6 +25,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import tape
 from ._lib import ACT_LEAKY, ACT_LINEAR, ACT_MISH, YoloHipError
 
 ACT_NAMES = {ACT_LINEAR: "linear", ACT_LEAKY: "leaky", ACT_MISH: "mish"}
@@ -640,15 +641,13 @@ class Network:
             if self._wgrad_stream is None:
                 self._wgrad_stream = torch.cuda.Stream(device=self.device)
             side = self._wgrad_stream
-            side.wait_stream(torch.cuda.current_stream())
+            tape.wait_stream(side, torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 self._refresh_wplanes()
-                self._wp_event = torch.cuda.Event()
-                self._wp_event.record(side)
+                self._wp_event = tape.record_event(side)
                 self._refresh_wT()
                 self._refresh_wTplanes()
-                self._wT_event = torch.cuda.Event()
-                self._wT_event.record(side)
+                self._wT_event = tape.record_event(side)
         else:
             self._refresh_wplanes()
         ops.zero_bytes(self._aux)   # bounds / per-channel maxima of this pass
@@ -661,7 +660,7 @@ class Network:
         P = self.params
         for u in self.units:
             if self._wp_event is not None and u.kind in ("conv", "head") and u.planes_fwd:
-                torch.cuda.current_stream().wait_event(self._wp_event)
+                tape.wait_event(torch.cuda.current_stream(), self._wp_event)
                 self._wp_event = None
             if u.kind == "conv":
                 xin = self.act[u.src.tid]
@@ -795,7 +794,7 @@ class Network:
                                                 cout, taps, u.src.c)
         for u in self.units:
             if u.kind == "head" and u.cpad:
-                u.w_pad[:u.out.c * u.src.c].copy_(self.params.view(u.p_kernel.name).reshape(-1))
+                tape.torch_op(lambda u=u: u.w_pad[:u.out.c * u.src.c].copy_(self.params.view(u.p_kernel.name).reshape(-1)))
         self._jobs_wT.run()
         self._wT_valid = True
 
@@ -808,7 +807,7 @@ class Network:
         if not self.training:
             raise YoloHipError("backward() requires a preceding forward(training=True)")
         if self._wT_event is not None:
-            torch.cuda.current_stream().wait_event(self._wT_event)
+            tape.wait_event(torch.cuda.current_stream(), self._wT_event)
             self._wT_event = None
         self._refresh_wT()
         self._refresh_wTplanes()
@@ -838,7 +837,7 @@ class Network:
                         ops.stem_bn_bwd_wgrad(u.desc, xin, u.y, dout, scale, shift, smean, sinv, u.act, red,
                                               self._gview(u.p_gamma), self._gview(u.p_beta), self._gview(u.p_kernel))
                         if self.grad_ready_hook is not None:
-                            self.grad_ready_hook(u)
+                            tape.host_call(lambda u=u: self.grad_ready_hook(u))
                         continue
                     dyp = self._next_dyp_buffer() if need_pl else None
                     dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
@@ -876,7 +875,7 @@ class Network:
                         else:
                             ops.conv2d_dgrad_planes(u.desc_pad, dtp, wTp, dx=cur, accumulate=True)
                     if self.grad_ready_hook is not None:
-                        self.grad_ready_hook(u)
+                        tape.host_call(lambda u=u: self.grad_ready_hook(u))
                     continue
                 dtp = self._dyp(u, dt)
                 with self._beside_backward(dt):
@@ -925,7 +924,7 @@ class Network:
                     else:
                         ops.space_to_depth2_bwd(dout, u.out.c, 0, cur, accumulate=True)
             if self.grad_ready_hook is not None and u.kind in ("conv", "head"):
-                self.grad_ready_hook(u)
+                tape.host_call(lambda u=u: self.grad_ready_hook(u))
         self._join_wgrad()
 
     # The filter gradient of a layer is independent of everything the backward pass does next (its data
@@ -940,7 +939,7 @@ class Network:
         self._dyp_idx ^= 1
         ev = self._dyp_events[self._dyp_idx]
         if ev is not None:
-            torch.cuda.current_stream().wait_event(ev)
+            tape.wait_event(torch.cuda.current_stream(), ev)
             self._dyp_events[self._dyp_idx] = None
         return self._dyplanes2[self._dyp_idx]
 
@@ -952,20 +951,19 @@ class Network:
         if self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device)
         side = self._wgrad_stream
-        side.wait_stream(torch.cuda.current_stream())
+        tape.wait_stream(side, torch.cuda.current_stream())
         for t in tensors:
             if t is not None:
                 t.record_stream(side)
         with torch.cuda.stream(side):
             yield
-            ev = torch.cuda.Event()
-            ev.record(side)
+            ev = tape.record_event(side)
         self._dyp_events[self._dyp_idx] = ev
         self._wgrad_pending = True
 
     def _join_wgrad(self):
         if self._wgrad_pending:
-            torch.cuda.current_stream().wait_stream(self._wgrad_stream)
+            tape.wait_stream(torch.cuda.current_stream(), self._wgrad_stream)
             self._wgrad_pending = False
 
     def _dyp(self, u, dy):

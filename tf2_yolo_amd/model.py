@@ -319,17 +319,21 @@ class Model:
         self._eager_steps = {}
 
     def _captured_step(self, x, y_list):
-        """Replay the captured step if there is one for this configuration; capture it after two eager steps of the same
-        configuration (allocations, lazy initialisation and filter preparation have then happened). YOLO_STEP_GRAPH=0
-        keeps every step eager. A failed capture is reported once and switches the feature off for this model."""
+        """Replay the recorded step if there is one for this configuration; record it after two eager steps of the same
+        configuration (allocations, lazy initialisation and filter preparation have then happened).
+        YOLO_STEP_MODE = tape (default: the launch tape of tape.py -- same launches on the same two streams, none of the
+        Python), graph (hipGraphs, capture.py: bit-identical too, but this runtime serialises the two captured streams:
+        35.4 vs 31.2 ms per step), eager (every step through Python; YOLO_STEP_GRAPH=0 means the same). A failed
+        recording is reported once and switches the feature off for this model."""
         import os
-        if os.environ.get("YOLO_STEP_GRAPH", "1") == "0" or getattr(self, "_graphs_failed", False):
+        mode = os.environ.get("YOLO_STEP_MODE", "tape")
+        if os.environ.get("YOLO_STEP_GRAPH", "1") == "0" or mode == "eager" or getattr(self, "_graphs_failed", False):
             return None
         if not getattr(self.optimizer, "capturable", False):
             return None
         if self.net.grad_ready_hook is not None and self._reducer is None:
             return None          # a foreign gradient hook: its host side would not run during replays
-        from .capture import StepGraphs
+        from .capture import StepGraphs, StepTape
         key = StepGraphs.key_of(self, x)
         g = self._step_graphs
         if g is not None and g.key == key:
@@ -340,16 +344,22 @@ class Model:
             self._step_graphs = None
             return None
         try:
-            self._step_graphs = StepGraphs(self, x, y_list)
+            if mode == "graph":
+                self._step_graphs = StepGraphs(self, x, y_list)
+                return self._step_graphs.replay(x, y_list)
+            self._step_graphs = StepTape(self, x, y_list)        # recording executes this step
+            return self._loss_bufs
         except Exception as e:   # e.g. a runtime that cannot capture some call: stay eager, say so once
             import sys
             import traceback
-            print(f"[tf2_yolo_amd] step capture failed ({e!r}); training continues with eager launches\n"
+            print(f"[tf2_yolo_amd] step recording ({mode}) failed ({e!r}); training continues with eager launches\n"
                   + "".join(traceback.format_exc().splitlines(True)[-12:]), file=sys.stderr)
             self._graphs_failed = True
             self._step_graphs = None
+            if mode != "graph":
+                from . import ops as _ops      # a recording that broke half-way has accumulated part of the gradients:
+                _ops.zero_bytes(self.net.grads)   # the eager step that follows starts from zero again
             return None
-        return self._step_graphs.replay(x, y_list)
 
     def train_step_device(self, x, y_list, with_metrics=False):
         """One optimizer step on device-resident float32 tensors. Returns the per-output loss

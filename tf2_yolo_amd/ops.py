@@ -10,6 +10,7 @@ from ctypes import byref, c_void_p
 import torch
 
 from . import _lib
+from . import tape as _tape
 from ._lib import ConvDesc, LossCfg, YoloHipError, check
 
 BN_EPS = 1e-3       # Keras BatchNormalization default
@@ -193,6 +194,8 @@ def _stream():
 def _p(t):
     if t is None:
         return c_void_p(0)
+    if _tape.ACTIVE is not None:
+        _tape.ACTIVE.keep.append(t)     # its address is about to enter a recorded argument tuple: it must outlive the tape
     return c_void_p(t.data_ptr())
 
 
