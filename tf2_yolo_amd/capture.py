@@ -28,6 +28,24 @@ from ._lib import YoloHipError
 _LEAKED = []   # graph objects of failed captures (see StepGraphs._capture)
 
 
+class _StaticInputs:
+    """the static input buffers of a recorded step: a caller's batch is copied in before a replay unless it is the very
+    tensor object (same storage, same version counter: not modified in place since) that was copied last time"""
+
+    def __init__(self, x, y_list):
+        self.x = x.clone()
+        self.ys = [y.clone() for y in y_list]
+        self._last = [(x, x._version)] + [(y, y._version) for y in y_list]
+
+    def load(self, x, y_list):
+        for i, (dst, src) in enumerate(zip([self.x] + self.ys, [x] + list(y_list))):
+            last, ver = self._last[i]
+            if src is last and src._version == ver:
+                continue
+            dst.copy_(src, non_blocking=True)
+            self._last[i] = (src, src._version)
+
+
 class StepGraphs:
     """Captured training step of one Model for one (batch size, loss list, optimizer, reducer) configuration."""
 
@@ -39,8 +57,8 @@ class StepGraphs:
         if not getattr(opt, "capturable", False):
             raise YoloHipError("this optimizer has no capturable form")
         # static inputs of the graphs: the caller's batch is copied into them before every replay
-        self.x = x.clone()
-        self.ys = [y.clone() for y in y_list]
+        self.inputs = _StaticInputs(x, y_list)
+        self.x, self.ys = self.inputs.x, self.inputs.ys
         self.segments = []          # (graph, action): action = ("reduce", bucket) | ("finish",) | None
         opt._hyper_buffers()        # (pinned host + device scalars: allocated here, never inside a capture)
         torch.cuda.synchronize()
@@ -126,11 +144,7 @@ class StepGraphs:
     def replay(self, x, y_list):
         model, net, opt = self.model, self.model.net, self.model.optimizer
         red = model._reducer if (model._reducer is not None and model._reducer.active) else None
-        if x.data_ptr() != self.x.data_ptr():
-            self.x.copy_(x, non_blocking=True)
-        for dst, src in zip(self.ys, y_list):
-            if src.data_ptr() != dst.data_ptr():
-                dst.copy_(src, non_blocking=True)
+        self.inputs.load(x, y_list)
         opt.refresh_hyper(grad_scale=(1.0 / red.world) if red is not None else 1.0)
         for g, action in self.segments:
             g.replay()
@@ -158,8 +172,8 @@ class StepTape:
         opt, net = model.optimizer, model.net
         if not getattr(opt, "capturable", False):
             raise YoloHipError("this optimizer has no capturable form")
-        self.x = x.clone()
-        self.ys = [y.clone() for y in y_list]
+        self.inputs = _StaticInputs(x, y_list)
+        self.x, self.ys = self.inputs.x, self.inputs.ys
         opt._hyper_buffers()
         red = model._reducer if (model._reducer is not None and model._reducer.active) else None
         # (events of the eager steps before: the recorded step must not wait for objects no replay will ever re-record;
@@ -186,11 +200,7 @@ class StepTape:
     def replay(self, x, y_list):
         model, net, opt = self.model, self.model.net, self.model.optimizer
         red = model._reducer if (model._reducer is not None and model._reducer.active) else None
-        if x.data_ptr() != self.x.data_ptr():
-            self.x.copy_(x, non_blocking=True)
-        for dst, src in zip(self.ys, y_list):
-            if src.data_ptr() != dst.data_ptr():
-                dst.copy_(src, non_blocking=True)
+        self.inputs.load(x, y_list)
         opt.refresh_hyper(grad_scale=(1.0 / red.world) if red is not None else 1.0)
         self.tape.replay()
         net.mark_params_changed()

@@ -334,11 +334,15 @@ class Model:
         if self.net.grad_ready_hook is not None and self._reducer is None:
             return None          # a foreign gradient hook: its host side would not run during replays
         from .capture import StepGraphs, StepTape
+        self.net.allocate(x.shape[0])     # (the key names the allocation the recording belongs to)
         key = StepGraphs.key_of(self, x)
         g = self._step_graphs
         if g is not None and g.key == key:
             return g.replay(x, y_list)
         n = self._eager_steps.get(key, 0)
+        if os.environ.get("YOLO_STEP_DEBUG"):
+            import sys
+            print(f"[step] mode {mode} eager steps so far {n} key {key} known {list(self._eager_steps)}", file=sys.stderr)
         if n < 2 or self._dpred is None:
             self._eager_steps = {key: n + 1}
             self._step_graphs = None

@@ -47,7 +47,13 @@ def wait_stream(waiter, other):
     """`waiter` waits for everything enqueued on `other` so far"""
     waiter.wait_stream(other)
     if ACTIVE is not None:
-        ACTIVE.py(lambda: waiter.wait_stream(other))
+        ev = torch.cuda.Event()      # one event object per recorded wait, re-recorded at every replay (Stream.wait_stream
+        rec, wait = ev.record, waiter.wait_event   # would create a fresh one each time: ~10 us of host time per wait)
+
+        def again():
+            rec(other)
+            wait(ev)
+        ACTIVE.py(again)
 
 
 def record_event(stream):
