@@ -86,8 +86,8 @@ def standalone(layer, reps=12):
 
 rows = []
 for (name, layer), a in sorted(instep.items(), key=lambda kv: -kv[1]["ms"]):
-    if layer is None:
-        continue
+    if layer is None or layer[3] % 16 or layer[4] % 16:
+        continue      # (the 255-channel heads run on padded copies: not reproducible from the descriptor alone)
     us_in = a["ms"] / a["launches"] * 1e3
     b = serial.get((name, layer))
     us_ser = b["ms"] / b["launches"] * 1e3 if b else None
