@@ -29,7 +29,7 @@ def train_bench(name, yolo, loss, batch, levels, finest_stride, steps=8, warmup=
     dt = (time.perf_counter() - t0) / steps
     loss_v = float(sum(b[0].item() for b in bufs))
     print(json.dumps({"config": name, "batch": batch, "ms_per_step": round(dt * 1e3, 3),
-                      "launch_mode": "hipGraph replay" if getattr(m, "_step_graphs", None) is not None else "eager",
+                      "launch_mode": type(m._step_graphs).__name__ if getattr(m, "_step_graphs", None) is not None else "eager",
                       "images_per_s": round(batch / dt, 2), "loss": round(loss_v, 4),
                       "finite": bool(np.isfinite(loss_v))}), flush=True)
 
