@@ -14,7 +14,10 @@ endif
 
 all: $(LIB)
 
-$(CSRC)/%.o: $(CSRC)/%.hip $(CSRC)/common.hpp $(CSRC)/conv_args.hpp $(CSRC)/planes.hpp $(CSRC)/planes_epilogue.hpp include/yolo_hip.h
+# (every kernel file is rebuilt when ANY shared header changes: act.hpp was missing from this list in round 3 and a change
+# to the Mish arithmetic silently never reached bn_act.o)
+HDRS  := $(wildcard $(CSRC)/*.hpp) include/yolo_hip.h
+$(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)

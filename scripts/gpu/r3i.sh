@@ -6,5 +6,5 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_
 cp $O/c4_ks/*/*kernel_stats.csv $O/c4_kernel_stats.csv 2>/dev/null; rm -rf $O/c4_ks
 cd $R
 grep -h images_per_s $O/c4_prof.log
-python scripts/kstats_summary.py $O/c4_kernel_stats.csv 16
-python bench.py > $O/bench.log 2>$O/bench.err; python scripts/bench_line.py $O/bench.log
+python scripts/kstats_summary.py $O/c4_kernel_stats.csv 12
+python scripts/bench_configs.py c4 2>&1 | grep images_per_s

@@ -79,7 +79,9 @@ class StepGraphs:
 
         def begin():
             g = torch.cuda.CUDAGraph()
-            g.capture_begin(pool=pool)
+            # thread_local: other threads of the process keep their runtime calls (RCCL's watchdog polls events while this
+            # thread captures; in the default "global" mode that poll is an error that kills the process group)
+            g.capture_begin(pool=pool, capture_error_mode="thread_local")
             state["g"] = g
 
         def end(action):

@@ -458,15 +458,15 @@ class Network:
     def allocate(self, N):
         if self.batch == N:
             return
-        # the planes kernels address their operands with 32-bit buffer offsets: say so HERE, with the largest batch
-        # that fits, instead of failing inside forward (use YOLO_CONV_PLANES=0, the exact register-staged kernels,
-        # for larger batches)
-        if ops.USE_PLANES:
-            worst = max((t.h * t.w * t.c * 4 for t in self.tensors), default=0)
-            if worst and N * worst + (1 << 20) >= (1 << 32):
-                raise YoloHipError(f"batch {N}: the largest activation ({worst / 2 ** 20:.1f} MiB per image) would exceed the "
-                                   f"4 GiB a planes operand may span; the largest batch for this model is "
-                                   f"{((1 << 32) - (1 << 20)) // worst - 1} (or set YOLO_CONV_PLANES=0)")
+        # every conv kernel addresses its operands through buffer descriptors with 32-bit offsets (the planes kernels check
+        # it per launch, the register-staged ones do not): say so HERE, with the largest batch that fits, instead of
+        # failing -- or wrapping around -- inside forward. 4 GiB per ACTIVATION is 192 images of YOLOv3-416 per GPU; a
+        # larger global batch is what data parallelism is for.
+        worst = max((t.h * t.w * t.c * 4 for t in self.tensors), default=0)
+        if worst and N * worst + (1 << 20) >= (1 << 32):
+            raise YoloHipError(f"batch {N}: the largest activation ({worst / 2 ** 20:.1f} MiB per image) would exceed the "
+                               f"4 GiB a conv operand may span; the largest per-GPU batch for this model is "
+                               f"{((1 << 32) - (1 << 20)) // worst - 1}")
         self.batch = N
         self.alloc_gen = getattr(self, "alloc_gen", 0) + 1   # captured step graphs (capture.py) belong to one allocation
         self._infer_graphs = {}   # captured graphs point into the buffers re-allocated below
