@@ -77,6 +77,26 @@ def _one_hot_argmax(iou_scores, depth):
     return torch.nn.functional.one_hot(idx, depth).to(iou_scores.dtype)
 
 
+def _decisions(iou_own, decide_iou, bbox_num, stats, threshes=()):
+    """The discrete decisions of a loss (responsible anchor = argmax IoU; ignore / truth masks = IoU against a threshold).
+    With `decide_iou` (the IoUs of ANOTHER execution's predictions, e.g. the device's) the decisions are taken from it --
+    the loss-side twin of layers.leaky_masked: two executions whose IoUs differ by rounding legitimately pick different
+    winners among near-tied anchors, and one different winner moves a head's gradient tensor by O(1). stats["disagree"]
+    records how far from a tie the decisions were where they differ (the caller asserts it is rounding-sized)."""
+    src = iou_own if decide_iou is None else decide_iou
+    idx = torch.argmax(src, dim=-1)
+    if decide_iou is not None and stats is not None:
+        own = torch.argmax(iou_own, dim=-1)
+        gap = (iou_own.gather(-1, own.unsqueeze(-1)) - iou_own.gather(-1, idx.unsqueeze(-1))).squeeze(-1)
+        d = float(gap[own != idx].max()) if bool((own != idx).any()) else 0.0
+        for t in threshes:
+            bad = (iou_own < t) != (src < t)
+            if bool(bad.any()):
+                d = max(d, float((iou_own[bad] - t).abs().max()))
+        stats["disagree"] = max(stats.get("disagree", 0.0), d)
+    return torch.nn.functional.one_hot(idx, bbox_num).to(iou_own.dtype), src
+
+
 def _sum_mean0(t):
     """tf.reduce_sum(tf.reduce_mean(t, axis=0))"""
     return t.mean(dim=0).sum()
@@ -85,7 +105,7 @@ def _sum_mean0(t):
 def wrap_yolo_loss_v3(grid_shape, bbox_num, class_num, anchors=None, binary_weight=1,
                       loss_weight=(1, 1, 1, 1), ignore_thresh=.6, use_focal_loss=False,
                       focal_loss_gamma=2, use_scale=True, parts=False):
-    def yolo_loss(y_true, y_pred):
+    def yolo_loss(y_true, y_pred, decide_with=None, stats=None):
         dt = y_pred.dtype
         panchors = 1 if anchors is None else torch.tensor(anchors, dtype=dt).reshape(1, 1, 1, bbox_num, 2)
         y_true_ = y_true.reshape(-1, *grid_shape, 1, 5 + class_num).to(dt)
@@ -93,7 +113,9 @@ def wrap_yolo_loss_v3(grid_shape, bbox_num, class_num, anchors=None, binary_weig
         xywh_true = y_true_[..., :4]
         xywh_pred = y_pred_[..., :4]
         iou_scores = cal_iou(xywh_true, xywh_pred, grid_shape).detach()
-        response_mask = _one_hot_argmax(iou_scores, bbox_num)
+        dec = None if decide_with is None else cal_iou(
+            xywh_true, decide_with.reshape(y_pred_.shape).to(dt)[..., :4], grid_shape).detach()
+        response_mask, iou_scores = _decisions(iou_scores, dec, bbox_num, stats, (ignore_thresh,))
         has_obj_mask = y_true_[..., 4] * response_mask
         has_obj_mask_exp = has_obj_mask.unsqueeze(-1)
         no_obj_mask = (iou_scores < ignore_thresh).to(dt)
@@ -134,13 +156,15 @@ def wrap_yolo_loss_v3(grid_shape, bbox_num, class_num, anchors=None, binary_weig
 
 def wrap_yolo_loss_v2(grid_shape, bbox_num, class_num, anchors, binary_weight=1, loss_weight=(1, 1, 1, 1),
                       ignore_thresh=.6):
-    def yolo_loss(y_true, y_pred):
+    def yolo_loss(y_true, y_pred, decide_with=None, stats=None):
         dt = y_pred.dtype
         panchors = torch.tensor(anchors, dtype=dt).reshape(1, 1, 1, bbox_num, 2)
         y_true_ = y_true.reshape(-1, *grid_shape, 1, 5 + class_num).to(dt)
         y_pred_ = y_pred.reshape(-1, *grid_shape, bbox_num, 5 + class_num)
         iou_scores = cal_iou(y_true_[..., :4], y_pred_[..., :4], grid_shape).detach()
-        response_mask = _one_hot_argmax(iou_scores, bbox_num)
+        dec = None if decide_with is None else cal_iou(
+            y_true_[..., :4], decide_with.reshape(y_pred_.shape).to(dt)[..., :4], grid_shape).detach()
+        response_mask, iou_scores = _decisions(iou_scores, dec, bbox_num, stats, (ignore_thresh,))
         has_obj_mask = y_true_[..., 4] * response_mask
         has_obj_mask_exp = has_obj_mask.unsqueeze(-1)
         no_obj_mask = (1 - has_obj_mask) * (iou_scores < ignore_thresh).to(dt)
@@ -165,14 +189,17 @@ def wrap_yolo_loss_v2(grid_shape, bbox_num, class_num, anchors, binary_weight=1,
 
 def wrap_yolo_loss_v4(grid_shape, bbox_num, class_num, anchors=None, binary_weight=1, loss_weight=(1, 1, 1),
                       wh_reg_weight=0.01, ignore_thresh=.6, truth_thresh=1, label_smooth=0, focal_loss_gamma=2):
-    def yolo_loss(y_true, y_pred):
+    def yolo_loss(y_true, y_pred, decide_with=None, stats=None):
         dt = y_pred.dtype
         panchors = 1 if anchors is None else torch.tensor(anchors, dtype=dt).reshape(1, 1, 1, bbox_num, 2)
         y_true_ = y_true.reshape(-1, *grid_shape, 1, 5 + class_num).to(dt)
         y_pred_ = y_pred.reshape(-1, *grid_shape, bbox_num, 5 + class_num)
         iou_scores, ciou_scores = cal_iou(y_true_[..., :4], y_pred_[..., :4], grid_shape, return_ciou=True)
         iou_const = iou_scores.detach()
-        response_mask = _one_hot_argmax(iou_const, bbox_num)
+        dec = None if decide_with is None else cal_iou(
+            y_true_[..., :4], decide_with.reshape(y_pred_.shape).to(dt)[..., :4], grid_shape).detach()
+        response_mask, iou_const = _decisions(iou_const, dec, bbox_num, stats,
+                                              (ignore_thresh,) + ((truth_thresh,) if truth_thresh < 1 else ()))
         has_obj_mask = y_true_[..., 4] * response_mask
         if truth_thresh < 1:
             truth_mask = (iou_const > truth_thresh).to(dt)
@@ -201,13 +228,15 @@ def wrap_yolo_loss_v4(grid_shape, bbox_num, class_num, anchors=None, binary_weig
 
 
 def wrap_yolo_loss_v1(grid_shape, bbox_num, class_num, binary_weight=1, loss_weight=(1, 1, 1, 1)):
-    def yolo_loss(y_true, y_pred):
+    def yolo_loss(y_true, y_pred, decide_with=None, stats=None):
         dt = y_pred.dtype
         y_true = y_true.to(dt)
         xywhc_true = y_true[..., :-class_num].reshape(-1, *grid_shape, 1, 5)
         xywhc_pred = y_pred[..., :-class_num].reshape(-1, *grid_shape, bbox_num, 5)
         iou_scores = cal_iou(xywhc_true, xywhc_pred, grid_shape)   # differentiated (loss.py:86-91)
-        response_mask = _one_hot_argmax(iou_scores, bbox_num)
+        dec = None if decide_with is None else cal_iou(
+            xywhc_true, decide_with.to(dt)[..., :-class_num].reshape(xywhc_pred.shape), grid_shape).detach()
+        response_mask, _ = _decisions(iou_scores.detach(), dec, bbox_num, stats)
         response_mask_exp = response_mask.unsqueeze(-1)
         has_obj_mask = xywhc_true[..., 4]
         has_obj_mask_exp = has_obj_mask.unsqueeze(-1)

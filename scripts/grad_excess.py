@@ -44,7 +44,8 @@ def oracle(dtype, threads=None):
         torch.set_num_threads(threads)
     wt = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in w.items()}
     out, ctx = fwd(wt, torch.tensor(x, dtype=dtype), True, masks)
-    tot = sum(lf(torch.tensor(yt, dtype=dtype), o) for lf, yt, o in zip(loss_o, ys, out))
+    tot = sum(lf(torch.tensor(yt, dtype=dtype), o, decide_with=torch.tensor(d, dtype=dtype))
+              for lf, yt, o, d in zip(loss_o, ys, out, dev_out))
     tot.backward()
     return wt, [o.detach().double().numpy() for o in out], ctx
 
