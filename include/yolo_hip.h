@@ -389,6 +389,11 @@ typedef struct yolo_loss_cfg {
   float label_smooth;     /* v4                                                       */
 } yolo_loss_cfg;
 
+/* workspace: the fused kernel needs none (yolo_loss_workspace_bytes returns 0). OPTIONAL diagnostic output: a workspace of at
+ * least 8 bytes per grid cell (N*gh*gw cells, A <= 16) receives two ints per cell -- [0] the responsible anchor (first maximal
+ * IoU, tf.argmax), [1] bit b = "IoU of anchor b < ignore_thresh", bit 16 + b = "IoU of anchor b > truth_thresh" -- the
+ * discrete decisions of yolov3/losses/loss.py:63-79 as THIS execution took them (parity tests hand them to the oracle: two
+ * executions legitimately disagree about near-tied anchors). */
 size_t yolo_loss_workspace_bytes(const yolo_loss_cfg* cfg);
 int yolo_loss_fwd_bwd(const yolo_loss_cfg* cfg, const float* y_true, const float* y_pred,
                       double* loss_out, float* dpred, float grad_scale,

@@ -77,22 +77,44 @@ def _one_hot_argmax(iou_scores, depth):
     return torch.nn.functional.one_hot(idx, depth).to(iou_scores.dtype)
 
 
-def _decisions(iou_own, decide_iou, bbox_num, stats, threshes=()):
-    """The discrete decisions of a loss (responsible anchor = argmax IoU; ignore / truth masks = IoU against a threshold).
-    With `decide_iou` (the IoUs of ANOTHER execution's predictions, e.g. the device's) the decisions are taken from it --
-    the loss-side twin of layers.leaky_masked: two executions whose IoUs differ by rounding legitimately pick different
-    winners among near-tied anchors, and one different winner moves a head's gradient tensor by O(1). stats["disagree"]
-    records how far from a tie the decisions were where they differ (the caller asserts it is rounding-sized)."""
-    src = iou_own if decide_iou is None else decide_iou
-    idx = torch.argmax(src, dim=-1)
-    if decide_iou is not None and stats is not None:
+def _decisions(iou_own, dec, bbox_num, stats, ignore_thresh=None, truth_thresh=None):
+    """The discrete decisions of a loss: the responsible anchor (argmax IoU) and the ignore / truth masks (IoU against a
+    threshold). dec = None: taken from this execution's own IoUs. dec = int tensor [..., 2] as yolo_loss_fwd_bwd exports it
+    ([0] responsible anchor, [1] bit b = IoU_b < ignore_thresh, bit 16 + b = IoU_b > truth_thresh): taken from ANOTHER
+    execution (the device) -- the loss-side twin of layers.leaky_masked: two executions whose IoUs differ by rounding (or
+    whose fp32 / fp64 evaluation of one tiny intersection lands on different sides of zero) pick different winners among
+    tied anchors, and one different winner moves a head's gradient tensor by O(1). Returns (one-hot of the responsible
+    anchor, a surrogate IoU tensor whose comparisons with the two thresholds reproduce the masks). stats["disagree"]
+    records how far from a tie / from the threshold the own IoUs were where the decisions differ (the caller asserts that
+    this is rounding-sized)."""
+    if dec is None:
+        idx = torch.argmax(iou_own, dim=-1)
+        return torch.nn.functional.one_hot(idx, bbox_num).to(iou_own.dtype), iou_own
+    dec = dec.reshape(*iou_own.shape[:-1], 2).long()
+    idx = dec[..., 0]
+    bits = dec[..., 1]
+    ar = torch.arange(bbox_num)
+    ign = ((bits.unsqueeze(-1) >> ar) & 1).bool()
+    tru = ((bits.unsqueeze(-1) >> (16 + ar)) & 1).bool()
+    lo = -1.0
+    mid = ignore_thresh if ignore_thresh is not None else 0.0
+    src = torch.full_like(iou_own, float(mid))            # mid = ignore_thresh (<= truth_thresh): in neither mask
+    if truth_thresh is not None and truth_thresh < 1:
+        src = torch.where(tru, torch.full_like(iou_own, float(truth_thresh) + 1.0), src)
+    if ignore_thresh is not None:
+        src = torch.where(ign, torch.full_like(iou_own, lo), src)
+    if stats is not None:
         own = torch.argmax(iou_own, dim=-1)
         gap = (iou_own.gather(-1, own.unsqueeze(-1)) - iou_own.gather(-1, idx.unsqueeze(-1))).squeeze(-1)
         d = float(gap[own != idx].max()) if bool((own != idx).any()) else 0.0
-        for t in threshes:
-            bad = (iou_own < t) != (src < t)
+        if ignore_thresh is not None:
+            bad = (iou_own < ignore_thresh) != ign
             if bool(bad.any()):
-                d = max(d, float((iou_own[bad] - t).abs().max()))
+                d = max(d, float((iou_own[bad] - ignore_thresh).abs().max()))
+        if truth_thresh is not None and truth_thresh < 1:
+            bad = (iou_own > truth_thresh) != tru
+            if bool(bad.any()):
+                d = max(d, float((iou_own[bad] - truth_thresh).abs().max()))
         stats["disagree"] = max(stats.get("disagree", 0.0), d)
     return torch.nn.functional.one_hot(idx, bbox_num).to(iou_own.dtype), src
 
@@ -113,9 +135,7 @@ def wrap_yolo_loss_v3(grid_shape, bbox_num, class_num, anchors=None, binary_weig
         xywh_true = y_true_[..., :4]
         xywh_pred = y_pred_[..., :4]
         iou_scores = cal_iou(xywh_true, xywh_pred, grid_shape).detach()
-        dec = None if decide_with is None else cal_iou(
-            xywh_true, decide_with.reshape(y_pred_.shape).to(dt)[..., :4], grid_shape).detach()
-        response_mask, iou_scores = _decisions(iou_scores, dec, bbox_num, stats, (ignore_thresh,))
+        response_mask, iou_scores = _decisions(iou_scores, decide_with, bbox_num, stats, ignore_thresh)
         has_obj_mask = y_true_[..., 4] * response_mask
         has_obj_mask_exp = has_obj_mask.unsqueeze(-1)
         no_obj_mask = (iou_scores < ignore_thresh).to(dt)
@@ -162,9 +182,7 @@ def wrap_yolo_loss_v2(grid_shape, bbox_num, class_num, anchors, binary_weight=1,
         y_true_ = y_true.reshape(-1, *grid_shape, 1, 5 + class_num).to(dt)
         y_pred_ = y_pred.reshape(-1, *grid_shape, bbox_num, 5 + class_num)
         iou_scores = cal_iou(y_true_[..., :4], y_pred_[..., :4], grid_shape).detach()
-        dec = None if decide_with is None else cal_iou(
-            y_true_[..., :4], decide_with.reshape(y_pred_.shape).to(dt)[..., :4], grid_shape).detach()
-        response_mask, iou_scores = _decisions(iou_scores, dec, bbox_num, stats, (ignore_thresh,))
+        response_mask, iou_scores = _decisions(iou_scores, decide_with, bbox_num, stats, ignore_thresh)
         has_obj_mask = y_true_[..., 4] * response_mask
         has_obj_mask_exp = has_obj_mask.unsqueeze(-1)
         no_obj_mask = (1 - has_obj_mask) * (iou_scores < ignore_thresh).to(dt)
@@ -196,10 +214,7 @@ def wrap_yolo_loss_v4(grid_shape, bbox_num, class_num, anchors=None, binary_weig
         y_pred_ = y_pred.reshape(-1, *grid_shape, bbox_num, 5 + class_num)
         iou_scores, ciou_scores = cal_iou(y_true_[..., :4], y_pred_[..., :4], grid_shape, return_ciou=True)
         iou_const = iou_scores.detach()
-        dec = None if decide_with is None else cal_iou(
-            y_true_[..., :4], decide_with.reshape(y_pred_.shape).to(dt)[..., :4], grid_shape).detach()
-        response_mask, iou_const = _decisions(iou_const, dec, bbox_num, stats,
-                                              (ignore_thresh,) + ((truth_thresh,) if truth_thresh < 1 else ()))
+        response_mask, iou_const = _decisions(iou_const, decide_with, bbox_num, stats, ignore_thresh, truth_thresh)
         has_obj_mask = y_true_[..., 4] * response_mask
         if truth_thresh < 1:
             truth_mask = (iou_const > truth_thresh).to(dt)
@@ -234,9 +249,7 @@ def wrap_yolo_loss_v1(grid_shape, bbox_num, class_num, binary_weight=1, loss_wei
         xywhc_true = y_true[..., :-class_num].reshape(-1, *grid_shape, 1, 5)
         xywhc_pred = y_pred[..., :-class_num].reshape(-1, *grid_shape, bbox_num, 5)
         iou_scores = cal_iou(xywhc_true, xywhc_pred, grid_shape)   # differentiated (loss.py:86-91)
-        dec = None if decide_with is None else cal_iou(
-            xywhc_true, decide_with.to(dt)[..., :-class_num].reshape(xywhc_pred.shape), grid_shape).detach()
-        response_mask, _ = _decisions(iou_scores.detach(), dec, bbox_num, stats)
+        response_mask, _ = _decisions(iou_scores.detach(), decide_with, bbox_num, stats)
         response_mask_exp = response_mask.unsqueeze(-1)
         has_obj_mask = xywhc_true[..., 4]
         has_obj_mask_exp = has_obj_mask.unsqueeze(-1)

@@ -32,7 +32,9 @@ from tf2_yolo_amd import optimizers
 model.compile(optimizer=optimizers.Adam(1e-3), loss=loss_g)
 outs = net.forward(torch.tensor(x).cuda(), training=True)
 masks = T._gpu_leaky_masks(net)
-dp = [lf.fwd_bwd(torch.tensor(yt).cuda(), o)[1] for lf, o, yt in zip(loss_g, outs, ys)]
+decs = [torch.zeros((o.shape[0] * o.shape[1] * o.shape[2], 2), dtype=torch.int32, device="cuda") for o in outs]
+dp = [lf.fwd_bwd(torch.tensor(yt).cuda(), o, decisions=dc)[1] for lf, o, yt, dc in zip(loss_g, outs, ys, decs)]
+decs = [d.cpu() for d in decs]
 net.backward(dp)
 torch.cuda.synchronize()
 g = net.grads.cpu().numpy()
@@ -44,8 +46,7 @@ def oracle(dtype, threads=None):
         torch.set_num_threads(threads)
     wt = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in w.items()}
     out, ctx = fwd(wt, torch.tensor(x, dtype=dtype), True, masks)
-    tot = sum(lf(torch.tensor(yt, dtype=dtype), o, decide_with=torch.tensor(d, dtype=dtype))
-              for lf, yt, o, d in zip(loss_o, ys, out, dev_out))
+    tot = sum(lf(torch.tensor(yt, dtype=dtype), o, decide_with=dc) for lf, yt, o, dc in zip(loss_o, ys, out, decs))
     tot.backward()
     return wt, [o.detach().double().numpy() for o in out], ctx
 

@@ -110,6 +110,7 @@ struct LossParams {
   yolo_loss_cfg c;
   long long cells;
   float inv_n;  // grad_scale / N
+  int* dec;     // optional [cells][2]: the discrete decisions of every cell (see yolo_loss_fwd_bwd in yolo_hip.h)
 };
 
 // parts: [0] total (weighted), then per-version diagnostics (see yolo_hip.h)
@@ -162,6 +163,17 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
       if (ib > best) {
         best = ib;
         resp = b;
+      }
+    }
+
+    if (lp.dec != nullptr) {
+      // the decisions a second execution can only reproduce by being told: [0] responsible anchor, [1] bit b = "anchor b is
+      // below ignore_thresh", bit 16 + b = "anchor b is above truth_thresh" (tests force the oracle's decisions to these)
+      const unsigned long long ign = __ballot(lane < A && iou < c.ignore_thresh);
+      const unsigned long long tru = __ballot(lane < A && iou > c.truth_thresh);
+      if (lane == 0) {
+        lp.dec[cell * 2] = resp;
+        lp.dec[cell * 2 + 1] = (int)((unsigned)(ign & 0xffffu) | ((unsigned)(tru & 0xffffu) << 16));
       }
     }
 
@@ -465,14 +477,15 @@ extern "C" size_t yolo_loss_workspace_bytes(const yolo_loss_cfg* cfg) {
 extern "C" int yolo_loss_fwd_bwd(const yolo_loss_cfg* cfg, const float* y_true, const float* y_pred, double* loss_out,
                                  float* dpred, float grad_scale, void* workspace, size_t workspace_bytes,
                                  void* stream) {
-  (void)workspace;
-  (void)workspace_bytes;
   if (int rc = validate_cfg(cfg)) return rc;
   YOLO_REQUIRE(y_true && y_pred && loss_out, "loss: null pointer");
   LossParams lp;
   lp.c = *cfg;
   lp.cells = (long long)cfg->N * cfg->gh * cfg->gw;
   lp.inv_n = grad_scale / (float)cfg->N;
+  // the kernel needs no scratch; a workspace of at least 8 bytes per cell receives the cells' discrete decisions
+  lp.dec = (workspace != nullptr && workspace_bytes >= (size_t)lp.cells * 8 && cfg->A <= 16) ? reinterpret_cast<int*>(workspace)
+                                                                                              : nullptr;
   hipStream_t st = as_stream(stream);
   if (hipMemsetAsync(loss_out, 0, 8 * sizeof(double), st) != hipSuccess) {
     set_error("loss: memset failed");

@@ -62,9 +62,10 @@ class YoloLoss:
         N = yt.numel() // (cells * (5 + self.class_num))
         return yt, yp, N
 
-    def fwd_bwd(self, y_true, y_pred, grad_scale=1.0, dpred=None, loss_out=None):
+    def fwd_bwd(self, y_true, y_pred, grad_scale=1.0, dpred=None, loss_out=None, decisions=None):
         yt, yp, N = self._prep(y_true, y_pred)
-        return ops.loss_fwd_bwd(self.cfg(N), yt, yp, loss_out=loss_out, dpred=dpred, grad_scale=grad_scale)
+        return ops.loss_fwd_bwd(self.cfg(N), yt, yp, loss_out=loss_out, dpred=dpred, grad_scale=grad_scale,
+                                decisions=decisions)
 
     def parts(self, y_true, y_pred):
         yt, yp, N = self._prep(y_true, y_pred)

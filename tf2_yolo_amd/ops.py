@@ -724,7 +724,9 @@ def make_loss_cfg(version, N, gh, gw, A, C, anchors=None, binary_weight=1.0, los
     return cfg
 
 
-def loss_fwd_bwd(cfg, y_true, y_pred, loss_out=None, dpred=None, grad_scale=1.0, want_grad=True):
+def loss_fwd_bwd(cfg, y_true, y_pred, loss_out=None, dpred=None, grad_scale=1.0, want_grad=True, decisions=None):
+    """decisions (optional): int32 CUDA tensor [cells, 2] that receives every cell's responsible anchor and its ignore /
+    truth mask bits as this execution decided them (include/yolo_hip.h; parity tests)"""
     _chk_f32(y_true, y_pred, dpred)
     cells = cfg.N * cfg.gh * cfg.gw
     pd = (5 * cfg.A + cfg.C) if cfg.version == 1 else cfg.A * (5 + cfg.C)
@@ -734,9 +736,11 @@ def loss_fwd_bwd(cfg, y_true, y_pred, loss_out=None, dpred=None, grad_scale=1.0,
         loss_out = torch.empty(8, device=y_pred.device, dtype=torch.float64)
     if want_grad and dpred is None:
         dpred = torch.empty_like(y_pred)
+    if decisions is not None and (decisions.dtype != torch.int32 or decisions.numel() < 2 * cells or not decisions.is_cuda):
+        raise YoloHipError("loss: decisions must be an int32 CUDA tensor with 2 entries per cell")
     check(_lib.load().yolo_loss_fwd_bwd(byref(cfg), _p(y_true), _p(y_pred), _p(loss_out),
-                                        _p(dpred if want_grad else None), float(grad_scale), c_void_p(0), 0,
-                                        _stream()), "yolo_loss_fwd_bwd")
+                                        _p(dpred if want_grad else None), float(grad_scale), _p(decisions),
+                                        0 if decisions is None else decisions.numel() * 4, _stream()), "yolo_loss_fwd_bwd")
     return loss_out, dpred
 
 
