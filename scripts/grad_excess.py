@@ -46,7 +46,9 @@ def oracle(dtype, threads=None):
         torch.set_num_threads(threads)
     wt = {k: torch.tensor(v, dtype=dtype, requires_grad=True) for k, v in w.items()}
     out, ctx = fwd(wt, torch.tensor(x, dtype=dtype), True, masks)
-    tot = sum(lf(torch.tensor(yt, dtype=dtype), o, decide_with=dc) for lf, yt, o, dc in zip(loss_o, ys, out, decs))
+    # (loss gradient taken at the DEVICE's predictions, straight-through: see tests/test_gpu_model.py)
+    tot = sum(lf(torch.tensor(yt, dtype=dtype), o + (torch.tensor(d, dtype=dtype) - o).detach(), decide_with=dc)
+              for lf, yt, o, dc, d in zip(loss_o, ys, out, decs, dev_out))
     tot.backward()
     return wt, [o.detach().double().numpy() for o in out], ctx
 
