@@ -186,6 +186,14 @@ int yolo_conv2d_fwd_planes_epi(const yolo_conv_desc* d, const void* x_planes, co
                                unsigned* absmax, void* stream);
 int yolo_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax, const float* extra_bound,
                              void* planes, float* out_bound, void* stream);
+/* Concatenate (keras.layers.Concatenate on channels: yolov3/models/darknet.py:88,93; the CSP / SPP / PAN concats of
+ * yolov4/models/backbone.py:141,183, yolov4/models/darknet.py:97-127; the passthrough of yolov2/models/darknet.py:49) straight
+ * into the planes of the result: up to four dense fp32 sources [rows][channels_host[i]] (multiples of 8; the sum a multiple
+ * of 16), each with ONE device float bounds_host[i] >= max|source| (what its producer recorded), become planes [rows][sum]
+ * in one pass; the bound of the result (the largest source bound) goes to *out_bound (optional). dst32 (optional) also
+ * receives the fp32 concatenation. The three *_host arguments are HOST arrays of nsrc entries (device pointers inside). */
+int yolo_split_planes_concat(const float* const* srcs_host, const int* channels_host, const float* const* bounds_host,
+                             int nsrc, long long rows, void* planes, float* dst32, float* out_bound, void* stream);
 /* yolo_conv2d_wgrad on pre-split operands (dw += ..., same contract; the bias gradient stays with
  * yolo_conv2d_wgrad_bias on the fp32 dy). Requires Cin % 16 == 0, Cout % 16 == 0, Cout >= 32, kh*kw*Cin >= 64. */
 int yolo_conv2d_wgrad_planes(const yolo_conv_desc* d, const void* x_planes, const void* dy_planes,

@@ -286,3 +286,35 @@ def test_bn_act_fwd_residual_from_planes(C, act):
     assert ops.bn_act_fwd(x, C, scale, shift, act, None, planes=pl3, bn_bound=bnb, want_out=False, residual_planes=rpl) is None
     torch.cuda.synchronize()
     assert torch.equal(pl3, pl)
+
+
+@pytest.mark.parametrize("chans", [(256, 128), (512, 512, 512, 512), (64,), (24, 40)])
+def test_split_planes_concat(chans):
+    """yolo_split_planes_concat: up to four fp32 sources -> the planes of their channel concatenation in one pass, the scale
+    from the sources' RECORDED bounds (loose on purpose here: 3x the true maximum). A 1x1 convolution on those planes equals
+    the convolution of the concatenated tensor to fp32 summation accuracy; the optional fp32 output is the exact
+    concatenation; the result's bound is the largest source bound."""
+    from tf2_yolo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(4)
+    n, h, w = 2, 13, 19
+    rows = n * h * w
+    srcs = [torch.randn(rows, c, device="cuda", generator=g) * (1.0 + 3.0 * i) for i, c in enumerate(chans)]
+    bounds = [(t.abs().max() * 3.0).reshape(1) for t in srcs]
+    C = sum(chans)
+    pl = torch.zeros(ops.planes_bytes(rows, C), device="cuda", dtype=torch.uint8)
+    d32 = torch.empty(rows, C, device="cuda")
+    ob = torch.zeros(1, device="cuda")
+    ops.split_planes_concat(srcs, list(chans), bounds, rows, pl, dst32=d32, out_bound=ob)
+    cat = torch.cat(srcs, dim=1)
+    assert torch.equal(d32, cat)
+    assert abs(float(ob) - float(max(b.item() for b in bounds)) * 1.001) <= 1e-5 * float(ob)
+    cout = 64
+    wk = torch.randn(cout, C, device="cuda", generator=g) / C ** 0.5
+    d = ops.conv_desc((n, h, w, C), cout, 1, 1, 1, "same")
+    y = ops.conv2d_fwd_planes(d, pl, ops.split_planes(wk, cout, C))
+    ref = cat.double() @ wk.double().t()
+    assert (y.reshape(rows, cout).double() - ref).abs().max().item() / ref.abs().max().item() < 2e-6
+    # without the fp32 output, planes only
+    pl2 = torch.zeros_like(pl)
+    ops.split_planes_concat(srcs, list(chans), bounds, rows, pl2)
+    assert torch.equal(pl, pl2)

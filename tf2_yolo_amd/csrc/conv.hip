@@ -845,6 +845,22 @@ extern "C" int yolo_split_planes_absmax(const float* x, long long rows, int C, c
   return launch_split_planes_absmax(x, rows, C, absmax, extra_bound, planes, out_bound, as_stream(stream));
 }
 
+extern "C" int yolo_split_planes_concat(const float* const* srcs_host, const int* channels_host,
+                                        const float* const* bounds_host, int nsrc, long long rows, void* planes, float* dst32,
+                                        float* out_bound, void* stream) {
+  YOLO_REQUIRE(srcs_host && channels_host && bounds_host && planes && nsrc >= 1 && nsrc <= 4 && rows > 0,
+               "split_planes_concat: 1..4 sources, non-null tables");
+  int C = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    YOLO_REQUIRE(srcs_host[i] && bounds_host[i] && channels_host[i] > 0 && (channels_host[i] % 8) == 0,
+                 "split_planes_concat: every source needs a pointer, a bound and a channel count that is a multiple of 8");
+    C += channels_host[i];
+  }
+  YOLO_REQUIRE((C % 16) == 0, "split_planes_concat: the concatenated channel count must be a multiple of 16");
+  return launch_split_planes_concat(srcs_host, channels_host, bounds_host, nsrc, rows, planes, dst32, out_bound,
+                                    as_stream(stream));
+}
+
 extern "C" size_t yolo_planes_bytes(long long rows, int C) {
   if (rows <= 0 || C <= 0 || (C % 16) != 0) return 0;
   return (size_t)planes_bytes(rows, C);

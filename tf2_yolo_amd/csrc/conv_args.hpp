@@ -108,6 +108,8 @@ long long planes_bytes(long long rows, int C);
 int launch_split_planes(const float* x, long long rows, int C, void* planes, hipStream_t st);
 int launch_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax, const float* extra_bound,
                                void* planes, float* out_bound, hipStream_t st);
+int launch_split_planes_concat(const float* const* xs, const int* Cs, const float* const* bounds, int nsrc, long long rows,
+                               void* planes, float* dst32, float* out_bound, hipStream_t st);
 int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, void* planes, hipStream_t st);
 int launch_split_planes_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);

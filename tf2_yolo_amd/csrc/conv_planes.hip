@@ -124,6 +124,77 @@ __global__ __launch_bounds__(256) void split_planes_absmax_kernel(const float* _
   }
 }
 
+// Channel concatenation straight into planes: up to four dense fp32 sources [rows][C_s] (C_s % 8 == 0) become the planes of
+// [rows][sum C_s] in ONE pass -- no fp32 copy of the concatenated tensor, no max pass: the bound is the largest of the
+// sources' recorded bounds (each source left one float behind: BatchNorm's output bound, or its input's for pools /
+// upsampling). Replaces copy_channels_in x nsrc + planes_amax + split_planes (20 B per element moved) by 8 B per element.
+// Optionally (dst32 != nullptr) the fp32 concatenation is written as well, for consumers that are not planes convolutions.
+struct ConcatSrcs {
+  const float* x[4];
+  const float* bound[4];
+  int g_end[4];   // exclusive prefix ends in 8-channel groups
+  int C[4];
+  int n;
+};
+__global__ __launch_bounds__(256) void split_planes_concat_kernel(const ConcatSrcs cs, long long rows, int C,
+                                                                 unsigned char* __restrict__ out, long long rows_padded,
+                                                                 float* __restrict__ dst32, float* __restrict__ out_bound) {
+  float b = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    if (i < cs.n) b = fmaxf(b, cs.bound[i][0]);
+  const float bound = b * 1.001f + 1e-30f;
+  unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
+  const float sc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bound));
+  const int G = C >> 3;
+  const int gbn = (G + 15) >> 4;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    header[0] = __builtin_bit_cast(unsigned, bound);
+    reinterpret_cast<float*>(header)[1] = sc;
+    reinterpret_cast<float*>(header)[2] = 1.f / sc;
+    if (out_bound != nullptr) out_bound[0] = bound;
+  }
+  const long long rb = blockIdx.x / gbn;
+  const int g = (int)(blockIdx.x - rb * gbn) * 16 + (threadIdx.x >> 4);
+  if (g >= G) return;
+  // which source owns channel group g
+  int si = 0, g0 = 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+    if (i + 1 < cs.n && g >= cs.g_end[i]) {
+      si = i + 1;
+      g0 = cs.g_end[i];
+    }
+  const float* src = cs.x[si];
+  const int Cs = cs.C[si];
+  const long long row0 = rb * (16 * SPLIT_BLOCKS_PER_WG) + (threadIdx.x & 15);
+  f32x4 v[SPLIT_BLOCKS_PER_WG][2];
+#pragma unroll
+  for (int u = 0; u < SPLIT_BLOCKS_PER_WG; ++u) {
+    const long long row = row0 + 16 * u;
+    v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row < rows) {
+      const float* p = src + row * Cs + (g - g0) * 8;
+      v[u][0] = *reinterpret_cast<const f32x4*>(p);
+      v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < SPLIT_BLOCKS_PER_WG; ++u) {
+    const long long row = row0 + 16 * u;
+    if (row >= rows_padded) continue;
+    const Planes8 sp = split8(v[u][0], v[u][1], sc);
+    unsigned char* o = out + planes_unit_offset(row, g, C);
+    *reinterpret_cast<u32x4*>(o) = sp.h;
+    *reinterpret_cast<u32x4*>(o + 512) = sp.l;
+    if (dst32 != nullptr && row < rows) {
+      float* q = dst32 + row * C + g * 8;
+      *reinterpret_cast<f32x4*>(q) = v[u][0];
+      *reinterpret_cast<f32x4*>(q + 4) = v[u][1];
+    }
+  }
+}
+
 // Dense [rows][Csrc] source with Csrc < C = Csrc rounded up to 16 (the 255-channel head gradients): scalar loads,
 // columns >= Csrc of the planes are zero.
 __global__ __launch_bounds__(256) void planes_amax_scalar_kernel(const float* __restrict__ x, long long n,
@@ -532,6 +603,30 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
     if (a.ncls <= 1 && conv_split_parts(a, nb, 128, min_cb, 4) > 1) return launch_planes<128, 128, 2, 2>(a, st);
   }
   return launch_planes<128, 128, 4, 2>(a, st);
+}
+
+int launch_split_planes_concat(const float* const* xs, const int* Cs, const float* const* bounds, int nsrc, long long rows,
+                               void* planes, float* dst32, float* out_bound, hipStream_t st) {
+  ConcatSrcs cs{};
+  int C = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    cs.x[i] = xs[i];
+    cs.bound[i] = bounds[i];
+    cs.C[i] = Cs[i];
+    C += Cs[i];
+    cs.g_end[i] = C >> 3;
+  }
+  cs.n = nsrc;
+  const long long rows_padded = ((rows + 15) / 16 + 1) * 16;   // data blocks + the all-zero block
+  const int G = C >> 3;
+  const long long blocks = ((rows_padded + 16 * SPLIT_BLOCKS_PER_WG - 1) / (16 * SPLIT_BLOCKS_PER_WG)) * ((G + 15) >> 4);
+  if (blocks <= 0 || blocks > 0x7fffffffLL) {
+    set_error("split_planes_concat: bad grid %lld", blocks);
+    return YOLO_ERR_INVALID_ARG;
+  }
+  hipLaunchKernelGGL(split_planes_concat_kernel, dim3((unsigned)blocks), dim3(256), 0, st, cs, rows, C,
+                     reinterpret_cast<unsigned char*>(planes), rows_padded, dst32, out_bound);
+  return check_launch("split_planes_concat_kernel");
 }
 
 // ---- batched forms: one launch for all the filters of a network (150 launches of ~5 us otherwise) ----

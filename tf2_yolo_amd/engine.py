@@ -388,6 +388,20 @@ class Network:
                 has_planes_src = any(c.kind in ("conv", "head") and c.src.tid == u.out.tid and c.planes_fwd for c in cs)
                 u.a_needed = ((not cs) or (u.out.tid in out_tids) or u.cout % 16 != 0 or not has_planes_src
                               or any(not reads_planes_only(c) for c in cs))
+        # concat units write the planes of their result directly from the fp32 sources (yolo_split_planes_concat): the fp32
+        # concatenation is produced only if somebody other than a planes convolution reads it; a source's bound is the one
+        # its producer recorded -- BatchNorm's output bound, or, through pools / upsampling / space-to-depth (which cannot
+        # increase max|x|), their input's
+        self._concat_planes = os.environ.get("YOLO_CONCAT_PLANES", "1") != "0"
+        self._bound_alias = {}
+        for u in self.units:
+            if u.kind in ("upsample", "maxpool", "space_to_depth"):
+                self._bound_alias[u.out.tid] = self._bound_alias.get(u.src.tid, u.src.tid)
+            elif u.kind == "concat":
+                cs = consumers.get(u.out.tid, [])
+                u.f32_needed = (u.out.tid in out_tids) or (not cs) or any(
+                    not (c.kind in ("conv", "head") and c.src.tid == u.out.tid and c.planes_fwd and c.planes_wgrad
+                         and getattr(c, "residual", None) is not u.out) for c in cs)
         self._wp_valid = False
         self._wTp_valid = False
         self._jobs_wp = self._jobs_wTp = self._jobs_wT = None
@@ -726,6 +740,18 @@ class Network:
             elif u.kind == "upsample":
                 ops.upsample2x_fwd(self.act[u.src.tid], u.buf, u.out.c, 0)
             elif u.kind == "concat":
+                pl = self._xplanes.get(u.out.tid) if self._concat_planes else None
+                slots = [self._bound_alias.get(s.tid, s.tid) for s in u.srcs]
+                if (pl is not None and len(u.srcs) <= 4 and all(sl in self._tbound_set for sl in slots)
+                        and all(s.c % 8 == 0 for s in u.srcs)):
+                    tb = self._tbound
+                    ops.split_planes_concat([self.act[s.tid] for s in u.srcs], [s.c for s in u.srcs],
+                                            [tb[sl:sl + 1] for sl in slots], self.batch * u.out.h * u.out.w, pl,
+                                            dst32=u.buf if u.f32_needed else None,
+                                            out_bound=tb[u.out.tid:u.out.tid + 1])
+                    self._xp_valid.add(u.out.tid)
+                    self._tbound_set.add(u.out.tid)
+                    continue
                 off = 0
                 for s in u.srcs:
                     ops.copy_channels_in(self.act[s.tid], s.c, u.buf, u.out.c, off)

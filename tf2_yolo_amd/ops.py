@@ -379,6 +379,27 @@ def split_planes_absmax(x, rows, c, absmax, planes, extra_bound=None, out_bound=
     return planes
 
 
+def split_planes_concat(srcs, channels, bounds, rows, planes, dst32=None, out_bound=None):
+    """channel concatenation of up to four fp32 [rows][C_i] tensors straight into planes [rows][sum C_i]; bounds: one
+    device float per source (>= max|source|); the result's bound -> out_bound (include/yolo_hip.h: yolo_split_planes_concat)"""
+    n = len(srcs)
+    _chk_f32(*srcs)
+    C = sum(channels)
+    if planes.numel() < planes_bytes(rows, C):
+        raise YoloHipError("split_planes_concat: planes buffer too small")
+    for t, c in zip(srcs, channels):
+        if t.numel() != rows * c:
+            raise YoloHipError("split_planes_concat: source size does not match rows x channels")
+    xs = (c_void_p * n)(*[t.data_ptr() for t in srcs])
+    bs = (c_void_p * n)(*[b.data_ptr() for b in bounds])
+    cs = (ctypes.c_int * n)(*[int(c) for c in channels])
+    if _tape.ACTIVE is not None:
+        _tape.ACTIVE.keep.extend(list(srcs) + list(bounds))
+    check(_lib.load().yolo_split_planes_concat(xs, cs, bs, n, int(rows), _p(planes), _p(dst32), _p(out_bound), _stream()),
+          "yolo_split_planes_concat")
+    return planes
+
+
 def conv2d_dgrad_planes(d, dyp, wTp, dx=None, accumulate=False):
     if dx is None:
         dx = torch.empty((d.N, d.H, d.W, d.Cin), device=dyp.device, dtype=torch.float32)
