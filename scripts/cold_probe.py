@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from tf2_yolo_amd import ops
 N = 32
+RING = float(os.environ.get('COLD_RING_BYTES', '1.5e9'))   # bytes of buffer sets cycled through
 layers = [(52, 256, 128, 1), (26, 512, 256, 1), (104, 128, 64, 1), (52, 128, 256, 3)]
 if len(sys.argv) > 1:
     layers = [tuple(int(v) for v in sys.argv[1].split(","))]
@@ -26,7 +27,7 @@ for (H, cin, cout, k) in layers:
     w = torch.randn(cout, k * k * cin, device="cuda", generator=g) * 0.05
     wp = ops.split_planes(w, cout, k * k * cin)
     nbytes = rows * cin * 4 + rows * cout * 4
-    nsets = max(2, int(1.5e9 // nbytes))
+    nsets = max(2, int(RING // nbytes))
     sets = []
     for i in range(nsets):
         x = torch.randn(rows, cin, device="cuda", generator=g)
@@ -41,7 +42,7 @@ for (H, cin, cout, k) in layers:
           f"cold ({nsets} sets) {cold:.1f} us ({nbytes / cold / 1e6:.2f} TB/s)", flush=True)
     # the BatchNorm forward pass that produces such planes: reads y (fp32), writes planes
     C = cout
-    ys = [torch.randn(N, H, H, C, device="cuda", generator=g) for _ in range(max(2, int(1.5e9 // (rows * C * 8))))]
+    ys = [torch.randn(N, H, H, C, device="cuda", generator=g) for _ in range(max(2, int(RING // (rows * C * 8))))]
     pls = [torch.empty(ops.planes_bytes(rows, C), device="cuda", dtype=torch.uint8) for _ in ys]
     scale, shift = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
     bnd = torch.zeros(4, device="cuda", dtype=torch.int32); bnd[0] = 0x42000000

@@ -726,12 +726,30 @@ __global__ void colsum_kernel(const float* __restrict__ x, long long P, int C, f
   if (part != nullptr) part[((long long)blockIdx.x * blockDim.y + threadIdx.y) * C + c] = s;
   else atomicAdd(&out[c], s);
 }
+// 64 channels x 16 part lanes per block: lane j adds parts j, j + 16, ... (independent chains, four loads in flight each),
+// the 16 lane sums are added in lane order: a fixed order, whatever the number of parts
 __global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s = 0.f;
-  for (int i = 0; i < nparts; ++i) s += part[(long long)i * C + c];
-  out[c] += s;
+  __shared__ float lanes[16][64];
+  const int c = blockIdx.x * 64 + threadIdx.x, j = threadIdx.y;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < C) {
+    int i = j;
+    for (; i + 48 < nparts; i += 64) {
+      s0 += part[(long long)i * C + c];
+      s1 += part[(long long)(i + 16) * C + c];
+      s2 += part[(long long)(i + 32) * C + c];
+      s3 += part[(long long)(i + 48) * C + c];
+    }
+    for (; i < nparts; i += 16) s0 += part[(long long)i * C + c];
+  }
+  lanes[j][threadIdx.x] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (j == 0 && c < C) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += lanes[k][threadIdx.x];
+    out[c] += s;
+  }
 }
 
 }  // namespace yolo
@@ -1069,7 +1087,7 @@ extern "C" int yolo_conv2d_wgrad_bias(const float* dy, long long P, int Cout, fl
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx, gy), block, 0, as_stream(stream), dy, P, Cout, dbias, part);
   if (int rc = check_launch("colsum_kernel")) return rc;
   if (part != nullptr) {
-    hipLaunchKernelGGL(colsum_finish_kernel, dim3((Cout + 63) / 64), dim3(64), 0, as_stream(stream), part,
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((Cout + 63) / 64), dim3(64, 16), 0, as_stream(stream), part,
                        (int)(gx * block.y), Cout, dbias);
     return check_launch("colsum_finish_kernel");
   }

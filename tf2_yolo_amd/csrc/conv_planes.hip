@@ -257,7 +257,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   static_assert(LPW <= 4, "loader layout: slot s = wave + i*NW loads A block s, or B block (s - RBA) % RBB");
   constexpr int ND = PL_PLANES * LPW;   // DMA instructions per wave per stage
   constexpr int STAGE_BYTES = (RBA + RBB) * PL_PLANES * 1024;
-  constexpr int NBUF = 3;
+  constexpr int NBUF = 3 + ((DBG >> 7) & 3);   // (bits 128 / 256: a deeper ring, NBUF - 1 stages in flight -- HBM-bound 1x1 layers)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds_base = (unsigned)(size_t)smem;
@@ -433,10 +433,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   // prologue: stages 0..2 in flight (stages >= nk are dummies that read the zero block, so that every
   // wave always has exactly 2 DMAs per stage on its counter), stage 0's fragments in set 0
   loader_tap();
-  issue_stage(0);
-  issue_stage(1);
-  issue_stage(2);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * ND) : "memory");   // stages 1 and 2 may still fly
+#pragma unroll
+  for (int b = 0; b < NBUF; ++b) issue_stage(b);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * ND) : "memory");   // the later stages may still fly
   __builtin_amdgcn_s_barrier();
   read_frags(0, S0{});
 
@@ -444,7 +443,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   // (into stage kt's buffer: everybody finished reading it before this iteration's barrier)
   auto step = [&](int rbuf, int wbuf, auto CUR, auto NXT) {
     // my pieces of stage kt+1 have landed (those of kt+2 may still fly)
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ND) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ND) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage kt's buffer are done
     if constexpr (!(DBG & 4)) __builtin_amdgcn_s_barrier();
     if constexpr (!(DBG & 2)) read_frags(rbuf, NXT);
@@ -470,9 +469,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   if constexpr (SPLIT)
     store_split_slab<TM, TN>(a, acc, BM * BN * 4, tile * SP + part, wave, lane);
   else if constexpr (MULTI)
-    planes_epilogue<BM, BN, WGM, WGN, 3 * STAGE_BYTES, 0>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid, NoStamp(), &G);
+    planes_epilogue<BM, BN, WGM, WGN, NBUF * STAGE_BYTES, 0>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid, NoStamp(), &G);
   else
-    planes_epilogue<BM, BN, WGM, WGN, 3 * STAGE_BYTES, DBG>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
+    planes_epilogue<BM, BN, WGM, WGN, NBUF * STAGE_BYTES, (DBG & 31)>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
 }
 
 template <int BM, int BN, int WGM, int WGN, int DBG = 0>
@@ -484,7 +483,7 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
     set_error("conv(planes): bad grid %lld", nb);
     return YOLO_ERR_INVALID_ARG;
   }
-  constexpr size_t lds = 3 * (BM / 32 + BN / 32) * PL_PLANES * 1024;
+  constexpr size_t lds = (3 + ((DBG >> 7) & 3)) * (BM / 32 + BN / 32) * PL_PLANES * 1024;
   if constexpr (DBG == 0) {
     if (a.ncls > 1) {   // the parity classes of a strided data gradient in one launch
       long long tm = 0;
@@ -569,6 +568,17 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
     const int rc = launch_conv_win(a, g_opt[OPT_CONV_WIN], st);
     if (rc <= 0) return rc;
   }
+  // 1x1 layers stream their operands once and, inside the training step, find them cold (behind kernels that left the
+  // Infinity Cache full of dirty lines a 52x52 256->128 launch takes 50 us, on warm buffers 36): what bounds them is the
+  // number of bytes in flight, so their DMA ring is deeper -- 5 stages (4 in flight, 80 KB, two workgroups per CU) under
+  // the 128 x 128 tile, 4 under the narrower ones (a fifth costs them a resident workgroup). Same-box A/B of the whole
+  // step: 31.04 -> 30.32 ms. YOLO_PLANES_DEEP = 0 / 1 / 2 forces the number of extra stages.
+  static const int deep_env = [] { const char* e = getenv("YOLO_PLANES_DEEP"); return e ? atoi(e) : -1; }();
+  const int deep = deep_env >= 0 ? deep_env : (a.Cout <= 64 ? 1 : 2);
+  if (deep && a.ntaps == 1 && a.ncls <= 1) {
+    if (a.Cout <= 32) return deep == 1 ? launch_planes<128, 32, 4, 1, 128>(a, st) : launch_planes<128, 32, 4, 1, 256>(a, st);
+    if (a.Cout <= 64) return deep == 1 ? launch_planes<128, 64, 4, 2, 128>(a, st) : launch_planes<128, 64, 4, 2, 256>(a, st);
+  }
   if (a.Cout <= 32) return launch_planes<128, 32, 4, 1>(a, st);
   if (a.Cout <= 64) return launch_planes<128, 64, 4, 2>(a, st);
   // few row tiles (13x13 layers at bs 32: 43): 128x128 tiles leave CUs idle (172 tiles for a 512-channel data
@@ -596,12 +606,17 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   }
 #endif
   if (waves == 2) return launch_planes<128, 128, 2, 1>(a, st);   // 2 waves x (64 x 128): one wave per SIMD, 512 registers
-  if (waves == 4) return launch_planes<128, 128, 2, 2>(a, st);
+  if (waves == 4) {
+    if (deep && a.ntaps == 1) return launch_planes<128, 128, 2, 2, 128>(a, st);
+    return launch_planes<128, 128, 2, 2>(a, st);
+  }
   {   // split-K (launches that leave the chip idle) lives in the 4-wave form
     const long long nb = ((a.M + 127) / 128) * ((a.Cout + 127) / 128);
     const int min_cb = a.ntaps >= 8 ? 1 : (8 + a.ntaps - 1) / a.ntaps;
     if (a.ncls <= 1 && conv_split_parts(a, nb, 128, min_cb, 4) > 1) return launch_planes<128, 128, 2, 2>(a, st);
   }
+  if (deep == 1 && a.ntaps == 1) return launch_planes<128, 128, 4, 2, 128>(a, st);
+  if (deep == 2 && a.ntaps == 1) return launch_planes<128, 128, 4, 2, 256>(a, st);
   return launch_planes<128, 128, 4, 2>(a, st);
 }
 

@@ -22,14 +22,14 @@ namespace yolo {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const WgradArgs a) {
+template <int BM, int BN, int WGM, int WGN, int NB = 3>
+__global__ __launch_bounds__(64 * WGM * WGN, (NB * (BM / 32 + BN / 32) * PL_PLANES * 1024 > 80 * 1024 ? 1 : 2)) void wgrad_planes_kernel(const WgradArgs a) {
   constexpr int NW = WGM * WGN;
   constexpr int TM = BM / WGM / 32;
   constexpr int TN = BN / WGN / 32;
   constexpr int RBA = BM / 32, RBB = BN / 32;
   constexpr int STAGE_BYTES = (RBA + RBB) * PL_PLANES * 1024;
-  constexpr int NBUF = 3;
+  constexpr int NBUF = NB;   // stages of the DMA ring (NB - 1 in flight); 1x1 layers, pure streams, take a deeper one
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds_base = (unsigned)(size_t)smem;
@@ -208,18 +208,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void wgrad_planes_kernel(const W
   using S1 = std::integral_constant<int, 1>;
 
   if (hasB) loader_addr();
-  issue_stage(0);
-  issue_stage(1);
-  issue_stage(2);
-  if (!BOTH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+  for (int b = 0; b < NBUF; ++b) issue_stage(b);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 1) * ND) : "memory");
   __builtin_amdgcn_s_barrier();
   read_frags(0, S0{});
 
   auto step = [&](int rbuf, int wbuf, auto CUR, auto NXT) {
     // my pieces of the next stage have landed (those of the one after may still fly)
-    if (!BOTH) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NBUF - 2) * ND) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of the current stage's buffer are done
     __builtin_amdgcn_s_barrier();
     read_frags(rbuf, NXT);
@@ -322,7 +319,7 @@ void* wgrad_workspace(size_t* bytes) {
   return g_wgrad_ws;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NB = 3>
 static int launch_wp(WgradArgs& a, hipStream_t st) {
   a.tiles_co = (a.Cout + BM - 1) / BM;
   const int cols = a.ntaps * a.Cs;
@@ -338,15 +335,17 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   static int resident = 0;
   if (resident == 0) {
     int per_cu = 0, dev = 0, cus = 0;
-    constexpr size_t lds_q = 3 * (BM / 32 + BN / 32) * PL_PLANES * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN>),
+    constexpr size_t lds_q = NB * (BM / 32 + BN / 32) * PL_PLANES * 1024;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN, NB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN>),
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN, NB>),
                                                      64 * WGM * WGN, lds_q) == hipSuccess &&
         hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
       resident = per_cu * cus;
     if (resident <= 0) resident = 512;
   }
+  // (round 3, slabs instead of atomics, same finding: 512 / 768 workgroups for the 1x1 layers are 12-25 % slower than 256,
+  // and a deeper DMA ring (NB = 4..6) changes nothing: these launches are not bound by bytes in flight)
   long long target = target_env > 0 ? target_env : (a.ntaps == 1 ? 256 : 1024);
   if (target_env <= 0 && a.ntaps > 1) {
     const long long s1 = resident / tiles, s2 = 2LL * resident / tiles;
@@ -378,14 +377,14 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
     return YOLO_ERR_INVALID_ARG;
   }
   a.nblocks = (int)(tiles * splits);
-  constexpr size_t lds = 3 * (BM / 32 + BN / 32) * PL_PLANES * 1024;
+  constexpr size_t lds = NB * (BM / 32 + BN / 32) * PL_PLANES * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN, NB>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_planes_kernel<BM, BN, WGM, WGN>), dim3((unsigned)(tiles * splits)), dim3(64 * WGM * WGN), lds,
+  hipLaunchKernelGGL((wgrad_planes_kernel<BM, BN, WGM, WGN, NB>), dim3((unsigned)(tiles * splits)), dim3(64 * WGM * WGN), lds,
                      st, a);
   if (int rc = check_launch("wgrad_planes_kernel")) return rc;
   if (a.slabs != nullptr) {
