@@ -189,6 +189,10 @@ PLANES_CASES = [
     (2, 51, 53, 160, 32, 1, 1, "same", False),        # 128x32 tile forward; its dgrad: 160 columns
     (3, 60, 60, 64, 64, 3, 2, "darknet_s2", False),   # dgrad: 4 parity classes of 2700 rows (scalar) / fwd 2700 rows
     (2, 72, 72, 48, 64, 3, 1, "same", True),          # 128x64 tile, 10368 rows
+    # stride-2 data gradients with >= 128 output columns: the four parity classes in ONE launch under the 128x128 tile
+    # (class 0 has a single tap there: must not be mistaken for a 1x1 layer)
+    (2, 18, 14, 128, 64, 3, 2, "darknet_s2", False),
+    (2, 17, 13, 160, 96, 3, 2, "same", True),         # odd sizes (classes of different tile counts), column tail
 ]
 
 

@@ -572,7 +572,7 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
   // Infinity Cache full of dirty lines a 52x52 256->128 launch takes 50 us, on warm buffers 36): what bounds them is the
   // number of bytes in flight, so their DMA ring is deeper -- 5 stages (4 in flight, 80 KB, two workgroups per CU) under
   // the 128 x 128 tile, 4 under the narrower ones (a fifth costs them a resident workgroup). Same-box A/B of the whole
-  // step: 31.04 -> 30.32 ms. YOLO_PLANES_DEEP = 0 / 1 / 2 forces the number of extra stages.
+  // step: C3 30.81 -> 30.63 ms, C4 41.35 -> 40.84 ms. YOLO_PLANES_DEEP = 0 / 1 / 2 forces the number of extra stages.
   static const int deep_env = [] { const char* e = getenv("YOLO_PLANES_DEEP"); return e ? atoi(e) : -1; }();
   const int deep = deep_env >= 0 ? deep_env : (a.Cout <= 64 ? 1 : 2);
   if (deep && a.ntaps == 1 && a.ncls <= 1) {
@@ -607,7 +607,8 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
 #endif
   if (waves == 2) return launch_planes<128, 128, 2, 1>(a, st);   // 2 waves x (64 x 128): one wave per SIMD, 512 registers
   if (waves == 4) {
-    if (deep && a.ntaps == 1) return launch_planes<128, 128, 2, 2, 128>(a, st);
+    // (a.ncls > 1: the parity classes of a strided data gradient in one launch -- a.ntaps is class 0's there)
+    if (deep && a.ntaps == 1 && a.ncls <= 1) return launch_planes<128, 128, 2, 2, 128>(a, st);
     return launch_planes<128, 128, 2, 2>(a, st);
   }
   {   // split-K (launches that leave the chip idle) lives in the 4-wave form
@@ -615,8 +616,8 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
     const int min_cb = a.ntaps >= 8 ? 1 : (8 + a.ntaps - 1) / a.ntaps;
     if (a.ncls <= 1 && conv_split_parts(a, nb, 128, min_cb, 4) > 1) return launch_planes<128, 128, 2, 2>(a, st);
   }
-  if (deep == 1 && a.ntaps == 1) return launch_planes<128, 128, 4, 2, 128>(a, st);
-  if (deep == 2 && a.ntaps == 1) return launch_planes<128, 128, 4, 2, 256>(a, st);
+  if (deep == 1 && a.ntaps == 1 && a.ncls <= 1) return launch_planes<128, 128, 4, 2, 128>(a, st);
+  if (deep == 2 && a.ntaps == 1 && a.ncls <= 1) return launch_planes<128, 128, 4, 2, 256>(a, st);
   return launch_planes<128, 128, 4, 2>(a, st);
 }
 
