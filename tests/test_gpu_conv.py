@@ -602,6 +602,90 @@ def test_conv_fused_inference_epilogue(act, with_res, case):
 
 @pytest.mark.parametrize("shape", [(2, 37, 45), (1, 16, 16), (3, 130, 127), (2, 21, 400), (1, 50, 50)])
 @pytest.mark.parametrize("act", ["leaky", "mish"])
+def _planes_values(pl, rows, c):
+    """the fp64 values a planes buffer holds ((h + l) / scale) and its header (bound, scale)"""
+    nblk = (rows + 15) // 16
+    body = (nblk + 1) * (c // 16) * 1024
+    hdr = pl[body:body + 12].view(torch.float32)
+    u = pl[:body].view(torch.float16).reshape(nblk + 1, c // 16, 2, 2, 16, 8)
+    f = u.permute(2, 0, 4, 1, 3, 5).reshape(2, (nblk + 1) * 16, c).double()
+    return (f[0] + f[1])[:rows] / float(hdr[1]), float(hdr[0]), float(hdr[1]), f[:, rows:]
+
+
+@pytest.mark.parametrize("case,with_res,expect_onepass", [
+    ((1, 13, 13, 512, 1024, 3, 1, "same", False), True, True),    # window kernel, split-K: the reduce kernel writes the planes
+    ((1, 26, 26, 512, 256, 1, 1, "same", False), False, True),   # per-tap kernel, split-K
+    ((1, 52, 52, 128, 256, 3, 1, "same", True), True, True),     # conv bias in front of the folded BatchNorm
+    ((1, 19, 19, 128, 96, 3, 1, "same", False), True, True),     # rows not a multiple of 16, column tail (96 = 64 + 32)
+    ((16, 52, 52, 64, 128, 3, 1, "same", False), True, False),   # tiles fill the chip: two passes inside the call
+])
+def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
+    """yolo_conv2d_fwd_infer_unit: y bit-identical to the fused-epilogue convolution, its planes (scaled by the a-priori
+    bound K max|x| + D + max|residual|, yolo_conv_pred_bound) hold y to the format's 22 bits, the recorded bound of the
+    result is max|y| (one pass) or an upper bound of it (two passes inside the call)"""
+    from tf2_yolo_amd import ops
+    ops.ensure_conv_workspace()   # (split-K needs its slabs: the engine registers them when a network is built)
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=21)
+    g = torch.Generator().manual_seed(22)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    rows = n * d.Ho * d.Wo
+    xd, wd = x.float().cuda(), _krsc(wk).float().cuda()
+    bd = None if b is None else b.float().cuda()
+    scale = (torch.rand(cout, generator=g) + 0.5).float().cuda() * torch.where(torch.rand(cout, generator=g) < 0.2, -1.0, 1.0).cuda()
+    shift = torch.randn(cout, generator=g).float().cuda() * 0.3
+    res = torch.randn(n, d.Ho, d.Wo, cout, generator=g).float().cuda() * 2.0 if with_res else None
+    xp = ops.split_planes(xd, n * h * w, cin)
+    wp = ops.split_planes(wd, cout, k * k * cin)
+    amax0 = torch.zeros(cout, device="cuda", dtype=torch.int32)
+    y_ref = ops.conv2d_fwd_planes_epi(d, xp, wp, bd, ops.EPI_AFFINE_LEAKY, scale, shift, residual=res, absmax=amax0)
+    in_bound = xd.abs().max().reshape(1)
+    res_bound = res.abs().max().reshape(1) if with_res else None
+    pred = torch.zeros(2, device="cuda")
+    ops.conv_pred_bound(wd, cout, k * k * cin, scale, shift, bd, pred)
+    l1 = wd.double().abs().reshape(cout, -1).sum(1)
+    K_ref = float((scale.double().abs() * l1).max())
+    D_ref = float((scale.double() * (bd.double() if bd is not None else 0.0) + shift.double()).abs().max())
+    assert K_ref <= float(pred[0]) <= K_ref * (1 + 1e-5) and D_ref <= float(pred[1]) <= D_ref * (1 + 1e-5) + 1e-30
+    amax = torch.zeros(cout, device="cuda", dtype=torch.int32)
+    y = torch.empty_like(y_ref)
+    pl = torch.zeros(ops.planes_bytes(rows, cout), device="cuda", dtype=torch.uint8)
+    out_bound = torch.zeros(1, device="cuda")
+    out_slots = torch.zeros(64, device="cuda", dtype=torch.int32)
+    # the input's bound as 64 slot words (what another one-pass unit leaves), the residual's as one float
+    in_slots = torch.zeros(64, device="cuda")
+    in_slots[torch.randint(0, 64, (5,), generator=g)] = in_bound * 0.5
+    in_slots[17] = in_bound
+    onepass = ops.conv2d_fwd_infer_unit(d, xp, wp, bd, ops.EPI_AFFINE_LEAKY, scale, shift, res, y, amax, pred,
+                                        in_slots.view(torch.int32), res_bound, pl, out_slots, out_bound)
+    torch.cuda.synchronize()
+    assert onepass == expect_onepass
+    assert torch.equal(y, y_ref)
+    ymax = float(y.abs().max())
+    vals, bound, sc, tail = _planes_values(pl.cpu(), rows, cout)
+    assert bound >= ymax and 2.0 ** 14 < sc * bound <= 2.0 ** 15
+    assert (tail == 0).all()
+    yd = y.double().cpu().reshape(rows, cout)
+    err = (vals - yd).abs()
+    assert (err <= torch.maximum(2.0 ** -22 * yd.abs(), torch.tensor(2.0 ** -25 / sc, dtype=torch.float64))).all()
+    if onepass:
+        assert float(out_slots.view(torch.float32).max()) == ymax and not bool(amax.any())
+        folded = torch.zeros(1, device="cuda")
+        ops.fold_bound(out_slots, folded)
+        assert float(folded) == ymax
+    else:
+        ob = float(out_bound)
+        assert torch.equal(amax, amax0)
+        assert ymax <= ob <= (ymax + (float(res_bound) if with_res else 0.0)) * 1.002 + 1e-30
+    # the consumer's view: a 1x1 convolution on these planes against the same convolution on planes split from y
+    w2 = (torch.randn(32, cout, generator=g) * 0.05).float().cuda()
+    w2p = ops.split_planes(w2, 32, cout)
+    d2 = ops.conv_desc((n, d.Ho, d.Wo, cout), 32, 1, 1, 1, "same")
+    z1 = ops.conv2d_fwd_planes(d2, pl, w2p)
+    z2 = ops.conv2d_fwd_planes(d2, ops.split_planes(y, rows, cout), w2p)
+    assert _relerr(z1.double(), z2.double()) < 2e-6
+
+
 def test_stem_backward_fused(shape, act):
     """yolo_stem_bn_bwd_wgrad (csrc/stem.hip): the BatchNorm / activation backward apply and the filter gradient of the
     stem unit in one pass. Against the unfused device path (yolo_bn_act_bwd_apply, then yolo_conv2d_wgrad on the dy it

@@ -329,13 +329,6 @@ static inline RowGeom row_geom(long long rows, int C) {
   return g;
 }
 
-__device__ __forceinline__ void store_planes8(unsigned char* planes, long long row, int g8, int C, const f32x4 v0,
-                                              const f32x4 v1, const float sc) {
-  const Planes8 s = split8(v0, v1, sc);
-  unsigned char* o = planes + planes_unit_offset(row, g8, C);
-  *reinterpret_cast<u32x4*>(o) = s.h;
-  *reinterpret_cast<u32x4*>(o + 512) = s.l;
-}
 // every thread derives the tensor's scale from the bound; one thread completes the planes header
 __device__ __forceinline__ float planes_begin(unsigned char* planes, long long P, int C, float bound) {
   const unsigned bits = __builtin_bit_cast(unsigned, bound);

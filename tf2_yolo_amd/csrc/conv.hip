@@ -752,6 +752,41 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts,
   }
 }
 
+// out[0] = max of n <= 64 non-negative floats (the slots of a one-pass inference unit, GatherConvArgs::pl_out_slots)
+__global__ void fold_bound_kernel(const unsigned* __restrict__ words, int n, float* __restrict__ out) {
+  float v = (int)threadIdx.x < n ? __builtin_bit_cast(float, words[threadIdx.x]) : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if (threadIdx.x == 0) out[0] = v;
+}
+
+// K = max_c |scale_c| * sum_j |w[c][j]|, D = max_c |scale_c * bias_c + shift_c| of one conv-BN unit (inference): then
+// |act(scale * (conv(x) + bias) + shift)| <= K * max|x| + D for LeakyReLU, Mish and the identity (|act(z)| <= |z|).
+// One workgroup per output channel, the row sum in fp64, out2 = {bits(K), bits(D)} by atomicMax (zeroed by the caller).
+__global__ __launch_bounds__(256) void conv_pred_bound_kernel(const float* __restrict__ w, int kdim,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ bias, unsigned* __restrict__ out2) {
+  __shared__ double part[256];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int j = threadIdx.x; j < kdim; j += 256) s += (double)fabsf(w[(long long)c * kdim + j]);
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) part[threadIdx.x] += part[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const float sc = scale != nullptr ? scale[c] : 1.f, sh = shift != nullptr ? shift[c] : 0.f;
+    const float b = bias != nullptr ? bias[c] : 0.f;
+    const float k = (float)(fabs((double)sc) * part[0] * (1.0 + 1e-6));          // (rounded up: the bound must hold)
+    const float d = (float)(fabs((double)sc * (double)b + (double)sh) * (1.0 + 1e-6));
+    atomicMax(&out2[0], __builtin_bit_cast(unsigned, k));
+    atomicMax(&out2[1], __builtin_bit_cast(unsigned, d));
+  }
+}
+
 }  // namespace yolo
 
 using namespace yolo;
@@ -857,10 +892,69 @@ extern "C" int yolo_conv2d_fwd_planes_epi(const yolo_conv_desc* d, const void* x
   return launch_gather_planes(a, as_stream(stream));
 }
 
+extern "C" int yolo_conv_pred_bound(const float* w, int Cout, int kdim, const float* scale, const float* shift,
+                                    const float* bias, float* out2, void* stream) {
+  YOLO_REQUIRE(w && out2 && Cout > 0 && kdim > 0, "conv_pred_bound: bad args");
+  hipLaunchKernelGGL(conv_pred_bound_kernel, dim3((unsigned)Cout), dim3(256), 0, as_stream(stream), w, kdim, scale, shift,
+                     bias, reinterpret_cast<unsigned*>(out2));
+  return check_launch("conv_pred_bound_kernel");
+}
+
+extern "C" int yolo_conv2d_fwd_infer_unit(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,
+                                          const float* bias, int epilogue, const float* scale, const float* shift,
+                                          const float* residual, float* y, unsigned* absmax, const float* pred,
+                                          const void* in_bound, int in_n, const void* residual_bound, int residual_n,
+                                          void* out_planes, unsigned* out_slots, float* out_bound, void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x_planes && w_planes && y && absmax && pred && in_bound && out_planes && out_slots && out_bound,
+               "conv_fwd_infer_unit: null pointer");
+  YOLO_REQUIRE((in_n == 1 || in_n == 64) && (residual == nullptr || residual_n == 1 || residual_n == 64),
+               "conv_fwd_infer_unit: a bound is 1 word (a float) or 64 slots");
+  YOLO_REQUIRE(epilogue == YOLO_EPI_AFFINE_LEAKY || epilogue == YOLO_EPI_AFFINE_MISH || epilogue == YOLO_EPI_AFFINE,
+               "conv_fwd_infer_unit: bad epilogue %d", epilogue);
+  YOLO_REQUIRE(scale && shift, "conv_fwd_infer_unit: affine epilogue without scale / shift");
+  YOLO_REQUIRE(d->Cout % 16 == 0, "conv_fwd_infer_unit: planes output needs Cout %% 16 == 0 (Cout=%d)", d->Cout);
+  YOLO_REQUIRE(residual == nullptr || residual_bound != nullptr, "conv_fwd_infer_unit: a residual needs its bound");
+  GatherConvArgs a{};
+  a.src = reinterpret_cast<const float*>(x_planes);
+  a.wgt = reinterpret_cast<const float*>(w_planes);
+  a.bias = bias;
+  a.dst = y;
+  fill_fwd_args(d, a);
+  a.stats = nullptr;
+  a.absmax = absmax;
+  a.epi_scale = scale;
+  a.epi_shift = shift;
+  a.epi_act = epilogue == YOLO_EPI_AFFINE_LEAKY ? YOLO_ACT_LEAKY : epilogue == YOLO_EPI_AFFINE_MISH ? YOLO_ACT_MISH : YOLO_ACT_LINEAR;
+  a.epi_res = residual;
+  a.out_planes = reinterpret_cast<unsigned char*>(out_planes);
+  a.pl_pred = pred;
+  a.pl_in_bound = reinterpret_cast<const unsigned*>(in_bound);
+  a.pl_in_n = in_n;
+  a.pl_res_bound = residual != nullptr ? reinterpret_cast<const unsigned*>(residual_bound) : nullptr;
+  a.pl_res_n = residual != nullptr ? residual_n : 0;
+  a.pl_out_slots = out_slots;
+  YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_infer_unit: needs Cin %% 16 == 0 and Cout >= 32");
+  if (int rc = launch_gather_planes(a, as_stream(stream))) return rc;
+  // split-K launch: conv_split_reduce_kernel wrote the planes and max|y|. Otherwise (the tiles filled the chip): the
+  // separate pass, its bound from the epilogue's per-channel maxima (+ the residual's bound), as yolo_split_planes_absmax
+  if (a.split_parts > 1) return 1;   // (positive: not an error -- the result's bound is in out_slots, not in *out_bound)
+  return launch_split_planes_absmax(y, (long long)d->N * d->Ho * d->Wo, d->Cout, absmax,
+                                    reinterpret_cast<const float*>(a.pl_res_bound), a.pl_res_n, out_planes, out_bound,
+                                    as_stream(stream));
+}
+
+extern "C" int yolo_fold_bound(const void* words, int n, float* out_bound, void* stream) {
+  YOLO_REQUIRE(words && out_bound && n >= 1 && n <= 64, "fold_bound: 1..64 words");
+  hipLaunchKernelGGL(fold_bound_kernel, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<const unsigned*>(words), n,
+                     out_bound);
+  return check_launch("fold_bound_kernel");
+}
+
 extern "C" int yolo_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax,
                                         const float* extra_bound, void* planes, float* out_bound, void* stream) {
   YOLO_REQUIRE(x && planes && absmax, "split_planes_absmax: null pointer");
-  return launch_split_planes_absmax(x, rows, C, absmax, extra_bound, planes, out_bound, as_stream(stream));
+  return launch_split_planes_absmax(x, rows, C, absmax, extra_bound, 1, planes, out_bound, as_stream(stream));
 }
 
 extern "C" int yolo_split_planes_concat(const float* const* srcs_host, const int* channels_host,

@@ -77,17 +77,21 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
 // inference path needs no separate bound kernel. Also leaves the bound in *out_bound (optional).
 __global__ __launch_bounds__(256) void split_planes_absmax_kernel(const float* __restrict__ x, long long rows, int C,
                                                                  const unsigned* __restrict__ absmax,
-                                                                 const float* __restrict__ extra,
+                                                                 const float* __restrict__ extra, int extra_n,
                                                                  unsigned char* __restrict__ out, long long rows_padded,
                                                                  float* __restrict__ out_bound) {
   __shared__ float s_max[4];
+  // (extra: the bound of the residual tensor as extra_n <= 64 non-negative floats whose maximum it is)
+  float ex = (extra != nullptr && (int)(threadIdx.x & 63) < extra_n) ? extra[threadIdx.x & 63] : 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ex = fmaxf(ex, __shfl_xor(ex, o, 64));
   float m = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, __builtin_bit_cast(float, absmax[c]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
   __syncthreads();
-  const float bound = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])) * 1.001f + (extra ? extra[0] : 0.f) + 1e-30f;
+  const float bound = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])) * 1.001f + ex + 1e-30f;
   unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
   const float sc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bound));
   const int G = C >> 3;
@@ -836,7 +840,7 @@ int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, 
   return check_launch("split_planes_padded_kernel");
 }
 
-int launch_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax, const float* extra_bound,
+int launch_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax, const float* extra_bound, int extra_n,
                                void* planes, float* out_bound, hipStream_t st) {
   if (C % 16 != 0 || rows <= 0) {
     set_error("split_planes_absmax: C %% 16 != 0 or rows <= 0");
@@ -849,7 +853,7 @@ int launch_split_planes_absmax(const float* x, long long rows, int C, const unsi
     return YOLO_ERR_INVALID_ARG;
   }
   hipLaunchKernelGGL(split_planes_absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, rows, C, absmax, extra_bound,
-                     reinterpret_cast<unsigned char*>(planes), rows_padded, out_bound);
+                     extra_n, reinterpret_cast<unsigned char*>(planes), rows_padded, out_bound);
   return check_launch("split_planes_absmax_kernel");
 }
 

@@ -553,8 +553,24 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
   const int col = tile_n * BN + (wn * TN + j) * 32 + (lane & 31);
   const long long mrow = (long long)tile_m * BM + (wm * TM + i) * 32 + 8 * q4 + 4 * (lane >> 5);
   // (a workgroup = the four q4 pieces of ONE 32 x 32 accumulator block: 32 columns x 32 rows)
+  // (one-pass inference units: the three scalars of the a-priori bound are fetched first, beside the slab loads)
+  float bnd = 0.f;
+  unsigned ob_seen = 0;   // my slot of the recorded max as it was when this workgroup started (a stale value only costs an atomic)
+  if (a.out_planes != nullptr) {
+    const int l6 = threadIdx.x & 63;
+    float ib = l6 < a.pl_in_n ? __builtin_bit_cast(float, a.pl_in_bound[l6]) : 0.f;
+    float rb = (a.pl_res_bound != nullptr && l6 < a.pl_res_n) ? __builtin_bit_cast(float, a.pl_res_bound[l6]) : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ib = fmaxf(ib, __shfl_xor(ib, o, 64));
+      rb = fmaxf(rb, __shfl_xor(rb, o, 64));
+    }
+    bnd = (a.pl_pred[0] * ib + a.pl_pred[1] + rb) * 1.001f + 1e-30f;
+    ob_seen = __hip_atomic_load(&a.pl_out_slots[blockIdx.x & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   const bool active = col < a.Cout && mrow < a.M;
-  float mx = 0.f;
+  float mx = 0.f, mxf = 0.f;              // max|.| before the residual (absmax) / of the values written
+  float vout[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's four rows of its column (0 where the row does not exist)
   if (active) {
   const int P = a.split_parts;
   const f32x4* sl = reinterpret_cast<const f32x4*>(a.sk_slabs) + (size_t)tile * P * QPT + qi;
@@ -605,11 +621,13 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
       if (a.epi_res != nullptr) v += a.epi_res[off + col];
       if (a.accumulate) v += a.dst[off + col];
       a.dst[off + col] = v;
+      vout[e] = v;
       mx = fmaxf(mx, fabsf(fused ? vstat : v));
+      mxf = fmaxf(mxf, fabsf(v));
     }
   }
   }
-  if (a.absmax != nullptr) {
+  if (a.absmax != nullptr && a.out_planes == nullptr) {   // (with planes going out nobody reads the per-channel maxima)
     // one atomic per column and workgroup (256 same-address atomics from eight XCDs per column made this kernel 21 us)
     __shared__ float smx[256];
     smx[threadIdx.x] = mx;
@@ -620,6 +638,43 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
       for (int u = 0; u < 8; ++u) m8 = fmaxf(m8, smx[threadIdx.x + 32 * u]);
       if (col < a.Cout && __builtin_bit_cast(unsigned, m8) > a.absmax[col])
         atomicMax(&a.absmax[col], __builtin_bit_cast(unsigned, m8));
+    }
+  }
+  if (a.out_planes != nullptr) {
+    // The finished 32 x 32 block also goes out as planes (dense outputs: pixel m is row m of the tensor): through LDS,
+    // 128 threads take one (row, 8-channel group) unit each. Scale from the a-priori bound (GatherConvArgs::pl_pred):
+    // it is looser than max|dst| by the ratio of a filter's l1 norm to the dot products it actually produces (2^6..2^9
+    // here), which moves the absolute error floor of the format from 2^-40 to ~2^-32 of the bound -- still far below
+    // fp32's own rounding (planes.hpp)
+    __shared__ float t32[32][33];
+    __shared__ float s_mxf[4];
+    const int rl = 8 * q4 + 4 * (lane >> 5);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) t32[rl + e][lane & 31] = vout[e];
+    const float psc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bnd));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      unsigned* header = reinterpret_cast<unsigned*>(a.out_planes + planes_body_bytes(a.M, a.Cout));
+      header[0] = __builtin_bit_cast(unsigned, bnd);
+      reinterpret_cast<float*>(header)[1] = psc;
+      reinterpret_cast<float*>(header)[2] = 1.f / psc;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o, 64));
+    if ((threadIdx.x & 63) == 0) s_mxf[threadIdx.x >> 6] = mxf;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int r = threadIdx.x >> 2, g = threadIdx.x & 3;
+      const long long m = (long long)tile_m * BM + (wm * TM + i) * 32 + r;
+      const int c0 = tile_n * BN + (wn * TN + j) * 32 + g * 8;
+      if (m < a.M && c0 < a.Cout) {
+        const f32x4 o0 = {t32[r][g * 8 + 0], t32[r][g * 8 + 1], t32[r][g * 8 + 2], t32[r][g * 8 + 3]};
+        const f32x4 o1 = {t32[r][g * 8 + 4], t32[r][g * 8 + 5], t32[r][g * 8 + 6], t32[r][g * 8 + 7]};
+        store_planes8(a.out_planes, m, c0 >> 3, a.Cout, o0, o1, psc);
+      }
+    }
+    if (threadIdx.x == 0) {
+      const float m4 = fmaxf(fmaxf(s_mxf[0], s_mxf[1]), fmaxf(s_mxf[2], s_mxf[3]));
+      if (__builtin_bit_cast(unsigned, m4) > ob_seen) atomicMax(&a.pl_out_slots[blockIdx.x & 63], __builtin_bit_cast(unsigned, m4));
     }
   }
 }

@@ -78,6 +78,14 @@ __device__ __forceinline__ Planes8 split8(const f32x4 v0, const f32x4 v1, const 
   return p;
 }
 
+__device__ __forceinline__ void store_planes8(unsigned char* planes, long long row, int g8, int C, const f32x4 v0,
+                                              const f32x4 v1, const float sc) {
+  const Planes8 s = split8(v0, v1, sc);
+  unsigned char* o = planes + planes_unit_offset(row, g8, C);
+  *reinterpret_cast<u32x4*>(o) = s.h;
+  *reinterpret_cast<u32x4*>(o + 512) = s.l;
+}
+
 // raw buffer descriptor in SGPRs: base, stride 0, num_records = bytes, raw bounds-checked addressing
 __device__ __forceinline__ i32x4 planes_rsrc(const void* base, unsigned bytes) {
   const unsigned long long pb = (unsigned long long)(size_t)base;

@@ -413,8 +413,21 @@ class Network:
             off += 72             # [72 .. 72+C) = per-channel max|conv out| from the conv epilogue
             if u.kind == "conv" and u.bn:
                 off += (u.cout + 7) // 8 * 8
-        self._aux = torch.zeros(max(off, 1), device=self.device, dtype=torch.int32)
-        self._tbound = torch.zeros(max(len(self.tensors), 1) + 1, device=self.device, dtype=torch.float32)
+        # (the per-tensor bounds live behind the units' words: zeroed with them at the start of every forward pass, which the
+        # one-pass inference units need -- their kernels raise the bound of their result with atomicMax)
+        # A one-pass inference unit leaves the bound of its result as 64 slot words (their maximum; include/yolo_hip.h:
+        # yolo_conv2d_fwd_infer_unit): [ntb floats][ntb x 64 slot words]; _tb_float() folds them for readers of one float
+        ntb = max(len(self.tensors), 1) + 1
+        self._aux = torch.zeros(max(off, 1) + ntb * 65, device=self.device, dtype=torch.int32)
+        self._tbound = self._aux[max(off, 1):max(off, 1) + ntb].view(torch.float32)
+        self._tslots = self._aux[max(off, 1) + ntb:]
+        self._tslot_set = set()
+        # {K, D} of every conv-BN unit for the a-priori bound of its inference output (ops.conv_pred_bound): made with
+        # the folded scale / shift, i.e. once per set of weights
+        self._pred = torch.zeros(2 * max(len(self.units), 1), device=self.device, dtype=torch.float32)
+        for i, u in enumerate(self.units):
+            u.pred_off = 2 * i
+        self._infer_onepass = os.environ.get("YOLO_INFER_ONEPASS", "1") != "0"
 
     # ---- construction -------------------------------------------------------------------
     def _declare_params(self):
@@ -533,6 +546,19 @@ class Network:
         self._dyp_idx = 0
         self._xp_valid = set()
 
+    def _tb_float(self, tid):
+        """the recorded bound of tensor tid as ONE device float (folds the slots of a one-pass inference unit once)"""
+        if tid in self._tslot_set:
+            ops.fold_bound(self._tslots[tid * 64:tid * 64 + 64], self._tbound[tid:tid + 1])
+            self._tslot_set.discard(tid)
+        return self._tbound[tid:tid + 1]
+
+    def _tb_words(self, tid):
+        """the recorded bound of tensor tid as the one-pass units take it: its 64 slots, or its float"""
+        if tid in self._tslot_set:
+            return self._tslots[tid * 64:tid * 64 + 64]
+        return self._tbound[tid:tid + 1]
+
     def _xp(self, t):
         """planes of activation tensor t for this forward pass (split once, shared by all consumers)"""
         buf = self._xplanes[t.tid]
@@ -648,6 +674,7 @@ class Network:
         self.act[self.input.tid] = x
         self._xp_valid = set()
         self._tbound_set = set()
+        self._tslot_set = set()   # tensors whose recorded bound is (still) 64 slot words
         # (a pending event of an earlier forward stays until a planes conv / a backward has waited for it)
         if training and self._overlap_wgrad and self._prep_beside and not (self._wp_valid and self._wT_valid and self._wTp_valid):
             # the filters' planes (needed by the first planes conv) and their transposed forms (needed by backward) are
@@ -723,7 +750,7 @@ class Network:
                     ops.bn_act_fwd(u.y, u.cout, scale, shift, u.act, res, out=u.a, planes=pl,
                                    want_out=not (training and pl is not None and not u.a_needed),
                                    bn_bound=self._aux[u.aux_off:u.aux_off + 1],
-                                   residual_bound=tb[u.residual.tid:u.residual.tid + 1] if res is not None else None,
+                                   residual_bound=self._tb_float(u.residual.tid) if res is not None else None,
                                    out_bound=tb[u.out.tid:u.out.tid + 1], residual_planes=res_pl)
                     if pl is not None:
                         self._xp_valid.add(u.out.tid)
@@ -746,7 +773,7 @@ class Network:
                         and all(s.c % 8 == 0 for s in u.srcs)):
                     tb = self._tbound
                     ops.split_planes_concat([self.act[s.tid] for s in u.srcs], [s.c for s in u.srcs],
-                                            [tb[sl:sl + 1] for sl in slots], self.batch * u.out.h * u.out.w, pl,
+                                            [self._tb_float(sl) for sl in slots], self.batch * u.out.h * u.out.w, pl,
                                             dst32=u.buf if u.f32_needed else None,
                                             out_bound=tb[u.out.tid:u.out.tid + 1])
                     self._xp_valid.add(u.out.tid)
@@ -783,11 +810,28 @@ class Network:
         amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout]
         res = self.act[u.residual.tid] if u.residual is not None else None
         epi = {ACT_LEAKY: ops.EPI_AFFINE_LEAKY, ACT_MISH: ops.EPI_AFFINE_MISH}.get(u.act, ops.EPI_AFFINE)
+        tb = self._tbound
+        src_slot = self._bound_alias.get(u.src.tid, u.src.tid)
+        if self._infer_onepass and src_slot in self._tbound_set:
+            # one pass: the kernel that finishes the tile writes the planes too, scaled by an a-priori bound
+            pred = self._pred[u.pred_off:u.pred_off + 2]
+            if not self._infer_scale_valid:
+                ops.zero_bytes(pred)
+                ops.conv_pred_bound(self.params.view(u.p_kernel.name), u.cout, u.k * u.k * u.src.c, scale, shift, bias, pred)
+            onepass = ops.conv2d_fwd_infer_unit(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias,
+                                                epi, scale, shift, res, u.a, amax, pred, self._tb_words(src_slot),
+                                                self._tb_words(u.residual.tid) if u.residual is not None else None, pl,
+                                                self._tslots[u.out.tid * 64:u.out.tid * 64 + 64],
+                                                tb[u.out.tid:u.out.tid + 1])
+            if onepass:
+                self._tslot_set.add(u.out.tid)
+            self._tbound_set.add(u.out.tid)
+            self._xp_valid.add(u.out.tid)
+            return True
         ops.conv2d_fwd_planes_epi(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias, epi, scale,
                                   shift, residual=res, out=u.a, absmax=amax)
-        tb = self._tbound
         ops.split_planes_absmax(u.a, self.batch * u.out.h * u.out.w, u.cout, amax, pl,
-                                extra_bound=tb[u.residual.tid:u.residual.tid + 1] if u.residual is not None else None,
+                                extra_bound=self._tb_float(u.residual.tid) if u.residual is not None else None,
                                 out_bound=tb[u.out.tid:u.out.tid + 1])
         self._tbound_set.add(u.out.tid)
         self._xp_valid.add(u.out.tid)
