@@ -600,8 +600,6 @@ def test_conv_fused_inference_epilogue(act, with_res, case):
     assert _relerr(y2.double().cpu(), L.conv2d(ref, w2, None, stride=1, padding="same")) < TOL
 
 
-@pytest.mark.parametrize("shape", [(2, 37, 45), (1, 16, 16), (3, 130, 127), (2, 21, 400), (1, 50, 50)])
-@pytest.mark.parametrize("act", ["leaky", "mish"])
 def _planes_values(pl, rows, c):
     """the fp64 values a planes buffer holds ((h + l) / scale) and its header (bound, scale)"""
     nblk = (rows + 15) // 16
@@ -686,6 +684,8 @@ def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
     assert _relerr(z1.double(), z2.double()) < 2e-6
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 45), (1, 16, 16), (3, 130, 127), (2, 21, 400), (1, 50, 50)])
+@pytest.mark.parametrize("act", ["leaky", "mish"])
 def test_stem_backward_fused(shape, act):
     """yolo_stem_bn_bwd_wgrad (csrc/stem.hip): the BatchNorm / activation backward apply and the filter gradient of the
     stem unit in one pass. Against the unfused device path (yolo_bn_act_bwd_apply, then yolo_conv2d_wgrad on the dy it

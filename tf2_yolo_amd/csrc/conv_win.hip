@@ -572,6 +572,36 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
   float mx = 0.f, mxf = 0.f;              // max|.| before the residual (absmax) / of the values written
   float vout[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's four rows of its column (0 where the row does not exist)
   if (active) {
+  // everything this thread needs besides the slabs is fetched first (this kernel is a chain of memory latencies: the
+  // per-column parameters and the residual values fly beside the parts instead of behind them)
+  const float bv = a.bias != nullptr ? a.bias[col] : 0.f;
+  const bool fused = a.epi_scale != nullptr;
+  const float esc = fused ? a.epi_scale[col] : 1.f, esh = fused ? a.epi_shift[col] : 0.f;
+  const float unscale =
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2] *
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wgt) + a.wgt_bytes - PL_HEADER)[2];
+  const bool dense = a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Hd == a.Hg && a.Wd == a.Wg;
+  const int HgWg = a.Hg * a.Wg;
+  long long offs[4];
+  float rv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long long m = mrow + e;
+    offs[e] = -1;
+    if (m < a.M) {
+      if (dense) {
+        offs[e] = m * a.Cd;
+      } else {
+        const int n = (int)(m / HgWg);
+        const int rem = (int)(m - (long long)n * HgWg);
+        const int y = rem / a.Wg;
+        const int x = rem - y * a.Wg;
+        offs[e] = (((long long)n * a.Hd + (y * a.osy + a.ooy)) * a.Wd + (x * a.osx + a.oox)) * a.Cd;
+      }
+      if (a.epi_res != nullptr) rv[e] = a.epi_res[offs[e] + col];
+      if (a.accumulate) rv[e] += a.dst[offs[e] + col];
+    }
+  }
   const int P = a.split_parts;
   const f32x4* sl = reinterpret_cast<const f32x4*>(a.sk_slabs) + (size_t)tile * P * QPT + qi;
   // the loads of up to 16 parts fly together (each is a miss: the slabs were written a kernel ago by other CUs; four at a
@@ -593,34 +623,14 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
     for (int u = 0; u < 4; ++u) t = t + v[u];
   }
   for (; p < P; ++p) t = t + sl[(size_t)p * QPT];
-  const float unscale =
-      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2] *
-      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.wgt) + a.wgt_bytes - PL_HEADER)[2];
-  const float bv = a.bias != nullptr ? a.bias[col] : 0.f;
-  const bool fused = a.epi_scale != nullptr;
-  const float esc = fused ? a.epi_scale[col] : 1.f, esh = fused ? a.epi_shift[col] : 0.f;
-  const bool dense = a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Hd == a.Hg && a.Wd == a.Wg;
-  const int HgWg = a.Hg * a.Wg;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const long long m = mrow + e;
-    if (m < a.M) {
-      long long off;
-      if (dense) {
-        off = m * a.Cd;
-      } else {
-        const int n = (int)(m / HgWg);
-        const int rem = (int)(m - (long long)n * HgWg);
-        const int y = rem / a.Wg;
-        const int x = rem - y * a.Wg;
-        off = (((long long)n * a.Hd + (y * a.osy + a.ooy)) * a.Wd + (x * a.osx + a.oox)) * a.Cd;
-      }
+    if (offs[e] >= 0) {
       float v = fmaf(t[e], unscale, bv);
       if (fused) v = act_fwd(fmaf(esc, v, esh), a.epi_act);
       const float vstat = v;     // max|.| before the residual, as planes_epilogue
-      if (a.epi_res != nullptr) v += a.epi_res[off + col];
-      if (a.accumulate) v += a.dst[off + col];
-      a.dst[off + col] = v;
+      v += rv[e];                // (residual and / or the accumulate form's old value; 0 otherwise)
+      a.dst[offs[e] + col] = v;
       vout[e] = v;
       mx = fmaxf(mx, fabsf(fused ? vstat : v));
       mxf = fmaxf(mxf, fabsf(v));
