@@ -1,0 +1,9 @@
+#!/bin/bash
+O=gpurun_out/r4e; mkdir -p $O
+python -m pytest tests/test_gpu_elementwise.py tests/test_gpu_model.py -x -q -k "not 608 and not 416" > $O/t.log 2>&1; echo "tests rc $?"; tail -3 $O/t.log
+cp tf2_yolo_amd/libyolo_hip.so $O/new.so
+for V in old new old new; do
+  if [ $V = old ]; then cp tf2_yolo_amd/libyolo_hip_old.so.bin tf2_yolo_amd/libyolo_hip.so; else cp $O/new.so tf2_yolo_amd/libyolo_hip.so; fi
+  echo -n "$V: "; python scripts/bench_configs.py c4 2>&1 | grep images_per_s | cut -c1-170
+done
+cp $O/new.so tf2_yolo_amd/libyolo_hip.so; rm $O/new.so

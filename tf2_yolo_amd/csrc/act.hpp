@@ -37,10 +37,21 @@ __device__ __forceinline__ float act_fwd(float z, int act) {
 __device__ __forceinline__ float act_grad(float z, int act) {
   if (act == YOLO_ACT_LEAKY) return z > 0.f ? 1.f : 0.1f;
   if (act == YOLO_ACT_MISH) {
-    // d/dz [z t] = t + z (1 - t^2) sigmoid(z),  1 - t^2 = (1 - t)(1 + t),  sigmoid = 1/(1+e) or e/(1+e)
-    const MishParts m = mish_parts(z);
-    const float sg = (z > 0.f ? 1.f : m.e) * __builtin_amdgcn_rcpf(1.f + m.e);
-    return fmaf(z * m.omt * (1.f + m.t), sg, m.t);
+    // d/dz [z t] = t + z (1 - t)(1 + t) sigmoid(z) as ONE rational function of e = exp(-|z|) (t = N / D as in mish_parts):
+    //   z > 0:  N = 1 + 2e,    D = N + 2e^2,  (1 - t)(1 + t) sigmoid = 4 e^2 (1 + e) / D^2
+    //   z <= 0: N = e^2 + 2e,  D = N + 2,     (1 - t)(1 + t) sigmoid = 4 e   (1 + e) / D^2
+    //   mish'(z) = (N D + 4 z w) / D^2,  w = e^2 (1 + e) or e (1 + e)
+    // -- one exponential, one reciprocal, 15 multiply-adds and selects (the form t + z omt (1 + t) sg needed two
+    // reciprocals and ~22; these passes are VALU-bound with Mish). The cancellation near the zero of mish' (z = -1.19) is
+    // the function's own: both forms subtract two terms of size ~0.3 there.
+    const float e = fast_exp_neg(-fabsf(z));
+    const bool pos = z > 0.f;
+    const float e2 = e * e;
+    const float n = fmaf(2.f, e, pos ? 1.f : e2);
+    const float d = n + (pos ? 2.f * e2 : 2.f);
+    const float w = (pos ? e2 : e) * (1.f + e);
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(4.f * z, w, n * d) * r * r;
   }
   return 1.f;
 }

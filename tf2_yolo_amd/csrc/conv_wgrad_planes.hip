@@ -22,7 +22,8 @@ namespace yolo {
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, int WGM, int WGN, int NB = 3>
+// KO: diagnostic knock-outs (wrong results; YOLO_WGRAD_KO): 1 = no operand DMAs, 2 = no fragment reads, 4 = no MFMAs
+template <int BM, int BN, int WGM, int WGN, int NB = 3, int KO = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, (NB * (BM / 32 + BN / 32) * PL_PLANES * 1024 > 80 * 1024 ? 1 : 2)) void wgrad_planes_kernel(const WgradArgs a) {
   constexpr int NW = WGM * WGN;
   constexpr int TM = BM / WGM / 32;
@@ -59,42 +60,59 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NB * (BM / 32 + BN / 32) * PL_PLAN
   const int Ktot = a.ntaps * a.Cs;
 
   // ---- loader role(s): lane -> (pixel of the stage, sub-block of the 32-channel block). An 8-wave
-  // workgroup gives every wave ONE 32-channel block of dy (waves < RBA) or of x; a 4-wave 128x128 workgroup
-  // gives every wave one of each (dy block `wave` and x block `wave`). ----
+  // workgroup gives every wave ONE 32-channel block of dy (waves < RBA) or of x; a 4-wave workgroup gives every wave
+  // RBA / 4 blocks of dy and RBB / 4 blocks of x (128x128: one of each; 128x256: one and two). ----
   constexpr bool BOTH = (RBA + RBB > NW);
-  static_assert(!BOTH || (RBA == NW && RBB == NW), "loader layout");
-  constexpr int ND = PL_PLANES * (BOTH ? 2 : 1);   // DMA instructions per wave per stage
+  constexpr int NA = BOTH ? RBA / NW : 1, NQ = BOTH ? RBB / NW : 1;
+  static_assert(!BOTH || (RBA % NW == 0 && RBB % NW == 0), "loader layout");
+  constexpr int ND = PL_PLANES * (BOTH ? NA + NQ : 1);   // DMA instructions per wave per stage
   const bool hasA = BOTH || wave < RBA, hasB = BOTH || wave >= RBA;
-  const int rbA = wave, rbB = BOTH ? wave : (wave - RBA) % RBB;
   const int lpix = 4 * (lane >> 4) + (lane & 3);
   const int lsb = (lane >> 2) & 3;
   const unsigned strideA = (unsigned)((a.Cout >> 4) * PL_RECORD);   // bytes per 16-pixel block of dy planes
   const unsigned strideB = (unsigned)((a.Cs >> 4) * PL_RECORD);
   const unsigned zeroA = (unsigned)a.zero_blk_dy * strideA, zeroB = (unsigned)a.zero_blk_src * strideB;
   const i32x4 rsrcA = planes_rsrc(a.dy, a.dy_bytes), rsrcB = planes_rsrc(a.src, a.src_bytes);
-  const unsigned ldsA = lds_base + rbA * PL_PLANES * 1024, ldsB = lds_base + (RBA + rbB) * PL_PLANES * 1024;
+  unsigned ldsA[NA], ldsB[NQ];
 
   // A (dy): unit (pixel block, 16-channel block co16, half, pixel); advances one pixel block per stage
-  bool okA = false, okB = false;
-  unsigned voffA = zeroA, voffB = zeroB;
+  bool okA[NA], okB[NQ];
+  unsigned voffA[NA], voffB[NQ];
   // B (x): column block -> (tap, 16-channel block), pixel decoded incrementally
-  int b_oy = 0, b_ox = 0, b_chan = 0;
+  int b_oy[NQ], b_ox[NQ], b_chan[NQ];
   int pn = 0, py = 0, px = 0;
   long long pcur = p_begin + lpix;
-  if (hasA) {
-    const int co16 = ((co0 + rbA * 32) >> 4) + (lsb >> 1);
-    okA = co16 * 16 < a.Cout;
-    voffA = okA ? (unsigned)(p_begin >> 4) * strideA + (unsigned)co16 * PL_RECORD + (lsb & 1) * 256 + lpix * 16 : zeroA;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int rb = BOTH ? wave + i * NW : wave;
+    ldsA[i] = lds_base + rb * PL_PLANES * 1024;
+    okA[i] = false;
+    voffA[i] = zeroA;
+    if (hasA) {
+      const int co16 = ((co0 + rb * 32) >> 4) + (lsb >> 1);
+      okA[i] = co16 * 16 < a.Cout;
+      voffA[i] = okA[i] ? (unsigned)(p_begin >> 4) * strideA + (unsigned)co16 * PL_RECORD + (lsb & 1) * 256 + lpix * 16 : zeroA;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    const int rb = BOTH ? wave + i * NW : (wave - RBA) % RBB;
+    ldsB[i] = lds_base + (RBA + rb) * PL_PLANES * 1024;
+    okB[i] = false;
+    voffB[i] = zeroB;
+    b_oy[i] = b_ox[i] = b_chan[i] = 0;
+    if (hasB) {
+      const int j16 = ((j0 + rb * 32) >> 4) + (lsb >> 1);
+      okB[i] = j16 * 16 < Ktot;
+      const int cpt = a.Cs >> 4;
+      const int t = okB[i] ? j16 / cpt : 0;
+      const int r = t / a.kw;
+      b_oy[i] = r - a.pad_t;
+      b_ox[i] = (t - r * a.kw) - a.pad_l;
+      b_chan[i] = (j16 - t * cpt) * PL_RECORD + (lsb & 1) * 256;
+    }
   }
   if (hasB) {
-    const int j16 = ((j0 + rbB * 32) >> 4) + (lsb >> 1);
-    okB = j16 * 16 < Ktot;
-    const int cpt = a.Cs >> 4;
-    const int t = okB ? j16 / cpt : 0;
-    const int r = t / a.kw;
-    b_oy = r - a.pad_t;
-    b_ox = (t - r * a.kw) - a.pad_l;
-    b_chan = (j16 - t * cpt) * PL_RECORD + (lsb & 1) * 256;
     const int HgWg = a.Hg * a.Wg;
     const long long pp = pcur < a.M ? pcur : 0;
     pn = (int)(pp / HgWg);
@@ -105,17 +123,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NB * (BM / 32 + BN / 32) * PL_PLAN
   int ld_stage = 0;  // stage the loader will issue next
 
   auto loader_addr = [&]() {   // x: source unit of this lane's pixel for the stage about to be issued
-    const int ys = py * a.sy + b_oy, xs = px * a.sx + b_ox;
-    const bool ok = okB && (ld_stage < nk) && (pcur < p_end) && ((unsigned)ys < (unsigned)a.Hs) &&
-                    ((unsigned)xs < (unsigned)a.Ws);
-    const int s = (pn * a.Hs + ys) * a.Ws + xs;
-    voffB = ok ? ((unsigned)s >> 4) * strideB + (s & 15) * 16 + b_chan : zeroB;
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+      const int ys = py * a.sy + b_oy[i], xs = px * a.sx + b_ox[i];
+      const bool ok = okB[i] && (ld_stage < nk) && (pcur < p_end) && ((unsigned)ys < (unsigned)a.Hs) &&
+                      ((unsigned)xs < (unsigned)a.Ws);
+      const int s = (pn * a.Hs + ys) * a.Ws + xs;
+      voffB[i] = ok ? ((unsigned)s >> 4) * strideB + (s & 15) * 16 + b_chan[i] : zeroB;
+    }
   };
   auto loader_next = [&]() {
     ++ld_stage;
     if (hasA) {
-      if (ld_stage >= nk) voffA = zeroA;
-      else if (okA) voffA += strideA;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        if (ld_stage >= nk) voffA[i] = zeroA;
+        else if (okA[i]) voffA[i] += strideA;
+      }
     }
     if (hasB) {
       pcur += 16;
@@ -131,13 +155,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NB * (BM / 32 + BN / 32) * PL_PLAN
       loader_addr();
     }
   };
-  // DMA d of a stage: plane d & 1 of the wave's dy block (d < 2 when it has one) or x block
+  // DMA d of a stage: plane d & 1 of block d >> 1 of this wave (BOTH: its dy blocks first, then its x blocks)
   auto issue_plane = [&](int d, int buf) {
-    const int p = d & 1;
-    const bool useA = BOTH ? (d < 2) : hasA;
-    const unsigned l = __builtin_amdgcn_readfirstlane((useA ? ldsA : ldsB) + buf * STAGE_BYTES + p * 1024);
-    if (useA) dma16(rsrcA, voffA, (unsigned)(p * 512), l);
-    else dma16(rsrcB, voffB, (unsigned)(p * 512), l);
+    if constexpr (KO & 1) return;
+    const int p = d & 1, blk = d >> 1;
+    const bool useA = BOTH ? (blk < NA) : hasA;
+    const int bi = BOTH ? (blk < NA ? blk : blk - NA) : 0;
+    const unsigned l = __builtin_amdgcn_readfirstlane((useA ? ldsA[BOTH && blk >= NA ? 0 : bi] : ldsB[bi]) + buf * STAGE_BYTES + p * 1024);
+    if (useA) dma16(rsrcA, voffA[BOTH && blk >= NA ? 0 : bi], (unsigned)(p * 512), l);
+    else dma16(rsrcB, voffB[bi], (unsigned)(p * 512), l);
   };
   auto issue_stage = [&](int buf) {
 #pragma unroll
@@ -169,6 +195,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NB * (BM / 32 + BN / 32) * PL_PLAN
   f16x8 fa[2][PL_PLANES][TM], fb[2][PL_PLANES][TN];
   auto read_frags = [&](int buf, auto SET) {
     constexpr int S = decltype(SET)::value;
+    if constexpr (KO & 2) return;
     const unsigned char* sb = smem + buf * STAGE_BYTES;
 #pragma unroll
     for (int p = 0; p < PL_PLANES; ++p) {
@@ -190,7 +217,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NB * (BM / 32 + BN / 32) * PL_PLAN
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
+          if constexpr (!(KO & 4)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][pa][i], fb[S][pb][j], acc[i][j], 0, 0, 0);
           const int idx = (q * TM + i) * TN + j;
 #pragma unroll
           for (int d = 0; d < ND; ++d)
@@ -319,7 +346,7 @@ void* wgrad_workspace(size_t* bytes) {
   return g_wgrad_ws;
 }
 
-template <int BM, int BN, int WGM, int WGN, int NB = 3>
+template <int BM, int BN, int WGM, int WGN, int NB = 3, int KO = 0>
 static int launch_wp(WgradArgs& a, hipStream_t st) {
   a.tiles_co = (a.Cout + BM - 1) / BM;
   const int cols = a.ntaps * a.Cs;
@@ -336,9 +363,9 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   if (resident == 0) {
     int per_cu = 0, dev = 0, cus = 0;
     constexpr size_t lds_q = NB * (BM / 32 + BN / 32) * PL_PLANES * 1024;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN, NB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN, NB, KO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN, NB>),
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN, NB, KO>),
                                                      64 * WGM * WGN, lds_q) == hipSuccess &&
         hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
       resident = per_cu * cus;
@@ -380,11 +407,11 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   constexpr size_t lds = NB * (BM / 32 + BN / 32) * PL_PLANES * 1024;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN, NB>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_planes_kernel<BM, BN, WGM, WGN, NB, KO>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((wgrad_planes_kernel<BM, BN, WGM, WGN, NB>), dim3((unsigned)(tiles * splits)), dim3(64 * WGM * WGN), lds,
+  hipLaunchKernelGGL((wgrad_planes_kernel<BM, BN, WGM, WGN, NB, KO>), dim3((unsigned)(tiles * splits)), dim3(64 * WGM * WGN), lds,
                      st, a);
   if (int rc = check_launch("wgrad_planes_kernel")) return rc;
   if (a.slabs != nullptr) {
@@ -417,6 +444,25 @@ int launch_wgrad_planes(WgradArgs& a, hipStream_t st) {
   // 4 waves x (64 x 64): 12 MFMAs per wave between barriers instead of 6. Alone 160-178 us against 200-207 us on the
   // 3x3 layers; in the training step (beside the data-gradient stream) 33.25 against 33.58 ms. YOLO_WGRAD_WAVES=8: old form
   static const int waves = [] { const char* e = getenv("YOLO_WGRAD_WAVES"); return e ? atoi(e) : 4; }();
+#ifdef YOLO_PLANES_KNOCKOUTS   // diagnostic build (make KNOCKOUTS=1)
+  static const int ko = [] { const char* e = getenv("YOLO_WGRAD_KO"); return e ? atoi(e) : 0; }();
+  switch (ko) {
+    case 1: return launch_wp<128, 128, 2, 2, 3, 1>(a, st);
+    case 2: return launch_wp<128, 128, 2, 2, 3, 2>(a, st);
+    case 3: return launch_wp<128, 128, 2, 2, 3, 3>(a, st);
+    case 4: return launch_wp<128, 128, 2, 2, 3, 4>(a, st);
+    case 7: return launch_wp<128, 128, 2, 2, 3, 7>(a, st);
+    default: break;
+  }
+#endif
+  // 128 x 256 tile (4 waves x (64 x 128), 243 registers, two workgroups per CU): 25 % fewer LDS bytes per MFMA -- the
+  // knock-out build (make KNOCKOUTS=1, YOLO_WGRAD_KO) shows this kernel's matrix work (89 us alone on 52x52x128->256) and
+  // its LDS traffic (DMA + fragment reads: 97 us alone) hardly overlapping (159 us together): 128 B/clk of LDS port are as
+  // busy as the matrix cores. Measured alone: 13x13x512->1024 188 -> 160 us, 26x26 +-0, 52x52 / 104x104 5-10 % slower (two
+  // workgroups per CU instead of three), 1x1 layers 30 % slower: used for the 3x3 layers with few pixels (YOLO_WGRAD_WIDE:
+  // 0 never, 1 wherever the shape allows, 2 = that policy)
+  static const int wide = [] { const char* e = getenv("YOLO_WGRAD_WIDE"); return e ? atoi(e) : 2; }();
+  if (cols >= 256 && (wide == 1 || (wide == 2 && a.ntaps > 1 && a.M <= 8192))) return launch_wp<128, 256, 2, 2>(a, st);
   if (waves == 4) return launch_wp<128, 128, 2, 2>(a, st);
   return launch_wp<128, 128, 4, 2>(a, st);
 }

@@ -79,7 +79,13 @@ def planes_wgrad_ok(cin, cout, taps, stride=1):
     return USE_PLANES and cin % 16 == 0 and cout % 16 == 0 and cout >= 32 and taps * cin >= 64
 
 
-def _wgrad_planes_variant(cout, cols):
+_WGRAD_WIDE = int(_os.environ.get("YOLO_WGRAD_WIDE", "2"))
+
+
+def _wgrad_planes_variant(cout, cols, taps=1, pixels=1 << 40):
+    """mirrors launch_wgrad_planes() in csrc/conv_wgrad_planes.hip"""
+    if cout > 64 and cols >= 256 and (_WGRAD_WIDE == 1 or (_WGRAD_WIDE == 2 and taps > 1 and pixels <= 8192)):
+        return "wgrad_planes_kernel<128,256,2,2>"
     big = "4,2" if _os.environ.get("YOLO_WGRAD_WAVES") == "8" else "2,2"
     return "wgrad_planes_kernel<%d,%d,%s>" % (64 if cout <= 64 else 128, 64 if cols <= 64 else 128,
                                              "2,2" if (cout <= 64 and cols <= 64) else "2,4" if cout <= 64
@@ -471,7 +477,8 @@ def conv2d_wgrad_planes(d, xp, dyp, dw, dy=None, dbias=None):
         check(_lib.load().yolo_conv2d_wgrad_planes(byref(d), _p(xp), _p(dyp), _p(dw), _stream()),
               "yolo_conv2d_wgrad_planes")
     if TIMER is not None:
-        TIMER.bracket(_wgrad_planes_variant(d.Cout, d.kh * d.kw * d.Cin), _conv_flops(d), 1, run, _layer_key(d, "wgrad"))
+        TIMER.bracket(_wgrad_planes_variant(d.Cout, d.kh * d.kw * d.Cin, d.kh * d.kw, d.N * d.Ho * d.Wo), _conv_flops(d), 1, run,
+                      _layer_key(d, "wgrad"))
     else:
         run()
     if dbias is not None:
