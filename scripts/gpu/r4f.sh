@@ -1,5 +1,6 @@
 #!/bin/bash
-# knock-out experiment on the filter-gradient kernel (diagnostic build of the library swapped in for the run)
+# knock-out experiment on the filter-gradient kernel (diagnostic build of the library swapped in for the run).
+# Before: make KNOCKOUTS=1 -B -j8 && cp tf2_yolo_amd/libyolo_hip.so tf2_yolo_amd/libyolo_hip_ko.so.bin && make -B -j8
 O=gpurun_out/r4f; mkdir -p $O
 cp tf2_yolo_amd/libyolo_hip.so $O/prod.so
 cp tf2_yolo_amd/libyolo_hip_ko.so.bin tf2_yolo_amd/libyolo_hip.so
