@@ -194,20 +194,21 @@ int yolo_split_planes_absmax(const float* x, long long rows, int C, const unsign
  *     |y| <= K * max|x| + D (+ max|residual|),   {K, D} = pred[0..1] from yolo_conv_pred_bound (per layer, from the
  *     filter's l1 norms and the folded scale / shift: computed once per set of weights),
  *     max|x|, max|residual| = the bounds the producers of those tensors recorded, each given as n words whose maximum is
- *     the bound: n = 1 (one float) or n = 64 (the slots of another such unit, below).
- * The result's own max|y| goes to out_slots[64] (zeroed by the caller; workgroup b raises slot b % 64 with atomicMax: one
- * word would queue every workgroup's device-scope atomic on one address) and the call returns 1 (not an error).
- * Launches whose tiles fill the chip keep the two-pass form internally (yolo_conv2d_fwd_planes_epi +
- * yolo_split_planes_absmax: *out_bound = max_c absmax[c] + the residual's bound) and return 0.
- * yolo_fold_bound turns slots into one float for consumers that want one. y is bit-identical to
+ *     the bound: n = 1 (one float) or the n words another such unit left behind (below), n <= YOLO_INFER_BOUND_WORDS.
+ * The result's own max|y| goes to out_words as ONE word per workgroup of the launch that finished the tiles (plain
+ * stores -- a shared word would queue every workgroup's device-scope atomic on one address); *out_n_host (a HOST int) is
+ * set to their number. Launches whose tiles fill the chip keep the two-pass form internally (yolo_conv2d_fwd_planes_epi +
+ * yolo_split_planes_absmax: *out_bound = max_c absmax[c] + the residual's bound) and set *out_n_host = 0.
+ * yolo_fold_bound turns words into one float for consumers that want one. y is bit-identical to
  * yolo_conv2d_fwd_planes_epi's; the planes differ from the two-pass ones only in their (looser) scale. */
+#define YOLO_INFER_BOUND_WORDS 4096
 int yolo_conv_pred_bound(const float* w, int Cout, int kdim, const float* scale, const float* shift, const float* bias,
                          float* pred2, void* stream);
 int yolo_conv2d_fwd_infer_unit(const yolo_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
                                int epilogue, const float* scale, const float* shift, const float* residual, float* y,
                                unsigned* absmax, const float* pred2, const void* in_bound, int in_n,
-                               const void* residual_bound, int residual_n, void* out_planes, unsigned* out_slots,
-                               float* out_bound, void* stream);
+                               const void* residual_bound, int residual_n, void* out_planes, unsigned* out_words,
+                               float* out_bound, int* out_n_host, void* stream);
 int yolo_fold_bound(const void* words, int n, float* out_bound, void* stream);
 /* Concatenate (keras.layers.Concatenate on channels: yolov3/models/darknet.py:88,93; the CSP / SPP / PAN concats of
  * yolov4/models/backbone.py:141,183, yolov4/models/darknet.py:97-127; the passthrough of yolov2/models/darknet.py:49) straight

@@ -620,7 +620,7 @@ def _planes_values(pl, rows, c):
 def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
     """yolo_conv2d_fwd_infer_unit: y bit-identical to the fused-epilogue convolution, its planes (scaled by the a-priori
     bound K max|x| + D + max|residual|, yolo_conv_pred_bound) hold y to the format's 22 bits, the recorded bound of the
-    result is max|y| (one pass) or an upper bound of it (two passes inside the call)"""
+    result is max|y| (one pass: one word per workgroup) or an upper bound of it (two passes inside the call)"""
     from tf2_yolo_amd import ops
     ops.ensure_conv_workspace()   # (split-K needs its slabs: the engine registers them when a network is built)
     n, h, w, cin, cout, k, s, pad, bias = case
@@ -649,15 +649,15 @@ def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
     y = torch.empty_like(y_ref)
     pl = torch.zeros(ops.planes_bytes(rows, cout), device="cuda", dtype=torch.uint8)
     out_bound = torch.zeros(1, device="cuda")
-    out_slots = torch.zeros(64, device="cuda", dtype=torch.int32)
-    # the input's bound as 64 slot words (what another one-pass unit leaves), the residual's as one float
-    in_slots = torch.zeros(64, device="cuda")
-    in_slots[torch.randint(0, 64, (5,), generator=g)] = in_bound * 0.5
-    in_slots[17] = in_bound
-    onepass = ops.conv2d_fwd_infer_unit(d, xp, wp, bd, ops.EPI_AFFINE_LEAKY, scale, shift, res, y, amax, pred,
-                                        in_slots.view(torch.int32), res_bound, pl, out_slots, out_bound)
+    out_words = torch.full((ops.INFER_BOUND_WORDS,), -1, device="cuda", dtype=torch.int32)   # (not zeroed: plain stores)
+    # the input's bound as the words another one-pass unit leaves (any number up to 4096), the residual's as one float
+    in_words = torch.zeros(777, device="cuda")
+    in_words[torch.randint(0, 777, (40,), generator=g)] = in_bound * 0.5
+    in_words[500] = in_bound
+    nw = ops.conv2d_fwd_infer_unit(d, xp, wp, bd, ops.EPI_AFFINE_LEAKY, scale, shift, res, y, amax, pred,
+                                   in_words.view(torch.int32), res_bound, pl, out_words, out_bound)
     torch.cuda.synchronize()
-    assert onepass == expect_onepass
+    assert (nw > 0) == expect_onepass
     assert torch.equal(y, y_ref)
     ymax = float(y.abs().max())
     vals, bound, sc, tail = _planes_values(pl.cpu(), rows, cout)
@@ -666,10 +666,11 @@ def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
     yd = y.double().cpu().reshape(rows, cout)
     err = (vals - yd).abs()
     assert (err <= torch.maximum(2.0 ** -22 * yd.abs(), torch.tensor(2.0 ** -25 / sc, dtype=torch.float64))).all()
-    if onepass:
-        assert float(out_slots.view(torch.float32).max()) == ymax and not bool(amax.any())
+    if nw:
+        assert nw <= ops.INFER_BOUND_WORDS and float(out_words[:nw].view(torch.float32).max()) == ymax
+        assert bool((out_words[nw:] == -1).all()) and not bool(amax.any())
         folded = torch.zeros(1, device="cuda")
-        ops.fold_bound(out_slots, folded)
+        ops.fold_bound(out_words[:nw], folded)
         assert float(folded) == ymax
     else:
         ob = float(out_bound)

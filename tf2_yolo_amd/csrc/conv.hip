@@ -752,12 +752,16 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, int nparts,
   }
 }
 
-// out[0] = max of n <= 64 non-negative floats (the slots of a one-pass inference unit, GatherConvArgs::pl_out_slots)
-__global__ void fold_bound_kernel(const unsigned* __restrict__ words, int n, float* __restrict__ out) {
-  float v = (int)threadIdx.x < n ? __builtin_bit_cast(float, words[threadIdx.x]) : 0.f;
+// out[0] = max of n non-negative floats (the words a one-pass inference unit left: GatherConvArgs::pl_out_words)
+__global__ __launch_bounds__(256) void fold_bound_kernel(const unsigned* __restrict__ words, int n, float* __restrict__ out) {
+  __shared__ float s_v[4];
+  float v = 0.f;
+  for (int w = threadIdx.x; w < n; w += 256) v = fmaxf(v, __builtin_bit_cast(float, words[w]));
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  if (threadIdx.x == 0) out[0] = v;
+  if ((threadIdx.x & 63) == 0) s_v[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = fmaxf(fmaxf(s_v[0], s_v[1]), fmaxf(s_v[2], s_v[3]));
 }
 
 // K = max_c |scale_c| * sum_j |w[c][j]|, D = max_c |scale_c * bias_c + shift_c| of one conv-BN unit (inference): then
@@ -904,17 +908,19 @@ extern "C" int yolo_conv2d_fwd_infer_unit(const yolo_conv_desc* d, const void* x
                                           const float* bias, int epilogue, const float* scale, const float* shift,
                                           const float* residual, float* y, unsigned* absmax, const float* pred,
                                           const void* in_bound, int in_n, const void* residual_bound, int residual_n,
-                                          void* out_planes, unsigned* out_slots, float* out_bound, void* stream) {
+                                          void* out_planes, unsigned* out_words, float* out_bound, int* out_n_host,
+                                          void* stream) {
   if (int rc = validate_desc(d)) return rc;
-  YOLO_REQUIRE(x_planes && w_planes && y && absmax && pred && in_bound && out_planes && out_slots && out_bound,
+  YOLO_REQUIRE(x_planes && w_planes && y && absmax && pred && in_bound && out_planes && out_words && out_bound && out_n_host,
                "conv_fwd_infer_unit: null pointer");
-  YOLO_REQUIRE((in_n == 1 || in_n == 64) && (residual == nullptr || residual_n == 1 || residual_n == 64),
-               "conv_fwd_infer_unit: a bound is 1 word (a float) or 64 slots");
   YOLO_REQUIRE(epilogue == YOLO_EPI_AFFINE_LEAKY || epilogue == YOLO_EPI_AFFINE_MISH || epilogue == YOLO_EPI_AFFINE,
                "conv_fwd_infer_unit: bad epilogue %d", epilogue);
   YOLO_REQUIRE(scale && shift, "conv_fwd_infer_unit: affine epilogue without scale / shift");
   YOLO_REQUIRE(d->Cout % 16 == 0, "conv_fwd_infer_unit: planes output needs Cout %% 16 == 0 (Cout=%d)", d->Cout);
   YOLO_REQUIRE(residual == nullptr || residual_bound != nullptr, "conv_fwd_infer_unit: a residual needs its bound");
+  YOLO_REQUIRE(in_n >= 1 && in_n <= YOLO_INFER_BOUND_WORDS &&
+               (residual == nullptr || (residual_n >= 1 && residual_n <= YOLO_INFER_BOUND_WORDS)),
+               "conv_fwd_infer_unit: a bound is 1..%d words", YOLO_INFER_BOUND_WORDS);
   GatherConvArgs a{};
   a.src = reinterpret_cast<const float*>(x_planes);
   a.wgt = reinterpret_cast<const float*>(w_planes);
@@ -933,20 +939,24 @@ extern "C" int yolo_conv2d_fwd_infer_unit(const yolo_conv_desc* d, const void* x
   a.pl_in_n = in_n;
   a.pl_res_bound = residual != nullptr ? reinterpret_cast<const unsigned*>(residual_bound) : nullptr;
   a.pl_res_n = residual != nullptr ? residual_n : 0;
-  a.pl_out_slots = out_slots;
+  a.pl_out_words = out_words;
   YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_infer_unit: needs Cin %% 16 == 0 and Cout >= 32");
   if (int rc = launch_gather_planes(a, as_stream(stream))) return rc;
-  // split-K launch: conv_split_reduce_kernel wrote the planes and max|y|. Otherwise (the tiles filled the chip): the
-  // separate pass, its bound from the epilogue's per-channel maxima (+ the residual's bound), as yolo_split_planes_absmax
-  if (a.split_parts > 1) return 1;   // (positive: not an error -- the result's bound is in out_slots, not in *out_bound)
+  // split-K launch: conv_split_reduce_kernel wrote the planes and one word of max|y| per workgroup. Otherwise (the tiles
+  // filled the chip): the separate pass, its bound from the epilogue's per-channel maxima (+ the residual's bound)
+  if (a.split_parts > 1) {
+    *out_n_host = a.nblocks * (128 * 128 / 4 / 256);   // workgroups of conv_split_reduce_kernel<128>
+    return YOLO_OK;
+  }
+  *out_n_host = 0;
   return launch_split_planes_absmax(y, (long long)d->N * d->Ho * d->Wo, d->Cout, absmax,
                                     reinterpret_cast<const float*>(a.pl_res_bound), a.pl_res_n, out_planes, out_bound,
                                     as_stream(stream));
 }
 
 extern "C" int yolo_fold_bound(const void* words, int n, float* out_bound, void* stream) {
-  YOLO_REQUIRE(words && out_bound && n >= 1 && n <= 64, "fold_bound: 1..64 words");
-  hipLaunchKernelGGL(fold_bound_kernel, dim3(1), dim3(64), 0, as_stream(stream), reinterpret_cast<const unsigned*>(words), n,
+  YOLO_REQUIRE(words && out_bound && n >= 1 && n <= YOLO_INFER_BOUND_WORDS, "fold_bound: 1..%d words", YOLO_INFER_BOUND_WORDS);
+  hipLaunchKernelGGL(fold_bound_kernel, dim3(1), dim3(256), 0, as_stream(stream), reinterpret_cast<const unsigned*>(words), n,
                      out_bound);
   return check_launch("fold_bound_kernel");
 }

@@ -53,17 +53,16 @@ struct GatherConvArgs {
   // values also go out as the planes of the consumer convolutions. Their scale cannot wait for max|dst| (it is needed
   // while the tile is written), so it comes from an a-priori bound: pl_pred = {K, D} of this layer (yolo_conv_pred_bound:
   // |dst| <= K * max|src| + D before the residual), pl_in_bound / pl_res_bound = the recorded bounds of the input and of
-  // the residual tensor, each given as pl_*_n words whose maximum is the bound (1 = a plain float; 64 = the slots another
-  // such unit left behind). pl_out_slots[64] (zeroed by the caller) receive max|dst| for the consumers: workgroup b raises
-  // slot b % 64 with atomicMax (bit patterns of non-negative floats order like integers) -- ONE word would take an atomic
-  // from every workgroup of the launch on the same address, and device-scope atomics on one address queue up: +4 us on
-  // a 6 us kernel.
+  // the residual tensor, each given as pl_*_n words whose maximum is the bound (1 = a plain float; more = the words another
+  // such unit left behind). pl_out_words receives max|dst| for the consumers as ONE word per workgroup of the reduce launch
+  // (plain stores; at most YOLO_INFER_BOUND_WORDS): one shared word would take an atomic from every workgroup on the same
+  // address, and device-scope atomics on one address queue up (+4 us on a 6 us kernel; 64 shared slots: +1.7 us).
   unsigned char* out_planes;
   const float* pl_pred;
   const unsigned* pl_in_bound;
   const unsigned* pl_res_bound;
   int pl_in_n, pl_res_n;
-  unsigned* pl_out_slots;
+  unsigned* pl_out_words;
   // conv_win.hip, stream-K form: workgroups of the launch (0 = one tile per workgroup), part slabs, tile tickets
   int sk_grid;
   int tile_order;   // conv_win.hip: 0 = column tile fastest inside an XCD's run, 1 = row tile fastest

@@ -80,18 +80,25 @@ __global__ __launch_bounds__(256) void split_planes_absmax_kernel(const float* _
                                                                  const float* __restrict__ extra, int extra_n,
                                                                  unsigned char* __restrict__ out, long long rows_padded,
                                                                  float* __restrict__ out_bound) {
-  __shared__ float s_max[4];
-  // (extra: the bound of the residual tensor as extra_n <= 64 non-negative floats whose maximum it is)
-  float ex = (extra != nullptr && (int)(threadIdx.x & 63) < extra_n) ? extra[threadIdx.x & 63] : 0.f;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ex = fmaxf(ex, __shfl_xor(ex, o, 64));
+  __shared__ float s_max[2][4];
+  // (extra: the bound of the residual tensor as extra_n non-negative floats whose maximum it is)
+  float ex = 0.f;
+  if (extra != nullptr)
+    for (int w = threadIdx.x; w < extra_n; w += 256) ex = fmaxf(ex, extra[w]);
   float m = 0.f;
   for (int c = threadIdx.x; c < C; c += 256) m = fmaxf(m, __builtin_bit_cast(float, absmax[c]));
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-  if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = m;
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o, 64));
+    ex = fmaxf(ex, __shfl_xor(ex, o, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_max[0][threadIdx.x >> 6] = m;
+    s_max[1][threadIdx.x >> 6] = ex;
+  }
   __syncthreads();
-  const float bound = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])) * 1.001f + ex + 1e-30f;
+  const float bound = fmaxf(fmaxf(s_max[0][0], s_max[0][1]), fmaxf(s_max[0][2], s_max[0][3])) * 1.001f +
+                      fmaxf(fmaxf(s_max[1][0], s_max[1][1]), fmaxf(s_max[1][2], s_max[1][3])) + 1e-30f;
   unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
   const float sc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bound));
   const int G = C >> 3;

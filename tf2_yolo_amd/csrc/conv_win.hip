@@ -554,19 +554,13 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
   const long long mrow = (long long)tile_m * BM + (wm * TM + i) * 32 + 8 * q4 + 4 * (lane >> 5);
   // (a workgroup = the four q4 pieces of ONE 32 x 32 accumulator block: 32 columns x 32 rows)
   // (one-pass inference units: the three scalars of the a-priori bound are fetched first, beside the slab loads)
-  float bnd = 0.f;
-  unsigned ob_seen = 0;   // my slot of the recorded max as it was when this workgroup started (a stale value only costs an atomic)
+  // (one-pass inference units: the words of the a-priori bound are fetched first, beside the slab loads; every wave folds
+  // a quarter of them, the workgroup's maximum is formed behind the barrier further down)
+  float ib = 0.f, rb = 0.f;
   if (a.out_planes != nullptr) {
-    const int l6 = threadIdx.x & 63;
-    float ib = l6 < a.pl_in_n ? __builtin_bit_cast(float, a.pl_in_bound[l6]) : 0.f;
-    float rb = (a.pl_res_bound != nullptr && l6 < a.pl_res_n) ? __builtin_bit_cast(float, a.pl_res_bound[l6]) : 0.f;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      ib = fmaxf(ib, __shfl_xor(ib, o, 64));
-      rb = fmaxf(rb, __shfl_xor(rb, o, 64));
-    }
-    bnd = (a.pl_pred[0] * ib + a.pl_pred[1] + rb) * 1.001f + 1e-30f;
-    ob_seen = __hip_atomic_load(&a.pl_out_slots[blockIdx.x & 63], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int w = threadIdx.x; w < a.pl_in_n; w += 256) ib = fmaxf(ib, __builtin_bit_cast(float, a.pl_in_bound[w]));
+    if (a.pl_res_bound != nullptr)
+      for (int w = threadIdx.x; w < a.pl_res_n; w += 256) rb = fmaxf(rb, __builtin_bit_cast(float, a.pl_res_bound[w]));
   }
   const bool active = col < a.Cout && mrow < a.M;
   float mx = 0.f, mxf = 0.f;              // max|.| before the residual (absmax) / of the values written
@@ -657,10 +651,25 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
     // here), which moves the absolute error floor of the format from 2^-40 to ~2^-32 of the bound -- still far below
     // fp32's own rounding (planes.hpp)
     __shared__ float t32[32][33];
-    __shared__ float s_mxf[4];
+    __shared__ float s_mxf[3][4];
     const int rl = 8 * q4 + 4 * (lane >> 5);
 #pragma unroll
     for (int e = 0; e < 4; ++e) t32[rl + e][lane & 31] = vout[e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      mxf = fmaxf(mxf, __shfl_xor(mxf, o, 64));
+      ib = fmaxf(ib, __shfl_xor(ib, o, 64));
+      rb = fmaxf(rb, __shfl_xor(rb, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_mxf[0][threadIdx.x >> 6] = mxf;
+      s_mxf[1][threadIdx.x >> 6] = ib;
+      s_mxf[2][threadIdx.x >> 6] = rb;
+    }
+    __syncthreads();
+    const float in_b = fmaxf(fmaxf(s_mxf[1][0], s_mxf[1][1]), fmaxf(s_mxf[1][2], s_mxf[1][3]));
+    const float res_b = fmaxf(fmaxf(s_mxf[2][0], s_mxf[2][1]), fmaxf(s_mxf[2][2], s_mxf[2][3]));
+    const float bnd = (a.pl_pred[0] * in_b + a.pl_pred[1] + res_b) * 1.001f + 1e-30f;
     const float psc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bnd));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       unsigned* header = reinterpret_cast<unsigned*>(a.out_planes + planes_body_bytes(a.M, a.Cout));
@@ -668,10 +677,6 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
       reinterpret_cast<float*>(header)[1] = psc;
       reinterpret_cast<float*>(header)[2] = 1.f / psc;
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o, 64));
-    if ((threadIdx.x & 63) == 0) s_mxf[threadIdx.x >> 6] = mxf;
-    __syncthreads();
     if (threadIdx.x < 128) {
       const int r = threadIdx.x >> 2, g = threadIdx.x & 3;
       const long long m = (long long)tile_m * BM + (wm * TM + i) * 32 + r;
@@ -682,10 +687,10 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
         store_planes8(a.out_planes, m, c0 >> 3, a.Cout, o0, o1, psc);
       }
     }
-    if (threadIdx.x == 0) {
-      const float m4 = fmaxf(fmaxf(s_mxf[0], s_mxf[1]), fmaxf(s_mxf[2], s_mxf[3]));
-      if (__builtin_bit_cast(unsigned, m4) > ob_seen) atomicMax(&a.pl_out_slots[blockIdx.x & 63], __builtin_bit_cast(unsigned, m4));
-    }
+    // max|dst| of this workgroup's block: ONE word per workgroup, a plain store (the consumers take the maximum of the
+    // launch's words: GatherConvArgs::pl_out_words)
+    if (threadIdx.x == 0)
+      a.pl_out_words[blockIdx.x] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(s_mxf[0][0], s_mxf[0][1]), fmaxf(s_mxf[0][2], s_mxf[0][3])));
   }
 }
 

@@ -415,13 +415,13 @@ class Network:
                 off += (u.cout + 7) // 8 * 8
         # (the per-tensor bounds live behind the units' words: zeroed with them at the start of every forward pass, which the
         # one-pass inference units need -- their kernels raise the bound of their result with atomicMax)
-        # A one-pass inference unit leaves the bound of its result as 64 slot words (their maximum; include/yolo_hip.h:
-        # yolo_conv2d_fwd_infer_unit): [ntb floats][ntb x 64 slot words]; _tb_float() folds them for readers of one float
         ntb = max(len(self.tensors), 1) + 1
-        self._aux = torch.zeros(max(off, 1) + ntb * 65, device=self.device, dtype=torch.int32)
-        self._tbound = self._aux[max(off, 1):max(off, 1) + ntb].view(torch.float32)
-        self._tslots = self._aux[max(off, 1) + ntb:]
-        self._tslot_set = set()
+        self._aux = torch.zeros(max(off, 1) + ntb, device=self.device, dtype=torch.int32)
+        self._tbound = self._aux[max(off, 1):].view(torch.float32)
+        # A one-pass inference unit leaves the bound of its result as one word per workgroup of its last launch (their
+        # maximum; include/yolo_hip.h: yolo_conv2d_fwd_infer_unit): _tword_n[tid] words of the tensor's row, allocated on first use
+        self._twords = None
+        self._tword_n = {}
         # {K, D} of every conv-BN unit for the a-priori bound of its inference output (ops.conv_pred_bound): made with
         # the folded scale / shift, i.e. once per set of weights
         self._pred = torch.zeros(2 * max(len(self.units), 1), device=self.device, dtype=torch.float32)
@@ -546,18 +546,23 @@ class Network:
         self._dyp_idx = 0
         self._xp_valid = set()
 
+    def _tb_row(self, tid):
+        if self._twords is None:
+            self._twords = torch.zeros((max(len(self.tensors), 1) + 1) * ops.INFER_BOUND_WORDS, device=self.device,
+                                       dtype=torch.int32)
+        return self._twords[tid * ops.INFER_BOUND_WORDS:(tid + 1) * ops.INFER_BOUND_WORDS]
+
     def _tb_float(self, tid):
-        """the recorded bound of tensor tid as ONE device float (folds the slots of a one-pass inference unit once)"""
-        if tid in self._tslot_set:
-            ops.fold_bound(self._tslots[tid * 64:tid * 64 + 64], self._tbound[tid:tid + 1])
-            self._tslot_set.discard(tid)
+        """the recorded bound of tensor tid as ONE device float (folds the words of a one-pass inference unit once)"""
+        n = self._tword_n.pop(tid, 0)
+        if n:
+            ops.fold_bound(self._tb_row(tid)[:n], self._tbound[tid:tid + 1])
         return self._tbound[tid:tid + 1]
 
     def _tb_words(self, tid):
-        """the recorded bound of tensor tid as the one-pass units take it: its 64 slots, or its float"""
-        if tid in self._tslot_set:
-            return self._tslots[tid * 64:tid * 64 + 64]
-        return self._tbound[tid:tid + 1]
+        """the recorded bound of tensor tid as the one-pass units take it: the words such a unit left, or one float"""
+        n = self._tword_n.get(tid, 0)
+        return self._tb_row(tid)[:n] if n else self._tbound[tid:tid + 1]
 
     def _xp(self, t):
         """planes of activation tensor t for this forward pass (split once, shared by all consumers)"""
@@ -674,7 +679,7 @@ class Network:
         self.act[self.input.tid] = x
         self._xp_valid = set()
         self._tbound_set = set()
-        self._tslot_set = set()   # tensors whose recorded bound is (still) 64 slot words
+        self._tword_n = {}        # tensors whose recorded bound is (still) the words of a one-pass inference unit
         # (a pending event of an earlier forward stays until a planes conv / a backward has waited for it)
         if training and self._overlap_wgrad and self._prep_beside and not (self._wp_valid and self._wT_valid and self._wTp_valid):
             # the filters' planes (needed by the first planes conv) and their transposed forms (needed by backward) are
@@ -818,13 +823,12 @@ class Network:
             if not self._infer_scale_valid:
                 ops.zero_bytes(pred)
                 ops.conv_pred_bound(self.params.view(u.p_kernel.name), u.cout, u.k * u.k * u.src.c, scale, shift, bias, pred)
-            onepass = ops.conv2d_fwd_infer_unit(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias,
-                                                epi, scale, shift, res, u.a, amax, pred, self._tb_words(src_slot),
-                                                self._tb_words(u.residual.tid) if u.residual is not None else None, pl,
-                                                self._tslots[u.out.tid * 64:u.out.tid * 64 + 64],
-                                                tb[u.out.tid:u.out.tid + 1])
-            if onepass:
-                self._tslot_set.add(u.out.tid)
+            nw = ops.conv2d_fwd_infer_unit(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias,
+                                           epi, scale, shift, res, u.a, amax, pred, self._tb_words(src_slot),
+                                           self._tb_words(u.residual.tid) if u.residual is not None else None, pl,
+                                           self._tb_row(u.out.tid), tb[u.out.tid:u.out.tid + 1])
+            if nw:
+                self._tword_n[u.out.tid] = nw
             self._tbound_set.add(u.out.tid)
             self._xp_valid.add(u.out.tid)
             return True

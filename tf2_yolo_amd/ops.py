@@ -385,34 +385,36 @@ def conv_pred_bound(w, cout, kdim, scale, shift, bias, pred2):
           "yolo_conv_pred_bound")
 
 
+INFER_BOUND_WORDS = 4096   # YOLO_INFER_BOUND_WORDS in include/yolo_hip.h
+
+
 def conv2d_fwd_infer_unit(d, xp, wp, bias, epilogue, scale, shift, residual, out, absmax, pred2, in_bound, residual_bound,
-                          planes, out_slots, out_bound):
+                          planes, out_words, out_bound):
     """inference conv-BN-activation(-Add) unit whose result also leaves as planes (yolo_conv2d_fwd_infer_unit). in_bound /
-    residual_bound: 1 float or 64 slot words. Returns True when the bound of the result is in out_slots (one pass), False
-    when it is the float out_bound (two passes inside the call)."""
+    residual_bound: 1 float or the words another such unit left. Returns the number of words of out_words that now hold
+    max|result| (one pass), or 0 when the bound is the float out_bound (two passes inside the call)."""
     _chk_f32(bias, scale, shift, residual, out, pred2, out_bound)
     if xp.numel() < planes_bytes(d.N * d.H * d.W, d.Cin) or wp.numel() < planes_bytes(d.Cout, d.kh * d.kw * d.Cin):
         raise YoloHipError("conv2d_fwd_infer_unit: planes buffers do not match the descriptor")
     if out.numel() != d.N * d.Ho * d.Wo * d.Cout or (residual is not None and residual.numel() != out.numel()):
         raise YoloHipError("conv2d_fwd_infer_unit: output / residual size does not match the descriptor")
-    if planes.numel() < planes_bytes(d.N * d.Ho * d.Wo, d.Cout) or absmax.numel() < d.Cout or out_slots.numel() != 64:
-        raise YoloHipError("conv2d_fwd_infer_unit: planes / absmax buffer too small, or out_slots is not 64 words")
+    if planes.numel() < planes_bytes(d.N * d.Ho * d.Wo, d.Cout) or absmax.numel() < d.Cout or out_words.numel() < INFER_BOUND_WORDS:
+        raise YoloHipError("conv2d_fwd_infer_unit: planes / absmax / out_words buffer too small")
     for b in (in_bound, residual_bound):
-        if b is not None and (b.numel() not in (1, 64) or b.element_size() != 4):
-            raise YoloHipError("conv2d_fwd_infer_unit: a bound is 1 or 64 four-byte words")
-    rc = _lib.load().yolo_conv2d_fwd_infer_unit(byref(d), _p(xp), _p(wp), _p(bias), int(epilogue), _p(scale), _p(shift),
-                                                _p(residual), _p(out), _p(absmax), _p(pred2), _p(in_bound),
-                                                int(in_bound.numel()), _p(residual_bound),
-                                                int(residual_bound.numel()) if residual_bound is not None else 0,
-                                                _p(planes), _p(out_slots), _p(out_bound), _stream())
-    if rc == 1:
-        return True
-    check(rc, "yolo_conv2d_fwd_infer_unit")
-    return False
+        if b is not None and (not 1 <= b.numel() <= INFER_BOUND_WORDS or b.element_size() != 4):
+            raise YoloHipError("conv2d_fwd_infer_unit: a bound is 1..4096 four-byte words")
+    n = ctypes.c_int(0)
+    check(_lib.load().yolo_conv2d_fwd_infer_unit(byref(d), _p(xp), _p(wp), _p(bias), int(epilogue), _p(scale), _p(shift),
+                                                 _p(residual), _p(out), _p(absmax), _p(pred2), _p(in_bound),
+                                                 int(in_bound.numel()), _p(residual_bound),
+                                                 int(residual_bound.numel()) if residual_bound is not None else 0,
+                                                 _p(planes), _p(out_words), _p(out_bound), byref(n), _stream()),
+          "yolo_conv2d_fwd_infer_unit")
+    return int(n.value)
 
 
 def fold_bound(words, out_bound):
-    """out_bound[0] = max of 1..64 non-negative floats (bit patterns): the slots of a one-pass inference unit as one float"""
+    """out_bound[0] = max of 1..4096 non-negative floats (bit patterns): the words of a one-pass inference unit as one float"""
     _chk_f32(out_bound)
     check(_lib.load().yolo_fold_bound(_p(words), int(words.numel()), _p(out_bound), _stream()), "yolo_fold_bound")
 
