@@ -373,6 +373,12 @@ int yolo_maxpool_fwd(const float* x, int N, int H, int W, int C, int k, int s, i
 /* dx[argmax] += dy (dx caller-initialised) */
 int yolo_maxpool_bwd(const float* dy, int N, int Ho, int Wo, int C, int Cy, int c_off,
                      const int* argmax, float* dx, void* stream);
+/* The same backward for stride-1 'same' pools (YOLOv4's SPP block: MaxPooling2D(5 / 9 / 13, strides 1, padding "same"),
+ * yolov4/models/backbone.py:175-185) as a gather without atomics: input pixel (h, w) adds, in a fixed order, the dy of the
+ * outputs whose window holds it and whose saved winner it is; dx += that sum (bit-reproducible, where the scatter form's
+ * result depends on the order of its atomicAdds). Shapes the gather kernel does not cover fall back to yolo_maxpool_bwd. */
+int yolo_maxpool_bwd_same(const float* dy, int N, int H, int W, int C, int Cy, int c_off, const int* argmax, int k,
+                          int pad_t, int pad_l, float* dx, void* stream);
 /* tf.nn.space_to_depth(x, 2): y[n,h,w,(dy*2+dx)*C+c] = x[n,2h+dy,2w+dx,c], into slice of Cy at c_off */
 int yolo_space_to_depth2_fwd(const float* x, int N, int H, int W, int C, float* y, int Cy, int c_off,
                              void* stream);

@@ -136,6 +136,52 @@ def test_upsample_concat_s2d_maxpool():
         assert _rel(dm, m.grad) < 1e-5
 
 
+@pytest.mark.parametrize("k,hh,ww,c", [(5, 19, 19, 16), (9, 19, 19, 16), (13, 19, 19, 24), (13, 13, 13, 8), (5, 7, 30, 8),
+                                       (9, 32, 32, 8)])
+def test_spp_pools_plane_kernels(k, hh, ww, c):
+    """stride-1 'same' pools with C % 8 == 0 and H W <= 1024 run on the plane kernels (csrc/elementwise.hip): values and
+    winners as the fp64 oracle's (first maximum in row-major window order; the data has ties), the gather backward equals the
+    oracle's gradient and is the same bit for bit from run to run"""
+    from tf2_yolo_amd import ops
+    g = torch.Generator().manual_seed(100 * k + hh)
+    m = torch.randint(-6, 7, (3, hh, ww, c), generator=g).double()          # small integers: many ties inside a window
+    m = (m + 0.25 * torch.randn(3, hh, ww, c, generator=g, dtype=torch.float64).round()).requires_grad_(True)
+    ref = L.maxpool(m, k, 1, "same")
+    dref = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dref)
+    pt, pl = L.same_pad(hh, k, 1)[1], L.same_pad(ww, k, 1)[1]
+    md = m.detach().float().cuda()
+    out = torch.empty(3, hh, ww, c + 8, device="cuda")                       # written into a channel slice
+    arg = torch.empty(3, hh, ww, c, device="cuda", dtype=torch.int32)
+    ops.maxpool_fwd(md, k, 1, pt, pl, hh, ww, out, c + 8, 4, arg)
+    assert torch.equal(out[..., 4:4 + c].double().cpu(), ref.detach().float().double())
+    # winners: the value at the saved offset is the output, and it is the FIRST such value of its window
+    flat = md.reshape(-1)
+    assert torch.equal(flat[arg.reshape(-1).long()].reshape(3, hh, ww, c), out[..., 4:4 + c])
+    mc, argc = m.detach().float(), arg.cpu()
+    for _ in range(300):
+        b, ho, wo, ch = (int(torch.randint(0, n_, (1,), generator=g)) for n_ in (3, hh, ww, c))
+        first = None
+        for r in range(k):
+            for q in range(k):
+                h, w = ho + r - pt, wo + q - pl
+                if 0 <= h < hh and 0 <= w < ww and (first is None or mc[b, h, w, ch] > mc[first]):
+                    first = (b, h, w, ch)
+        assert int(argc[b, ho, wo, ch]) == ((first[0] * hh + first[1]) * ww + first[2]) * c + first[3]
+    dyd = torch.zeros(3, hh, ww, c + 8, device="cuda")
+    dyd[..., 4:4 + c] = dref.float().cuda()
+    runs = []
+    for _ in range(2):
+        dm = torch.ones(3, hh, ww, c, device="cuda")                         # dx += ...
+        ops.maxpool_bwd_same(dyd, 3, hh, ww, c, c + 8, 4, arg, k, pt, pl, dm)
+        runs.append(dm.clone())
+    assert torch.equal(runs[0], runs[1])
+    # the scatter form on the same winners is the reference for WHICH input receives each gradient
+    dscat = torch.ones(3, hh, ww, c, device="cuda")
+    ops.maxpool_bwd(dyd[..., 4:4 + c].contiguous(), 3, hh, ww, c, c, 0, arg, dscat)
+    assert _rel(runs[0], dscat.double().cpu()) < 1e-5
+
+
 @pytest.mark.parametrize("version,A,C", [(3, 3, 80), (4, 3, 7), (2, 5, 20), (1, 2, 1), (1, 2, 4)])
 def test_head_act(version, A, C):
     from tf2_yolo_amd import ops

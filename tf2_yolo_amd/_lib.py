@@ -101,6 +101,7 @@ SIGNATURES = {
     "yolo_maxpool_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                  _P, c_int, c_int, _P, _P]),
     "yolo_maxpool_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
+    "yolo_maxpool_bwd_same": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P]),
     "yolo_space_to_depth2_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "yolo_space_to_depth2_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),
     "yolo_head_act_fwd": (c_int, [_P, _LL, c_int, c_int, c_int, _P, _P, _P]),

@@ -166,6 +166,109 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, long long n, in
   }
 }
 
+// ---- stride-1 'same' pools with large windows (the 5 / 9 / 13 pools of YOLOv4's SPP block on a 19x19 or 13x13 map) ----
+// The kernel above reads k^2 values per output one after the other (169 for k = 13: 131 us for a 12 MB tensor). Here a
+// workgroup holds the H x W plane of 8 channels of one image in LDS and pools it in two passes -- along the rows (value +
+// column of the first maximum), then down the columns of those -- 2k LDS reads per output. Same result bit for bit, same
+// winner: the first maximum in row-major window order is the first row holding the maximum and, in it, its first column.
+constexpr int POOL_CG = 8;
+__global__ __launch_bounds__(256) void maxpool_plane_fwd_kernel(const float* __restrict__ x, int H, int W, int C, int k,
+                                                                int pad_t, int pad_l, float* __restrict__ y, int Cy,
+                                                                int c_off, int* __restrict__ argmax) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pool_sm[];
+  const int HW = H * W, n = HW * POOL_CG;
+  float* val = reinterpret_cast<float*>(pool_sm);
+  float* rval = val + n;
+  unsigned short* rarg = reinterpret_cast<unsigned short*>(rval + n);
+  const int groups = C / POOL_CG;
+  const int b = blockIdx.x / groups, c0 = (blockIdx.x - b * groups) * POOL_CG;
+  const long long base = (long long)b * HW;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int p = e / POOL_CG, c = e - p * POOL_CG;
+    val[e] = x[(base + p) * C + c0 + c];
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int p = e / POOL_CG, c = e - p * POOL_CG;
+    const int h = p / W, wo = p - h * W;
+    float best = -FLT_MAX;
+    int arg = -1;
+    for (int q = 0; q < k; ++q) {
+      const int w = wo + q - pad_l;
+      if ((unsigned)w >= (unsigned)W) continue;
+      const float v = val[(h * W + w) * POOL_CG + c];
+      if (arg < 0 || v > best) {
+        best = v;
+        arg = w;
+      }
+    }
+    rval[e] = best;
+    rarg[e] = (unsigned short)(arg < 0 ? 0xFFFF : arg);
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int p = e / POOL_CG, c = e - p * POOL_CG;
+    const int ho = p / W, wo = p - ho * W;
+    float best = -FLT_MAX;
+    int arg = -1;
+    for (int r = 0; r < k; ++r) {
+      const int h = ho + r - pad_t;
+      if ((unsigned)h >= (unsigned)H) continue;
+      const int idx = (h * W + wo) * POOL_CG + c;
+      const unsigned short ra = rarg[idx];
+      if (ra == 0xFFFF) continue;
+      const float v = rval[idx];
+      if (arg < 0 || v > best) {
+        best = v;
+        arg = h * W + ra;
+      }
+    }
+    y[(base + p) * Cy + c_off + c0 + c] = best;
+    if (argmax) argmax[(base + p) * C + c0 + c] = arg < 0 ? -1 : (int)((base + arg) * C + c0 + c);
+  }
+}
+
+// backward of the same pools as a GATHER: input pixel (h, w) adds, in a fixed order, the gradients of the outputs whose
+// window holds it and whose saved winner it is -- no atomics (the scatter form's fp32 atomicAdds made the step's result
+// depend on their order, and 169 windows can share one winner), dx += the sum
+__global__ __launch_bounds__(256) void maxpool_plane_bwd_kernel(const float* __restrict__ dy, int H, int W, int C, int Cy,
+                                                                int c_off, const int* __restrict__ argmax, int k, int pad_t,
+                                                                int pad_l, float* __restrict__ dx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char pool_sm[];
+  const int HW = H * W, n = HW * POOL_CG;
+  float* dyv = reinterpret_cast<float*>(pool_sm);
+  unsigned short* win = reinterpret_cast<unsigned short*>(dyv + n);
+  const int groups = C / POOL_CG;
+  const int b = blockIdx.x / groups, c0 = (blockIdx.x - b * groups) * POOL_CG;
+  const long long base = (long long)b * HW;
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int p = e / POOL_CG, c = e - p * POOL_CG;
+    dyv[e] = dy[(base + p) * Cy + c_off + c0 + c];
+    const int a = argmax[(base + p) * C + c0 + c];
+    win[e] = (unsigned short)(a < 0 ? 0xFFFF : (int)((long long)a / C - base));   // the winner's pixel inside this plane
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < n; e += 256) {
+    const int p = e / POOL_CG, c = e - p * POOL_CG;
+    const int h = p / W, w = p - h * W;
+    // output (ho, wo) covers input (h, w) iff ho - pad_t <= h <= ho - pad_t + k - 1
+    const int ho_lo = h + pad_t - (k - 1) < 0 ? 0 : h + pad_t - (k - 1), ho_hi = h + pad_t >= H ? H - 1 : h + pad_t;
+    const int wo_lo = w + pad_l - (k - 1) < 0 ? 0 : w + pad_l - (k - 1), wo_hi = w + pad_l >= W ? W - 1 : w + pad_l;
+    float sum = 0.f;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        const int idx = (ho * W + wo) * POOL_CG + c;
+        if (win[idx] == (unsigned short)p) sum += dyv[idx];
+      }
+    dx[(base + p) * C + c0 + c] += sum;
+  }
+}
+
+static bool pool_plane_ok(int H, int W, int C, int k, int s, int Ho, int Wo) {
+  static const bool on = [] { const char* e = getenv("YOLO_POOL_PLANE"); return !(e && atoi(e) == 0); }();
+  return on && s == 1 && Ho == H && Wo == W && k >= 4 && (C % POOL_CG) == 0 && H * W <= 1024;
+}
+
 // ---- space_to_depth(2) ----------------------------------------------------------------------
 __global__ void s2d_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, float* __restrict__ y, int Cy,
                                int c_off) {
@@ -409,10 +512,39 @@ extern "C" int yolo_maxpool_fwd(const float* x, int N, int H, int W, int C, int 
   YOLO_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && s > 0 && Ho > 0 && Wo > 0, "maxpool_fwd: bad args");
   YOLO_REQUIRE(c_off >= 0 && c_off + C <= Cy, "maxpool_fwd: bad channel slice");
   YOLO_REQUIRE((long long)N * H * W * C < (1LL << 31), "maxpool_fwd: tensor too large for int32 argmax");
+  if (pool_plane_ok(H, W, C, k, s, Ho, Wo)) {
+    const size_t lds = (size_t)H * W * POOL_CG * 10;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&maxpool_plane_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * POOL_CG * 10);
+      attr = true;
+    }
+    hipLaunchKernelGGL(maxpool_plane_fwd_kernel, dim3((unsigned)(N * (C / POOL_CG))), dim3(256), lds, as_stream(stream), x, H, W,
+                       C, k, pad_t, pad_l, y, Cy, c_off, argmax);
+    return check_launch("maxpool_plane_fwd_kernel");
+  }
   const long long n = (long long)N * Ho * Wo * C;
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), x, N, H, W, C, k,
                      s, pad_t, pad_l, Ho, Wo, y, Cy, c_off, argmax);
   return check_launch("maxpool_fwd_kernel");
+}
+
+extern "C" int yolo_maxpool_bwd_same(const float* dy, int N, int H, int W, int C, int Cy, int c_off, const int* argmax, int k,
+                                     int pad_t, int pad_l, float* dx, void* stream) {
+  YOLO_REQUIRE(dy && argmax && dx && N > 0 && H > 0 && W > 0 && C > 0 && k > 0, "maxpool_bwd_same: bad args");
+  YOLO_REQUIRE(c_off >= 0 && c_off + C <= Cy, "maxpool_bwd_same: bad channel slice");
+  if (pool_plane_ok(H, W, C, k, 1, H, W)) {
+    const size_t lds = (size_t)H * W * POOL_CG * 6;
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&maxpool_plane_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * POOL_CG * 6);
+      attr = true;
+    }
+    hipLaunchKernelGGL(maxpool_plane_bwd_kernel, dim3((unsigned)(N * (C / POOL_CG))), dim3(256), lds, as_stream(stream), dy, H, W,
+                       C, Cy, c_off, argmax, k, pad_t, pad_l, dx);
+    return check_launch("maxpool_plane_bwd_kernel");
+  }
+  return yolo_maxpool_bwd(dy, N, H, W, C, Cy, c_off, argmax, dx, stream);
 }
 
 extern "C" int yolo_maxpool_bwd(const float* dy, int N, int Ho, int Wo, int C, int Cy, int c_off, const int* argmax,

@@ -987,7 +987,10 @@ class Network:
                         cur = torch.empty((N, u.src.h, u.src.w, u.src.c), device=self.device, dtype=torch.float32)
                         ops.zero_bytes(cur)
                         grads[u.src.tid] = cur
-                    ops.maxpool_bwd(dout, N, u.out.h, u.out.w, u.out.c, u.out.c, 0, u.argmax, cur)
+                    if u.stride == 1 and (u.out.h, u.out.w) == (u.src.h, u.src.w):
+                        ops.maxpool_bwd_same(dout, N, u.out.h, u.out.w, u.out.c, u.out.c, 0, u.argmax, u.k, u.pad_t, u.pad_l, cur)
+                    else:
+                        ops.maxpool_bwd(dout, N, u.out.h, u.out.w, u.out.c, u.out.c, 0, u.argmax, cur)
             elif u.kind == "space_to_depth":
                 if self._needs_grad[u.src.tid]:
                     cur = grads.get(u.src.tid)

@@ -736,6 +736,12 @@ def maxpool_bwd(dy, N, Ho, Wo, C, Cy, c_off, argmax, dx):
           "yolo_maxpool_bwd")
 
 
+def maxpool_bwd_same(dy, N, H, W, C, Cy, c_off, argmax, k, pad_t, pad_l, dx):
+    """backward of a stride-1 'same' pool without atomics (yolo_maxpool_bwd_same): dx += gathered dy"""
+    check(_lib.load().yolo_maxpool_bwd_same(_p(dy), N, H, W, C, Cy, c_off, _p(argmax), int(k), int(pad_t), int(pad_l), _p(dx),
+                                            _stream()), "yolo_maxpool_bwd_same")
+
+
 def space_to_depth2_fwd(x, y, Cy, c_off):
     n, h, w, c = x.shape
     check(_lib.load().yolo_space_to_depth2_fwd(_p(x), n, h, w, c, _p(y), Cy, c_off, _stream()),
