@@ -210,6 +210,18 @@ int yolo_conv2d_fwd_infer_unit(const yolo_conv_desc* d, const void* x_planes, co
                                const void* residual_bound, int residual_n, void* out_planes, unsigned* out_words,
                                float* out_bound, int* out_n_host, void* stream);
 int yolo_fold_bound(const void* words, int n, float* out_bound, void* stream);
+/* The first unit of every Darknet body -- Conv2D(32, 3, padding "same") + BatchNormalization + LeakyReLU / Mish on the RGB
+ * image (yolov3/models/backbone.py:60, yolov4/models/backbone.py:127, yolov2/models/backbone.py:44) -- as ONE inference launch:
+ * the direct fp32 stem kernel applies the folded scale / shift and the activation to a pixel's 32 sums in registers and writes
+ * the planes of the next convolution (scale from K * max|image| + D, pred2 of yolo_conv_pred_bound; max|image| as the words of
+ * yolo_absmax_words: one per workgroup, *n_words_host of them, no atomics). wt = the filter prepared by yolo_stem_filter_prep
+ * ([27 taps + bias row][32], once per set of weights); y (fp32, optional) only if somebody reads it. out_words / *out_n_host as
+ * in yolo_conv2d_fwd_infer_unit. */
+int yolo_absmax_words(const float* x, long long n, unsigned* words, int* n_words_host, void* stream);
+int yolo_stem_filter_prep(const float* w, const float* bias, float* wt, void* stream);
+int yolo_stem_fwd_infer_unit(const yolo_conv_desc* d, const float* x, const float* wt, int epilogue, const float* scale,
+                             const float* shift, const float* pred2, const void* in_bound, int in_n, float* y,
+                             void* out_planes, unsigned* out_words, int* out_n_host, void* stream);
 /* Concatenate (keras.layers.Concatenate on channels: yolov3/models/darknet.py:88,93; the CSP / SPP / PAN concats of
  * yolov4/models/backbone.py:141,183, yolov4/models/darknet.py:97-127; the passthrough of yolov2/models/darknet.py:49) straight
  * into the planes of the result: up to four dense fp32 sources [rows][channels_host[i]] (multiples of 8; the sum a multiple

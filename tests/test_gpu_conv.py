@@ -685,6 +685,52 @@ def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
     assert _relerr(z1.double(), z2.double()) < 2e-6
 
 
+@pytest.mark.parametrize("shape,act,with_y", [((2, 37, 45), "leaky", True), ((1, 64, 64), "mish", False),
+                                              ((1, 416, 416), "leaky", False), ((3, 21, 130), "leaky", True)])
+def test_stem_inference_unit(shape, act, with_y):
+    """yolo_stem_fwd_infer_unit: Conv2D(32, 3, same) + folded BatchNorm + activation of the RGB image in one launch against
+    the fp64 oracle; the planes hold the result to the format's 22 bits under the a-priori bound K max|image| + D, one word
+    of max|result| per workgroup"""
+    from tf2_yolo_amd import ops
+    n, h, w = shape
+    g = torch.Generator().manual_seed(31 + h)
+    img = torch.rand(n, h, w, 3, generator=g, dtype=torch.float64)
+    wk = torch.randn(3, 3, 3, 32, generator=g, dtype=torch.float64) * 0.3
+    b = torch.randn(32, generator=g, dtype=torch.float64) * 0.1
+    scale = (torch.rand(32, generator=g, dtype=torch.float64) + 0.5) * torch.where(torch.rand(32, generator=g) < 0.2, -1.0, 1.0)
+    shift = torch.randn(32, generator=g, dtype=torch.float64) * 0.3
+    z = L.conv2d(img, wk, b, stride=1, padding="same") * scale + shift
+    ref = torch.where(z > 0, z, 0.1 * z) if act == "leaky" else z * torch.tanh(torch.nn.functional.softplus(z))
+    d = ops.conv_desc((n, h, w, 3), 32, 3, 3, 1, "same")
+    xd, wd, bd = img.float().cuda(), _krsc(wk).float().cuda(), b.float().cuda()
+    sc, sh = scale.float().cuda(), shift.float().cuda()
+    wt = torch.empty(28 * 32, device="cuda")
+    ops.stem_filter_prep(wd, bd, wt)
+    pred = torch.zeros(2, device="cuda")
+    ops.conv_pred_bound(wd, 32, 27, sc, sh, bd, pred)
+    words = torch.full((ops.INFER_BOUND_WORDS,), -1, device="cuda", dtype=torch.int32)
+    n_in = ops.absmax_words(xd, words)
+    assert 1 <= n_in <= 256 and float(words[:n_in].view(torch.float32).max()) == float(xd.abs().max())
+    rows = n * h * w
+    pl = torch.zeros(ops.planes_bytes(rows, 32), device="cuda", dtype=torch.uint8)
+    out_words = torch.full((ops.INFER_BOUND_WORDS,), -1, device="cuda", dtype=torch.int32)
+    y = torch.empty(n, h, w, 32, device="cuda") if with_y else None
+    epi = ops.EPI_AFFINE_LEAKY if act == "leaky" else ops.EPI_AFFINE_MISH
+    nw = ops.stem_fwd_infer_unit(d, xd, wt, epi, sc, sh, pred, words[:n_in], y, pl, out_words)
+    torch.cuda.synchronize()
+    vals, bound, s_, tail = _planes_values(pl.cpu(), rows, 32)
+    refm = float(ref.abs().max())
+    assert _relerr(vals.reshape(ref.shape), ref) < 1e-5
+    assert bound >= refm and (tail == 0).all() and 2.0 ** 14 < s_ * bound <= 2.0 ** 15
+    got_max = float(out_words[:nw].view(torch.float32).max())
+    assert nw >= 1 and abs(got_max - refm) <= 1e-5 * refm and bool((out_words[nw:] == -1).all())
+    if with_y:
+        assert _relerr(y.double().cpu(), ref) < 1e-5
+        yv = y.double().cpu().reshape(rows, 32)
+        assert ((vals - yv).abs() <= torch.maximum(2.0 ** -22 * yv.abs(), torch.tensor(2.0 ** -25 / s_, dtype=torch.float64))).all()
+        assert got_max == float(y.abs().max())
+
+
 @pytest.mark.parametrize("shape", [(2, 37, 45), (1, 16, 16), (3, 130, 127), (2, 21, 400), (1, 50, 50)])
 @pytest.mark.parametrize("act", ["leaky", "mish"])
 def test_stem_backward_fused(shape, act):

@@ -954,6 +954,35 @@ extern "C" int yolo_conv2d_fwd_infer_unit(const yolo_conv_desc* d, const void* x
                                     as_stream(stream));
 }
 
+extern "C" int yolo_absmax_words(const float* x, long long n, unsigned* words, int* n_words_host, void* stream) {
+  YOLO_REQUIRE(x && words && n_words_host && n > 0, "absmax_words: bad args");
+  return launch_absmax_words(x, n, words, n_words_host, as_stream(stream));
+}
+
+extern "C" int yolo_stem_filter_prep(const float* w, const float* bias, float* wt, void* stream) {
+  YOLO_REQUIRE(w && wt, "stem_filter_prep: null pointer");
+  return launch_stem_filter_prep(w, bias, wt, as_stream(stream));
+}
+
+extern "C" int yolo_stem_fwd_infer_unit(const yolo_conv_desc* d, const float* x, const float* wt, int epilogue,
+                                        const float* scale, const float* shift, const float* pred, const void* in_bound,
+                                        int in_n, float* y, void* out_planes, unsigned* out_words, int* out_n_host,
+                                        void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x && wt && scale && shift && pred && in_bound && out_planes && out_words && out_n_host,
+               "stem_fwd_infer_unit: null pointer");
+  YOLO_REQUIRE(stem_infer_supported(d), "stem_fwd_infer_unit: Conv2D(32, 3, strides 1, padding same) on 3 channels only");
+  YOLO_REQUIRE(epilogue == YOLO_EPI_AFFINE_LEAKY || epilogue == YOLO_EPI_AFFINE_MISH || epilogue == YOLO_EPI_AFFINE,
+               "stem_fwd_infer_unit: bad epilogue %d", epilogue);
+  YOLO_REQUIRE(in_n >= 1 && in_n <= YOLO_INFER_BOUND_WORDS, "stem_fwd_infer_unit: a bound is 1..%d words", YOLO_INFER_BOUND_WORDS);
+  StemEpiArgs e;
+  e.scale = scale; e.shift = shift;
+  e.act = epilogue == YOLO_EPI_AFFINE_LEAKY ? YOLO_ACT_LEAKY : epilogue == YOLO_EPI_AFFINE_MISH ? YOLO_ACT_MISH : YOLO_ACT_LINEAR;
+  e.planes = out_planes; e.pred = pred;
+  e.in_words = reinterpret_cast<const unsigned*>(in_bound); e.in_n = in_n; e.out_words = out_words;
+  return launch_stem_infer(d, x, wt, y, e, out_n_host, as_stream(stream));
+}
+
 extern "C" int yolo_fold_bound(const void* words, int n, float* out_bound, void* stream) {
   YOLO_REQUIRE(words && out_bound && n >= 1 && n <= YOLO_INFER_BOUND_WORDS, "fold_bound: 1..%d words", YOLO_INFER_BOUND_WORDS);
   hipLaunchKernelGGL(fold_bound_kernel, dim3(1), dim3(256), 0, as_stream(stream), reinterpret_cast<const unsigned*>(words), n,

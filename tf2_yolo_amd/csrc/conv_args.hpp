@@ -150,6 +150,22 @@ constexpr size_t WGRAD_WS_COLSUM_BYTES = 1 << 20;
 void* wgrad_workspace(size_t* bytes);
 // stem.hip (direct fp32 kernel for the 3-channel 3x3 stem)
 bool stem_fwd_supported(const yolo_conv_desc* d);
+// the stem's inference unit in one pass (stem.hip): prepared filter [28][32] (launch_stem_filter_prep), epilogue arguments
+struct StemEpiArgs {
+  const float* scale;
+  const float* shift;
+  int act;
+  void* planes;
+  const float* pred;
+  const unsigned* in_words;
+  int in_n;
+  unsigned* out_words;
+};
+bool stem_infer_supported(const yolo_conv_desc* d);
+int launch_stem_filter_prep(const float* w, const float* bias, float* wt, hipStream_t st);
+int launch_absmax_words(const float* x, long long n, unsigned* words, int* n_words, hipStream_t st);
+int launch_stem_infer(const yolo_conv_desc* d, const float* x, const float* wt, float* y, const StemEpiArgs& e, int* out_n,
+                      hipStream_t st);
 size_t stem_bwd_scratch_bytes();
 int launch_stem_bn_bwd_wgrad(const yolo_conv_desc* d, const float* y, const float* dout, const float* img, const float* scale,
                              const float* shift, const float* smean, const float* sinv, int act, const double* redsum,

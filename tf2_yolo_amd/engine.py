@@ -727,6 +727,8 @@ class Network:
                                         absmax=self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout], mean_offset=bias)
                     elif self._fuse_infer and self._fused_infer_unit(u, bias, gamma, beta, scale, shift):
                         continue
+                    elif self._fuse_infer and self._infer_onepass and self._stem_infer_unit(u, xin, w, bias, gamma, beta, scale, shift):
+                        continue
                     else:
                         amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout]
                         if u.planes_fwd:
@@ -798,6 +800,32 @@ class Network:
         if not training:
             self._infer_scale_valid = True
         return [self.act[t.tid] for t in self.outputs]
+
+    def _stem_infer_unit(self, u, xin, w, bias, gamma, beta, scale, shift):
+        """The RGB stem's inference unit in one launch (yolo_stem_fwd_infer_unit): direct fp32 convolution, folded
+        BatchNormalization + activation in registers, the planes of the next convolution written by the same kernel; the image's
+        max|x| comes from yolo_absmax_words. Returns False for any other unit."""
+        pl = self._xplanes.get(u.out.tid)
+        if u.residual is not None or pl is None or u.src.tid != self.input.tid or not ops.stem_infer_supported(u.desc):
+            return False
+        if not self._infer_scale_valid:
+            ops.bn_fold_inference(u.cout, gamma, beta, self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
+                                  scale, shift)
+            if getattr(u, "stem_wt", None) is None:
+                u.stem_wt = torch.empty(28 * 32, device=self.device, dtype=torch.float32)
+            ops.stem_filter_prep(w, bias, u.stem_wt)
+            pred = self._pred[u.pred_off:u.pred_off + 2]
+            ops.zero_bytes(pred)
+            ops.conv_pred_bound(w, u.cout, 27, scale, shift, bias, pred)
+        epi = {ACT_LEAKY: ops.EPI_AFFINE_LEAKY, ACT_MISH: ops.EPI_AFFINE_MISH}.get(u.act, ops.EPI_AFFINE)
+        row = self._tb_row(self.input.tid)
+        n_in = ops.absmax_words(xin, row)
+        nw = ops.stem_fwd_infer_unit(u.desc, xin, u.stem_wt, epi, scale, shift, self._pred[u.pred_off:u.pred_off + 2], row[:n_in],
+                                     u.a if u.a_needed else None, pl, self._tb_row(u.out.tid))
+        self._tword_n[u.out.tid] = nw
+        self._tbound_set.add(u.out.tid)
+        self._xp_valid.add(u.out.tid)
+        return True
 
     def _fused_infer_unit(self, u, bias, gamma, beta, scale, shift):
         """Inference form of a conv-BN-activation(-Add) unit in two launches (include/yolo_hip.h, fused epilogue): the

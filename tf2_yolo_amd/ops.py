@@ -413,6 +413,41 @@ def conv2d_fwd_infer_unit(d, xp, wp, bias, epilogue, scale, shift, residual, out
     return int(n.value)
 
 
+def absmax_words(x, words):
+    """max|x| as one word per workgroup of the launch (yolo_absmax_words); returns their number"""
+    _chk_f32(x)
+    n = ctypes.c_int(0)
+    check(_lib.load().yolo_absmax_words(_p(x), int(x.numel()), _p(words), byref(n), _stream()), "yolo_absmax_words")
+    return int(n.value)
+
+
+def stem_filter_prep(w, bias, wt):
+    """wt (28 x 32 floats) <- the stem filter as the direct kernel reads it (yolo_stem_filter_prep)"""
+    _chk_f32(w, bias, wt)
+    if w.numel() != 32 * 27 or wt.numel() != 28 * 32:
+        raise YoloHipError("stem_filter_prep: w must hold 32 x 27 floats, wt 28 x 32")
+    check(_lib.load().yolo_stem_filter_prep(_p(w), _p(bias), _p(wt), _stream()), "yolo_stem_filter_prep")
+
+
+def stem_infer_supported(d):
+    return d.Cin == 3 and d.Cout == 32 and d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.Ho == d.H and d.Wo == d.W
+
+
+def stem_fwd_infer_unit(d, x, wt, epilogue, scale, shift, pred2, in_bound, out, planes, out_words):
+    """the stem's inference unit in one launch (yolo_stem_fwd_infer_unit); out: fp32 result or None; returns the number of
+    words of out_words that hold max|result|"""
+    _chk_f32(x, wt, scale, shift, pred2, out)
+    if planes.numel() < planes_bytes(d.N * d.H * d.W, 32) or out_words.numel() < INFER_BOUND_WORDS:
+        raise YoloHipError("stem_fwd_infer_unit: planes / out_words buffer too small")
+    if out is not None and out.numel() != d.N * d.H * d.W * 32:
+        raise YoloHipError("stem_fwd_infer_unit: output size does not match the descriptor")
+    n = ctypes.c_int(0)
+    check(_lib.load().yolo_stem_fwd_infer_unit(byref(d), _p(x), _p(wt), int(epilogue), _p(scale), _p(shift), _p(pred2),
+                                               _p(in_bound), int(in_bound.numel()), _p(out), _p(planes), _p(out_words),
+                                               byref(n), _stream()), "yolo_stem_fwd_infer_unit")
+    return int(n.value)
+
+
 def fold_bound(words, out_bound):
     """out_bound[0] = max of 1..4096 non-negative floats (bit patterns): the words of a one-pass inference unit as one float"""
     _chk_f32(out_bound)
