@@ -284,6 +284,154 @@ __global__ __launch_bounds__(1024) void stem_wgrad_sum_kernel(const float* __res
   }
 }
 
+// ---- the stem's inference unit in one launch (yolo_stem_fwd_infer_unit) ----
+// At inference sizes (bs 1: 173 k pixels) the training kernel above -- one pixel and 864 dependent FMAs per lane -- is a
+// latency chain (63 us). Here a wave owns ONE 8-channel group of 64 pixels (its 27 x 8 filter slice and folded scale / shift
+// arrive by scalar loads), a workgroup the four groups of those pixels: a quarter of the chain, four times the waves. The
+// folded BatchNormalization and the activation are applied in registers and the result leaves as the planes of the next
+// convolution, scaled by the a-priori bound K max|image| + D (as conv_split_reduce_kernel does); y (fp32) only if somebody
+// reads it; one word of max|result| per workgroup goes to out_words.
+struct StemEpi {
+  const float* scale;
+  const float* shift;
+  int act;
+  unsigned char* planes;
+  const float* pred;
+  const unsigned* in_words;
+  int in_n;
+  unsigned* out_words;
+};
+template <bool STATS, bool EPI>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict__ x, const float* __restrict__ wt,
+                                                       float* __restrict__ y, double* __restrict__ stats,
+                                                       unsigned* __restrict__ absmax, int H, int W, int pad_t, int pad_l,
+                                                       int M, const StemEpi ep) {
+  // The 28 x 32 product (27 taps + a constant 1 for the bias row) on the fp32 matrix cores: v_mfma_f32_32x32x2_f32, rows =
+  // 32 pixels, columns = the 32 channels, 14 steps of two taps. Lane (m = lane & 31, kh = lane >> 5) supplies pixel m's taps
+  // 2i + kh, holds filter rows 2i + kh of channel m in 14 registers for the whole launch, and ends with channel m of 16
+  // pixels in its accumulator: the folded scale / shift are per-lane scalars, a store instruction writes two whole 128-byte
+  // pixel rows, and nothing waits for scalar loads (the FMA form with the filter in SGPRs took 47 us at bs 1).
+  constexpr int TLD = 36;                          // strip rows of 36 floats (16-byte aligned, conflict-free 8-float reads)
+  __shared__ __attribute__((aligned(16))) float strip[4][32 * TLD];
+  __shared__ float s_max[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m = lane & 31, kh = lane >> 5;
+  [[maybe_unused]] float psc = 1.f, sc = 1.f, sh = 0.f;
+  if constexpr (EPI) {
+    float ib = 0.f;
+    for (int i = lane; i < ep.in_n; i += 64) ib = fmaxf(ib, __builtin_bit_cast(float, ep.in_words[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ib = fmaxf(ib, __shfl_xor(ib, o, 64));
+    const float bnd = (ep.pred[0] * ib + ep.pred[1]) * 1.001f + 1e-30f;
+    psc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bnd));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      unsigned* header = reinterpret_cast<unsigned*>(ep.planes + planes_body_bytes(M, STEM_CO));
+      header[0] = __builtin_bit_cast(unsigned, bnd);
+      reinterpret_cast<float*>(header)[1] = psc;
+      reinterpret_cast<float*>(header)[2] = 1.f / psc;
+    }
+    sc = ep.scale[m];
+    sh = ep.shift[m];
+  }
+  float bw[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) bw[i] = wt[(2 * i + kh) * STEM_CO + m];   // (row 27 = bias, met by the constant-1 tap)
+  // training form: channel m's sum / sum of squares / max|.| of this lane's pixels (fp32 inside a tile, fp64 across tiles)
+  [[maybe_unused]] double d1 = 0.0, d2 = 0.0;
+  [[maybe_unused]] float mxs = 0.f;
+  const int HW = H * W;
+  float vmax = 0.f;
+  float* st = &strip[wave][0];
+  const int ntiles = (M + 31) / 32;
+  for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
+    const int p0 = t * 32;
+    const int pm = p0 + m < M ? p0 + m : M - 1;
+    const int n = pm / HW;
+    const int rem = pm - n * HW;
+    const int yy = rem / W, xx = rem - yy * W;
+    float av[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) {
+      // tap j = 2i + kh = (r * 3 + s) * 3 + ci; both candidates are compile-time constants
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int j0 = 2 * i, j1 = 2 * i + 1;
+      const int r = kh ? j1 / 9 : j0 / 9, s3 = kh ? (j1 / 3) % 3 : (j0 / 3) % 3, ci = kh ? j1 % 3 : j0 % 3;
+      const int iy = yy + r - pad_t, ix = xx + s3 - pad_l;
+      const bool tap = (2 * i + kh) < STEM_K;
+      const bool ok = tap && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
+      const float v = x[((long long)(n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3 + (ok ? ci : 0)];
+      av[i] = ok ? v : (tap ? 0.f : 1.f);          // (tap 27 does not exist: the constant that meets the bias row)
+    }
+    f32x16s acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 14; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bw[i], acc, 0, 0, 0);
+    // acc[q] = channel m of pixel p0 + (q & 3) + 8 (q >> 2) + 4 kh
+    if constexpr (EPI) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
+        const float v = act_fwd(fmaf(sc, acc[q], sh), ep.act);
+        st[row * TLD + m] = v;
+        if (p0 + row < M) {
+          vmax = fmaxf(vmax, fabsf(v));
+          if (y != nullptr) y[(long long)(p0 + row) * STEM_CO + m] = v;
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its own strip writes are visible to itself)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int u = lane + 64 * it, px = u >> 2, g8 = u & 3;
+        const f32x4 o0 = *reinterpret_cast<const f32x4*>(st + px * TLD + g8 * 8);
+        const f32x4 o1 = *reinterpret_cast<const f32x4*>(st + px * TLD + g8 * 8 + 4);
+        if (p0 + px < M) store_planes8(ep.planes, p0 + px, g8, STEM_CO, o0, o1, psc);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next tile's writes
+    } else {
+      float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
+        if (p0 + row < M) {
+          const float v = acc[q];
+          __builtin_nontemporal_store(v, &y[(long long)(p0 + row) * STEM_CO + m]);
+          if (STATS) {
+            t1 += v;
+            t2 = fmaf(v, v, t2);
+            mxs = fmaxf(mxs, fabsf(v));
+          }
+        }
+      }
+      if (STATS) {
+        d1 += (double)t1;
+        d2 += (double)t2;
+      }
+    }
+  }
+  if constexpr (STATS) {
+    // lanes m and m + 32 hold the same channel: one fp64 atomic per channel and wave into the workgroup's replica slot
+    d1 += __shfl_xor(d1, 32, 64);
+    d2 += __shfl_xor(d2, 32, 64);
+    mxs = fmaxf(mxs, __shfl_xor(mxs, 32, 64));
+    if (kh == 0) {
+      if (stats != nullptr) {
+        double* slot = stats + (long long)(blockIdx.x & (YOLO_BN_STAT_SLOTS - 1)) * 2 * STEM_CO;
+        atomicAdd(&slot[m], d1);
+        atomicAdd(&slot[STEM_CO + m], d2);
+      }
+      if (absmax != nullptr && __builtin_bit_cast(unsigned, mxs) > absmax[m]) atomicMax(&absmax[m], __builtin_bit_cast(unsigned, mxs));
+    }
+  }
+  if constexpr (!EPI) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+  if (lane == 0) s_max[wave] = vmax;
+  __syncthreads();
+  if (threadIdx.x == 0) ep.out_words[blockIdx.x] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
+}
+
 bool stem_fwd_supported(const yolo_conv_desc* d) {
   static const bool on = [] { const char* e = getenv("YOLO_STEM_DIRECT"); return !(e && atoi(e) == 0); }();
   // (below ~1 M pixels - bs 1 inference - a lane gets a single pixel and the kernel is bound by the latency of its
@@ -326,6 +474,20 @@ int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, con
   }
   int grid = (M + 255) / 256;
   if (grid > per_cu[st_on] * cus) grid = per_cu[st_on] * cus;
+  static const int mfma = [] { const char* e = getenv("YOLO_STEM_MFMA"); return e ? atoi(e) : 0; }();
+  if (sreg && mfma) {
+    float* wt = wt_ring + (size_t)(wt_next++ & 7) * (STEM_K + 1) * STEM_CO;
+    hipLaunchKernelGGL(stem_filter_prep_kernel, dim3(1), dim3(256), 0, st, w, bias, wt);
+    int g2 = ((M + 31) / 32 + 3) / 4;
+    if (g2 > mfma * cus) g2 = mfma * cus;   // (YOLO_STEM_MFMA = workgroups per CU)
+    if (st_on)
+      hipLaunchKernelGGL((stem_mfma_kernel<true, false>), dim3(g2), dim3(256), 0, st, x, wt, y, stats, absmax, d->H, d->W,
+                         d->pad_t, d->pad_l, M, StemEpi{});
+    else
+      hipLaunchKernelGGL((stem_mfma_kernel<false, false>), dim3(g2), dim3(256), 0, st, x, wt, y, stats, absmax, d->H, d->W,
+                         d->pad_t, d->pad_l, M, StemEpi{});
+    return check_launch("stem_mfma_kernel");
+  }
   if (sreg) {
     float* wt = wt_ring + (size_t)(wt_next++ & 7) * (STEM_K + 1) * STEM_CO;
     hipLaunchKernelGGL(stem_filter_prep_kernel, dim3(1), dim3(256), 0, st, w, bias, wt);
@@ -342,109 +504,6 @@ int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, con
     hipLaunchKernelGGL((stem_conv3x3_kernel<false, false>), dim3(grid), dim3(256), 0, st, x, w, bias, y, stats, absmax, d->H,
                        d->W, d->pad_t, d->pad_l, M);
   return check_launch("stem_conv3x3_kernel");
-}
-
-// ---- the stem's inference unit in one launch (yolo_stem_fwd_infer_unit) ----
-// At inference sizes (bs 1: 173 k pixels) the training kernel above -- one pixel and 864 dependent FMAs per lane -- is a
-// latency chain (63 us). Here a wave owns ONE 8-channel group of 64 pixels (its 27 x 8 filter slice and folded scale / shift
-// arrive by scalar loads), a workgroup the four groups of those pixels: a quarter of the chain, four times the waves. The
-// folded BatchNormalization and the activation are applied in registers and the result leaves as the planes of the next
-// convolution, scaled by the a-priori bound K max|image| + D (as conv_split_reduce_kernel does); y (fp32) only if somebody
-// reads it; one word of max|result| per workgroup goes to out_words.
-struct StemEpi {
-  const float* scale;
-  const float* shift;
-  int act;
-  unsigned char* planes;
-  const float* pred;
-  const unsigned* in_words;
-  int in_n;
-  unsigned* out_words;
-};
-__global__ __launch_bounds__(256) void stem_infer_kernel(const float* __restrict__ x, const float* __restrict__ wt,
-                                                        float* __restrict__ y, int H, int W, int pad_t, int pad_l, int M,
-                                                        const StemEpi ep) {
-  // The 28 x 32 product (27 taps + a constant 1 for the bias row) on the fp32 matrix cores: v_mfma_f32_32x32x2_f32, rows =
-  // 32 pixels, columns = the 32 channels, 14 steps of two taps. Lane (m = lane & 31, kh = lane >> 5) supplies pixel m's taps
-  // 2i + kh, holds filter rows 2i + kh of channel m in 14 registers for the whole launch, and ends with channel m of 16
-  // pixels in its accumulator: the folded scale / shift are per-lane scalars, a store instruction writes two whole 128-byte
-  // pixel rows, and nothing waits for scalar loads (the FMA form with the filter in SGPRs took 47 us at bs 1).
-  constexpr int TLD = 36;                          // strip rows of 36 floats (16-byte aligned, conflict-free 8-float reads)
-  __shared__ __attribute__((aligned(16))) float strip[4][32 * TLD];
-  __shared__ float s_max[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int m = lane & 31, kh = lane >> 5;
-  float ib = 0.f;
-  for (int i = lane; i < ep.in_n; i += 64) ib = fmaxf(ib, __builtin_bit_cast(float, ep.in_words[i]));
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) ib = fmaxf(ib, __shfl_xor(ib, o, 64));
-  const float bnd = (ep.pred[0] * ib + ep.pred[1]) * 1.001f + 1e-30f;
-  const float psc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bnd));
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    unsigned* header = reinterpret_cast<unsigned*>(ep.planes + planes_body_bytes(M, STEM_CO));
-    header[0] = __builtin_bit_cast(unsigned, bnd);
-    reinterpret_cast<float*>(header)[1] = psc;
-    reinterpret_cast<float*>(header)[2] = 1.f / psc;
-  }
-  float bw[14];
-#pragma unroll
-  for (int i = 0; i < 14; ++i) bw[i] = wt[(2 * i + kh) * STEM_CO + m];   // (row 27 = bias, met by the constant-1 tap)
-  const float sc = ep.scale[m], sh = ep.shift[m];
-  const int HW = H * W;
-  float vmax = 0.f;
-  float* st = &strip[wave][0];
-  const int ntiles = (M + 31) / 32;
-  for (int t = blockIdx.x * 4 + wave; t < ntiles; t += gridDim.x * 4) {
-    const int p0 = t * 32;
-    const int pm = p0 + m < M ? p0 + m : M - 1;
-    const int n = pm / HW;
-    const int rem = pm - n * HW;
-    const int yy = rem / W, xx = rem - yy * W;
-    float av[14];
-#pragma unroll
-    for (int i = 0; i < 14; ++i) {
-      // tap j = 2i + kh = (r * 3 + s) * 3 + ci; both candidates are compile-time constants
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int j0 = 2 * i, j1 = 2 * i + 1;
-      const int r = kh ? j1 / 9 : j0 / 9, s3 = kh ? (j1 / 3) % 3 : (j0 / 3) % 3, ci = kh ? j1 % 3 : j0 % 3;
-      const int iy = yy + r - pad_t, ix = xx + s3 - pad_l;
-      const bool tap = (2 * i + kh) < STEM_K;
-      const bool ok = tap && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-      const float v = x[((long long)(n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3 + (ok ? ci : 0)];
-      av[i] = ok ? v : (tap ? 0.f : 1.f);          // (tap 27 does not exist: the constant that meets the bias row)
-    }
-    f32x16s acc;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 14; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bw[i], acc, 0, 0, 0);
-    // acc[q] = channel m of pixel p0 + (q & 3) + 8 (q >> 2) + 4 kh
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
-      const float v = act_fwd(fmaf(sc, acc[q], sh), ep.act);
-      st[row * TLD + m] = v;
-      if (p0 + row < M) {
-        vmax = fmaxf(vmax, fabsf(v));
-        if (y != nullptr) y[(long long)(p0 + row) * STEM_CO + m] = v;
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its own strip writes are visible to itself)
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int u = lane + 64 * it, px = u >> 2, g8 = u & 3;
-      const f32x4 o0 = *reinterpret_cast<const f32x4*>(st + px * TLD + g8 * 8);
-      const f32x4 o1 = *reinterpret_cast<const f32x4*>(st + px * TLD + g8 * 8 + 4);
-      if (p0 + px < M) store_planes8(ep.planes, p0 + px, g8, STEM_CO, o0, o1, psc);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next tile's writes
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-  if (lane == 0) s_max[wave] = vmax;
-  __syncthreads();
-  if (threadIdx.x == 0) ep.out_words[blockIdx.x] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
 }
 
 // one word of max|x| per workgroup (no atomics, nothing to zero): the bound of a tensor nobody recorded one for -- the image
@@ -510,9 +569,10 @@ int launch_stem_infer(const yolo_conv_desc* d, const float* x, const float* wt, 
   ep.scale = e.scale; ep.shift = e.shift; ep.act = e.act;
   ep.planes = reinterpret_cast<unsigned char*>(e.planes);
   ep.pred = e.pred; ep.in_words = e.in_words; ep.in_n = e.in_n; ep.out_words = e.out_words;
-  hipLaunchKernelGGL(stem_infer_kernel, dim3(grid), dim3(256), 0, st, x, wt, y, d->H, d->W, d->pad_t, d->pad_l, M, ep);
+  hipLaunchKernelGGL((stem_mfma_kernel<false, true>), dim3(grid), dim3(256), 0, st, x, wt, y, (double*)nullptr,
+                     (unsigned*)nullptr, d->H, d->W, d->pad_t, d->pad_l, M, ep);
   *out_n = grid;
-  return check_launch("stem_infer_kernel");
+  return check_launch("stem_mfma_kernel(infer)");
 }
 
 }  // namespace yolo
