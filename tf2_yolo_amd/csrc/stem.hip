@@ -336,6 +336,18 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
   float bw[14];
 #pragma unroll
   for (int i = 0; i < 14; ++i) bw[i] = wt[(2 * i + kh) * STEM_CO + m];   // (row 27 = bias, met by the constant-1 tap)
+  // per-lane constants of tap j = 2i + kh = (r * 3 + s) * 3 + ci (both candidates are compile-time constants): row / column
+  // offset for the bounds test, float offset from the pixel's own first channel
+  int toff[14];
+  short tdr[14], tds[14];
+#pragma unroll
+  for (int i = 0; i < 14; ++i) {
+    const int j0 = 2 * i, j1 = 2 * i + 1;
+    const int r = kh ? j1 / 9 : j0 / 9, s3 = kh ? (j1 / 3) % 3 : (j0 / 3) % 3, ci = kh ? j1 % 3 : j0 % 3;
+    tdr[i] = (short)((2 * i + kh) < STEM_K ? r - pad_t : -20000);   // (tap 27: never in range)
+    tds[i] = (short)(s3 - pad_l);
+    toff[i] = ((r - pad_t) * W + (s3 - pad_l)) * 3 + ci;
+  }
   // training form: channel m's sum / sum of squares / max|.| of this lane's pixels (fp32 inside a tile, fp64 across tiles)
   [[maybe_unused]] double d1 = 0.0, d2 = 0.0;
   [[maybe_unused]] float mxs = 0.f;
@@ -349,20 +361,18 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
     const int n = pm / HW;
     const int rem = pm - n * HW;
     const int yy = rem / W, xx = rem - yy * W;
+    // pixel (n, yy, xx) IS linear pixel pm: tap (dr, ds, ci) of it sits at float pm * 3 + toff -- one add per tap (the first
+    // version rebuilt a 64-bit ((n * H + iy) * W + ix) * 3 + ci per tap: 2000 cycles of integer multiplies per tile where
+    // the MFMAs need 900)
     float av[14];
+    const int base = pm * 3;
 #pragma unroll
     for (int i = 0; i < 14; ++i) {
-      // tap j = 2i + kh = (r * 3 + s) * 3 + ci; both candidates are compile-time constants
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int j0 = 2 * i, j1 = 2 * i + 1;
-      const int r = kh ? j1 / 9 : j0 / 9, s3 = kh ? (j1 / 3) % 3 : (j0 / 3) % 3, ci = kh ? j1 % 3 : j0 % 3;
-      const int iy = yy + r - pad_t, ix = xx + s3 - pad_l;
-      const bool tap = (2 * i + kh) < STEM_K;
-      const bool ok = tap && ((unsigned)iy < (unsigned)H) && ((unsigned)ix < (unsigned)W);
-      const float v = x[((long long)(n * H + (ok ? iy : 0)) * W + (ok ? ix : 0)) * 3 + (ok ? ci : 0)];
-      av[i] = ok ? v : (tap ? 0.f : 1.f);          // (tap 27 does not exist: the constant that meets the bias row)
+      const bool ok = ((unsigned)(yy + tdr[i]) < (unsigned)H) && ((unsigned)(xx + tds[i]) < (unsigned)W);
+      const float v = x[ok ? base + toff[i] : 0];
+      av[i] = ok ? v : 0.f;
     }
+    if (kh) av[13] = 1.f;   // tap 27 does not exist: the constant that meets the bias row of the prepared filter
     f32x16s acc;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[q] = 0.f;
@@ -375,10 +385,9 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
         const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
         const float v = act_fwd(fmaf(sc, acc[q], sh), ep.act);
         st[row * TLD + m] = v;
-        if (p0 + row < M) {
-          vmax = fmaxf(vmax, fabsf(v));
-          if (y != nullptr) y[(long long)(p0 + row) * STEM_CO + m] = v;
-        }
+        const bool live = p0 + row < M;
+        vmax = fmaxf(vmax, live ? fabsf(v) : 0.f);
+        if (y != nullptr && live) y[(long long)(p0 + row) * STEM_CO + m] = v;
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its own strip writes are visible to itself)
 #pragma unroll
@@ -390,19 +399,23 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next tile's writes
     } else {
+      // (branch-free: a per-row "if" turns into sixteen exec-mask blocks; rows past the end count as zeros)
+      const bool full = p0 + 32 <= M;
       float t1 = 0.f, t2 = 0.f;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
-        if (p0 + row < M) {
-          const float v = acc[q];
-          __builtin_nontemporal_store(v, &y[(long long)(p0 + row) * STEM_CO + m]);
-          if (STATS) {
-            t1 += v;
-            t2 = fmaf(v, v, t2);
-            mxs = fmaxf(mxs, fabsf(v));
-          }
+        const float v = (full || p0 + row < M) ? acc[q] : 0.f;
+        if (STATS) {
+          t1 += v;
+          t2 = fmaf(v, v, t2);
+          mxs = fmaxf(mxs, fabsf(v));
         }
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
+        if (full || p0 + row < M) __builtin_nontemporal_store(acc[q], &y[(long long)(p0 + row) * STEM_CO + m]);
       }
       if (STATS) {
         d1 += (double)t1;
@@ -474,7 +487,9 @@ int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, con
   }
   int grid = (M + 255) / 256;
   if (grid > per_cu[st_on] * cus) grid = per_cu[st_on] * cus;
-  static const int mfma = [] { const char* e = getenv("YOLO_STEM_MFMA"); return e ? atoi(e) : 0; }();
+  // the fp32 matrix-core form (stem_mfma_kernel) is the default: 8 workgroups per CU; YOLO_STEM_MFMA=0 selects the FMA kernel
+  // above (same-box A/B of the whole step: 29.98 -> 29.87 ms)
+  static const int mfma = [] { const char* e = getenv("YOLO_STEM_MFMA"); return e ? atoi(e) : 8; }();
   if (sreg && mfma) {
     float* wt = wt_ring + (size_t)(wt_next++ & 7) * (STEM_K + 1) * STEM_CO;
     hipLaunchKernelGGL(stem_filter_prep_kernel, dim3(1), dim3(256), 0, st, w, bias, wt);
