@@ -1,9 +1,13 @@
 // The RGB stem: Conv2D(32, 3, padding="same") on the 3-channel image, the first layer of every Darknet body
 // (yolov3/models/backbone.py:60, yolov4/models/backbone.py:127, yolov2/models/backbone.py:44).
 // K = 27 and a 32-channel output at full resolution make it a WRITE-bound layer (bs 32 at 416x416: 66 MB in,
-// 709 MB out, 9.6 GFLOP): the implicit-GEMM kernels spend their time on 27-wide gathers, so the stem gets a
-// direct fp32 kernel - one pixel per lane, the 27 x 32 filter broadcast from LDS, exact fp32 FMA chains, the
-// BatchNorm statistics of the output accumulated on the way.
+// 709 MB out, 9.6 GFLOP): the implicit-GEMM kernels spend their time on 27-wide gathers, so the stem has kernels of its
+// own. Default (round 3): stem_mfma_kernel -- the 28 x 32 product (27 taps + the bias row) on the fp32 matrix cores, 14 x
+// v_mfma_f32_32x32x2_f32 per 32 pixels, BatchNorm statistics per lane (a lane ends up with ONE channel of 16 pixels), and
+// with an epilogue flag the whole inference unit (folded BatchNormalization + activation + planes of the next layer).
+// stem_conv3x3_kernel (rounds 1-2, YOLO_STEM_MFMA=0) is the direct FMA form: one pixel per lane, the filter through the
+// scalar cache, exact fp32 FMA chains. The backward (stem_bn_bwd_wgrad_kernel) fuses the BatchNorm backward apply with the
+// filter gradient.
 #include "common.hpp"
 #include "conv_args.hpp"
 #include "act.hpp"
