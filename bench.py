@@ -54,6 +54,12 @@ def hbm_traffic_from_profile(kernel):
     prof = json.load(open(paths[-1]))["kernels"]
     if kernel in prof:           # split kernels: the timer name is the rocprof name without "void yolo::" and spaces
         return prof[kernel]["hbm_bytes_per_launch"]
+    # the timer's name is the kernel's leading template arguments (tile shape); rocprof's name carries the trailing ones too
+    # (ring depth, diagnostic flags, class / split instantiations): launch-weighted mean over the instantiations of the shape
+    fam = [v for n, v in prof.items() if n.startswith(kernel[:-1] + ",") and kernel.endswith(">")]
+    cnt = sum(v["launches"] for v in fam)
+    if cnt:
+        return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / cnt)
     base, _, rest = kernel.partition("<")
     dims = rest.rstrip(">").split(",")
     flat = "true" if "flat" in dims else "false"
