@@ -416,11 +416,18 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
           mxs = fmaxf(mxs, fabsf(v));
         }
       }
+      // through the wave's strip so that one store instruction writes 1 KB of consecutive output (8 pixels x 128 B) instead
+      // of 64 dwords in two 128-byte pieces
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int row = (q & 3) + 8 * (q >> 2) + 4 * kh;
-        if (full || p0 + row < M) __builtin_nontemporal_store(acc[q], &y[(long long)(p0 + row) * STEM_CO + m]);
+      for (int q = 0; q < 16; ++q) st[((q & 3) + 8 * (q >> 2) + 4 * kh) * TLD + m] = acc[q];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (one wave: its own strip writes are visible to itself)
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int px = it * 8 + (lane >> 3), c4 = lane & 7;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(st + px * TLD + c4 * 4);
+        if (full || p0 + px < M) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(y + (long long)(p0 + px) * STEM_CO + c4 * 4));
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // strip reads done before the next tile's writes
       if (STATS) {
         d1 += (double)t1;
         d2 += (double)t2;
