@@ -456,13 +456,20 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const float* __restrict_
   if (threadIdx.x == 0) ep.out_words[blockIdx.x] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3])));
 }
 
+static int stem_mfma_per_cu() {
+  // the fp32 matrix-core form (stem_mfma_kernel) is the default: 8 workgroups per CU; YOLO_STEM_MFMA=0 selects the FMA kernel
+  // (same-box A/B of the whole step: 29.98 -> 29.87 ms)
+  static const int v = [] { const char* e = getenv("YOLO_STEM_MFMA"); return e ? atoi(e) : 8; }();
+  return v;
+}
+
 bool stem_fwd_supported(const yolo_conv_desc* d) {
   static const bool on = [] { const char* e = getenv("YOLO_STEM_DIRECT"); return !(e && atoi(e) == 0); }();
-  // (below ~1 M pixels - bs 1 inference - a lane gets a single pixel and the kernel is bound by the latency of its
-  // 216 LDS filter reads: the implicit-GEMM kernel is faster there, 3.76 vs 4.0 ms for the whole bs-1 forward)
+  // (the FMA kernel below ~1 M pixels - bs 1 inference - gives a lane a single pixel and is bound by the latency of its
+  // filter loads: the implicit-GEMM kernel is faster there; the matrix-core form has no such floor)
   const long long M = (long long)d->N * d->H * d->W;
   return on && d->Cin == 3 && d->Cout == STEM_CO && d->kh == 3 && d->kw == 3 && d->sh == 1 && d->sw == 1 &&
-         d->Ho == d->H && d->Wo == d->W && M >= (1LL << 20) && M < (1LL << 31) - (1 << 20);
+         d->Ho == d->H && d->Wo == d->W && (stem_mfma_per_cu() > 0 || M >= (1LL << 20)) && M < (1LL << 31) - (1 << 20);
 }
 
 int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, const float* bias, float* y, double* stats,
@@ -498,9 +505,7 @@ int launch_stem_fwd(const yolo_conv_desc* d, const float* x, const float* w, con
   }
   int grid = (M + 255) / 256;
   if (grid > per_cu[st_on] * cus) grid = per_cu[st_on] * cus;
-  // the fp32 matrix-core form (stem_mfma_kernel) is the default: 8 workgroups per CU; YOLO_STEM_MFMA=0 selects the FMA kernel
-  // above (same-box A/B of the whole step: 29.98 -> 29.87 ms)
-  static const int mfma = [] { const char* e = getenv("YOLO_STEM_MFMA"); return e ? atoi(e) : 8; }();
+  const int mfma = stem_mfma_per_cu();
   if (sreg && mfma) {
     float* wt = wt_ring + (size_t)(wt_next++ & 7) * (STEM_K + 1) * STEM_CO;
     hipLaunchKernelGGL(stem_filter_prep_kernel, dim3(1), dim3(256), 0, st, w, bias, wt);
