@@ -298,6 +298,7 @@ class Network:
         self._overlap_wgrad = os.environ.get("YOLO_BWD_OVERLAP", "1") != "0"
         self._prep_beside = os.environ.get("YOLO_PREP_OVERLAP", "1") != "0"   # filter preparation beside the stem
         self._stem_fused = os.environ.get("YOLO_STEM_FUSED_BWD", "1") != "0"  # stem: BN backward apply + wgrad in one pass
+        self._bn_tight = int(os.environ.get("YOLO_BN_TIGHT_BOUND", "0"))
         self._res_from_planes = os.environ.get("YOLO_RES_PLANES", "1") != "0"  # residual adds read the planes, not an fp32 copy
         self._wp_event = self._wT_event = None
         self._use_infer_graph = os.environ.get("YOLO_INFER_GRAPH", "1") != "0"
@@ -608,11 +609,18 @@ class Network:
         self._wTp_valid = True
 
     def _conv_fwd(self, u, xin, w, bias, out, stats=None):
-        amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout] if stats is not None else None
+        amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout] if (stats is not None and self._tight_bound(u)) else None
         if u.planes_fwd:
             return ops.conv2d_fwd_planes(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias,
                                          out=out, stats=stats, absmax=amax)
         return ops.conv2d_fwd(u.desc, xin, w, bias, out=out, stats=stats, absmax=amax)
+
+    def _tight_bound(self, u):
+        """whether the conv epilogue records per-channel max|y| for the bound of the BatchNorm output (YOLO_BN_TIGHT_BOUND:
+        0 never, 1 always, 2 = not for 1x1 layers). Without it bn_finalize takes |y - mean| <= sqrt(P var), sqrt(P) / (max / sigma)
+        ~ 2^6 looser: the planes' absolute error floor moves from 2^-40 to 2^-34 of the bound (planes.hpp)."""
+        m = self._bn_tight
+        return m == 1 or (m == 2 and u.k != 1)
 
     def _bn_bufs(self, u):
         c = u.cout
@@ -724,7 +732,8 @@ class Network:
                                         self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
                                         scale, shift, smean, sinv, unbiased=self.unbiased_moving_var,
                                         bound=self._aux[u.aux_off:u.aux_off + 1],
-                                        absmax=self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout], mean_offset=bias)
+                                        absmax=(self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout]
+                                                if self._tight_bound(u) else None), mean_offset=bias)
                     elif self._fuse_infer and self._fused_infer_unit(u, bias, gamma, beta, scale, shift):
                         continue
                     elif self._fuse_infer and self._infer_onepass and self._stem_infer_unit(u, xin, w, bias, gamma, beta, scale, shift):
