@@ -14,6 +14,17 @@ for (h, cin, cout, k) in [(52, 128, 256, 3), (26, 256, 512, 3), (13, 512, 1024, 
     st = torch.zeros(ops.BN_STAT_SLOTS * 2 * cout, device="cuda", dtype=torch.float64)
     am = torch.zeros(cout, device="cuda", dtype=torch.int32)
     res = {}
+    def plain():
+        ops.conv2d_fwd_planes(d, xp, wp, None, out=y)
+    for _ in range(3): plain()
+    torch.cuda.synchronize()
+    ev = []
+    for _ in range(20):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); plain(); e1.record(); ev.append((e0, e1))
+    torch.cuda.synchronize()
+    t = sorted(p_.elapsed_time(q_) * 1e3 for p_, q_ in ev)
+    res["no statistics at all"] = t[len(t) // 2]
     for name, a in (("with absmax", am), ("without", None), ("with absmax, zeroed each launch", "z")):
         def f():
             if a is "z":
