@@ -84,6 +84,11 @@ int main(int argc, char** argv) {
   void* ws;
   CK(hipMalloc(&ws, yolo_conv_workspace_bytes()));
   YK(yolo_set_conv_workspace(ws, yolo_conv_workspace_bytes(), st));
+  if (getenv("CONV_BENCH_WGRAD_WS") != nullptr) {   // the reproducible filter-gradient form (slabs + ordered reduce), as Network runs it
+    void* wws;
+    CK(hipMalloc(&wws, yolo_wgrad_workspace_bytes()));
+    YK(yolo_set_wgrad_workspace(wws, yolo_wgrad_workspace_bytes()));
+  }
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));

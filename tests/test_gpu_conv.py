@@ -871,6 +871,68 @@ def test_conv_wgrad_planes_reproducible(case):
         assert _relerr((db1 - 0.25).double().cpu(), b.grad) < TOL and _relerr(db1.double(), db_a.double()) < 1e-5
 
 
+# ---- 3x3 stride-1 filter gradient with the input window in LDS (csrc/conv_wgrad_win.hip; yolo_set_option key 6) ----
+# Cout % 128 == 0, Cin % 32 == 0, 3x3 stride 1 'same', 32 / W + 2 <= H, 2 W + 81 <= 512
+WGRAD_WIN_CASES = [
+    (4, 26, 26, 128, 256, 3, 1, "same", False),       # 8 tiles, several splits
+    (2, 13, 13, 64, 128, 3, 1, "same", True),         # stages that cross image rows and images; bias
+    (3, 8, 7, 32, 128, 3, 1, "same", False),          # 56-pixel images: every stage crosses rows, most cross an image
+    (1, 19, 38, 64, 128, 3, 1, "same", False),        # H != W
+    (5, 13, 13, 32, 256, 3, 1, "same", False),        # 845 pixels: not a multiple of 16 (zero rows of the last planes block)
+    (2, 76, 76, 32, 128, 3, 1, "same", False),        # the longest rows the 256-slot ring takes (2 W + 81 <= 256 up to 87)
+    (1, 104, 104, 32, 128, 3, 1, "same", False),      # 512-slot ring
+    (8, 52, 52, 128, 256, 3, 1, "same", False),       # a benchmark layer at bs 8
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_WIN_CASES)
+def test_conv_wgrad_window_kernel(case):
+    """wgrad_win_kernel: all nine taps of 32 input channels from ONE ring of x pixels in LDS, borders by pointing invalid
+    (pixel, tap) pairs at a zero slot. Against the float64 oracle (1e-4), against the per-tap kernel (fp32 summation order),
+    accumulation into dw, and -- with the workspace registered -- bit-identical from run to run."""
+    from tf2_yolo_amd import _lib, ops
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=21)
+    wk.requires_grad_(True)
+    ref = L.conv2d(x, wk, None, stride=s, padding=pad)
+    g = torch.Generator().manual_seed(22)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    want = _krsc(wk.grad)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    xp = ops.split_planes(x.float().cuda(), n * h * w, cin)
+    dyd = dy.float().cuda()
+    dyp = ops.split_planes(dyd, n * d.Ho * d.Wo, cout)
+    lib = _lib.load()
+
+    def run(win, fill=0.0):
+        ops.set_option(ops.OPT_WGRAD_WIN, win)
+        dw = torch.full((cout, k, k, cin), fill, device="cuda")
+        db = torch.zeros(cout, device="cuda") if bias else None
+        ops.conv2d_wgrad_planes(d, xp, dyp, dw, dy=dyd, dbias=db)
+        torch.cuda.synchronize()
+        return dw, db
+    try:
+        _lib.check(lib.yolo_set_wgrad_workspace(None, 0), "yolo_set_wgrad_workspace")     # atomics
+        ops._WGRAD_WS = None
+        dw_old, _ = run(0)
+        dw_at, db_at = run(1)
+        assert _relerr(dw_at.double().cpu(), want) < TOL
+        assert _relerr(dw_at.double(), dw_old.double()) < 1e-5
+        if bias:
+            assert _relerr(db_at.double().cpu(), dy.sum((0, 1, 2))) < TOL
+        ops.ensure_wgrad_workspace()                                                      # slabs + ordered reduce
+        dw1, _ = run(1, 0.5)
+        dw2, _ = run(1, 0.5)
+        assert torch.equal(dw1, dw2)
+        assert _relerr((dw1 - 0.5).double().cpu(), want) < TOL
+        # border handling, element by element: the corner taps of the first / last filter rows
+        err = ((dw1 - 0.5).double().cpu() - want).abs().amax(dim=(0, 3)) / want.abs().amax()
+        assert float(err.max()) < TOL, err
+    finally:
+        ops.reset_options()
+
+
 def test_batched_filter_split_equals_per_tensor_split():
     """yolo_split_planes_batch / yolo_filter_transpose_batch (one launch for every filter of a network) against the
     per-tensor entry points, byte for byte: ragged row counts, a job smaller than one workgroup, and a transposed

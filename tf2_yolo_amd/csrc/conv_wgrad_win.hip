@@ -1,0 +1,374 @@
+// Filter gradient of 3x3 stride-1 "same" convolutions with the INPUT WINDOW kept in LDS (round 4).
+//   dW[co][t][ci] += sum_p dy[p][co] * x[p + dy_t * W + dx_t][ci]        (zero outside the image)
+// wgrad_planes_kernel (conv_wgrad_planes.hip) gives a workgroup 128 filters x 128 columns of ONE tap and streams, for
+// every one of the nine taps, the shifted pixels of x from L2 again: 341 B of operands per MFMA through L2 -> LDS (1.56 GB per
+// launch on 52x52x128->256), and its own knock-outs show the DMA side as the largest single cost (159 -> 97 us without it).
+// Here a workgroup owns 128 filters x (9 taps x 32 input channels). The contraction runs over pixels in linear order, so the
+// x rows a tap needs are the SAME rows shifted by dy*W + dx pixels: x is streamed ONCE through a ring of RING pixel slots in
+// LDS (32 new pixels per 32-pixel stage) and every tap's B fragment is a transposing read (ds_read_b64_tr_b16) at
+// "my pixel + tap shift" in that ring; image borders are handled by pointing the lanes of an invalid (pixel, tap) pair at an
+// all-zero slot. Per stage a workgroup moves 16 KiB of dy + 4 KiB of x for 216 MFMAs: 95 B per MFMA (3.6x less).
+//
+//   wave w: filters co0 + 32 w .. + 31, all nine taps of the 32 channels: nine 32x32 accumulators (144 registers),
+//           two waves per SIMD, two workgroups per CU.
+//   dy (A): staged exactly as in wgrad_planes_kernel (pieces of 16 pixels x 32 filters of one plane, lane-linear image
+//           [pixel quad][sub-block][pixel], conflict-free transposed reads), two stage buffers.
+//   x  (B): ring [plane][slot = pixel mod RING][64 B = 32 channels]; a DMA piece = 16 pixels of one plane; the four pixels of
+//           a transposed read are consecutive slots = 256 contiguous bytes: conflict-free at any tap shift.
+// One barrier per 32-pixel stage (54 MFMAs per wave), loads of stage s+1 issued at the head of stage s.
+// The partial of every workgroup goes to its slab (accumulator order) and wgrad_win_reduce_kernel adds the splits in order:
+// bit-reproducible like the per-tap kernel; without a registered workspace the epilogue falls back to fp32 atomics.
+#include "planes.hpp"
+#include <cstdlib>
+
+namespace yolo {
+
+typedef short ws16x4 __attribute__((ext_vector_type(4)));
+typedef short ws16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WW_CO = 128;       // filters per workgroup
+constexpr int WW_CI = 32;        // input channels per workgroup (all nine taps)
+constexpr int WW_STAGE_PX = 32;  // pixels per stage (two MFMA k-steps)
+constexpr int WW_TILE_FLOATS = WW_CO * 9 * WW_CI;
+
+// KO: diagnostic knock-outs (wrong results): 1 = no DMAs in the loop, 2 = no fragment reads, 4 = no MFMAs, 8 = no border masks
+template <int RING, int KO = 0>
+__global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradArgs a) {
+  constexpr int A_STAGE = 2 * 4 * PL_PLANES * 1024;   // [k-step][filter block][plane][1 KiB piece]
+  constexpr int WIN_PLANE = RING * 64 + 64;           // ring + one all-zero slot
+  constexpr int WIN_OFF = 2 * A_STAGE;
+  constexpr unsigned RMASK = RING * 64 - 1;
+  constexpr unsigned ZSLOT = RING * 64;               // byte offset of the zero slot inside a plane of the window
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds_base = (unsigned)(size_t)smem;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  const int lid = xcd_remap(blockIdx.x, a.nblocks);
+  const int tiles = a.tiles_co * a.tiles_j;
+  const int split = lid / tiles;
+  const int tile = lid - split * tiles;
+  const int co0 = (tile % a.tiles_co) * WW_CO;
+  const int ci0 = (tile / a.tiles_co) * WW_CI;
+  const int p_begin = (int)((long long)split * a.chunk);   // multiple of 32
+  int p_end = p_begin + (int)a.chunk;
+  if (p_end > (int)a.M) p_end = (int)a.M;
+  if (p_begin >= p_end) return;
+  const int nst = (p_end - p_begin + WW_STAGE_PX - 1) / WW_STAGE_PX;
+  const int W = a.Ws, H = a.Hs, M = (int)a.M;
+
+  if (lds_base != 0) __builtin_trap();   // the window reads below address LDS from 0
+  // zero slots of the two window planes
+  if (tid < 32) reinterpret_cast<unsigned*>(smem + WIN_OFF + (tid >> 4) * WIN_PLANE + ZSLOT)[tid & 15] = 0u;
+
+  // ---- loader roles ----
+  // dy: this wave's 32-filter block, pieces (k-step j, plane): lane -> pixel 4 (l >> 4) + (l & 3), sub-block (l >> 2) & 3
+  const unsigned strideA = (unsigned)((a.Cout >> 4) * PL_RECORD);
+  const unsigned strideB = (unsigned)((a.Cs >> 4) * PL_RECORD);
+  const unsigned zeroA = (unsigned)a.zero_blk_dy * strideA, zeroB = (unsigned)a.zero_blk_src * strideB;
+  const i32x4 rsrcA = planes_rsrc(a.dy, a.dy_bytes), rsrcB = planes_rsrc(a.src, a.src_bytes);
+  const int lpix = 4 * (lane >> 4) + (lane & 3), lsb = (lane >> 2) & 3;
+  const unsigned a_lane = (unsigned)(((co0 + wave * 32) >> 4) + (lsb >> 1)) * PL_RECORD + (lsb & 1) * 256 + lpix * 16;
+  auto issue_A = [&](int stage, int buf) {   // 4 DMAs: the two 16-pixel blocks of the stage, both planes
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pb16 = p_begin + stage * WW_STAGE_PX + j * 16;
+      const unsigned v = (pb16 < p_end) ? (unsigned)(pb16 >> 4) * strideA + a_lane : zeroA;
+#pragma unroll
+      for (int p = 0; p < PL_PLANES; ++p) {
+        const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + buf * A_STAGE + ((j * 4 + wave) * PL_PLANES + p) * 1024);
+        dma16(rsrcA, v, (unsigned)(p * 512), l);
+      }
+    }
+  };
+  // x: one piece = 16 consecutive pixels of one plane of the 32 channels: lane -> pixel l >> 2, 8-channel chunk l & 3
+  const int bpx = lane >> 2, bch = lane & 3;
+  const unsigned b_lane = (unsigned)((ci0 >> 4) + (bch >> 1)) * PL_RECORD + (bch & 1) * 256;
+  auto issue_B = [&](int P0, int plane) {   // P0: first pixel of the group (multiple of 16, may be < 0 or >= M)
+    const int P = P0 + bpx;
+    const unsigned v = ((unsigned)P < (unsigned)M) ? (unsigned)(P >> 4) * strideB + b_lane + (P & 15) * 16 : zeroB;
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + WIN_OFF + plane * WIN_PLANE + (unsigned)((P0 & (RING - 1)) * 64));
+    dma16(rsrcB, v, (unsigned)(plane * 512), l);
+  };
+
+  // ---- prologue: the window [lo, Lbase) and dy of stage 0 ----
+  const int lo = (p_begin - W - 1) & ~15;
+  const int Lbase = (p_begin + W + 33 + 15) & ~15;   // the loads issued in stage s (32 pixels from Lbase + 32 s) complete stage s + 1
+  {
+    const int npieces = ((Lbase - lo) >> 4) * PL_PLANES;
+    for (int idx = wave; idx < npieces; idx += 4) issue_B(lo + (idx >> 1) * 16, idx & 1);
+  }
+  issue_A(0, 0);
+
+  // ---- reader roles ----
+  // transposed reads (as wgrad_planes_kernel): 16-lane group g -> channel half g & 1, pixel half g >> 1; lane (qq, pq) of the
+  // group supplies pixel qq of the read, channels 4 pq .. 4 pq + 3 of the half
+  const int grp = lane >> 4, i16 = lane & 15;
+  const int qq = i16 >> 2, pq = i16 & 3;
+  const int tr_off = ((2 * (grp >> 1)) * 16 + ((grp & 1) * 2 + (pq >> 1)) * 4 + qq) * 16 + (pq & 1) * 8;   // dy pieces
+  const unsigned lc = (unsigned)((2 * (grp & 1) + (pq >> 1)) * 16 + (pq & 1) * 8);                        // inside a window slot
+  typedef ws16x4 __attribute__((address_space(3))) * lds_p;
+  // the lane's four pixels of a stage: k-step j, read r -> pixel p0 + 16 j + 8 (grp >> 1) + 4 r + qq
+  unsigned pb[2][2];   // ring byte offset of the pixel's slot + lc
+  int px[2][2], py[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int p = p_begin + 16 * j + 8 * (grp >> 1) + 4 * r + qq;
+      pb[j][r] = (((unsigned)p & (RING - 1)) << 6) + lc;
+      const int row = p / W;
+      px[j][r] = p - row * W;
+      py[j][r] = row % H;
+    }
+  const int adv_rows = WW_STAGE_PX / W, adv_rem = WW_STAGE_PX - adv_rows * W;   // 32 pixels = adv_rows rows + adv_rem pixels
+  int shb[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) shb[t] = ((t / 3 - 1) * W + (t % 3 - 1)) * 64;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // The stage body is scheduled by hand (sched_barrier(0) between the groups: hipcc otherwise issues a tap's four fragment
+  // reads right in front of its MFMAs and waits for them): per tap-step i = (k-step j, tap t)
+  //   MFMA 1 of i | the 4 fragment reads of i + 1 | MFMA 2 of i | the addresses of i + 2 (VALU) | MFMA 3 of i
+  // two fragment register sets, two address sets; the dy fragments of k-step 1 are read during tap-step 6.
+  // (dynamic LDS starts at address 0 in a kernel without static LDS: the window reads take WIN_OFF as an immediate offset)
+  auto rd_pair = [&](unsigned a0, unsigned a1, int off) -> f16x8 {
+    const ws16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(size_t)(a0 + off));
+    const ws16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(size_t)(a1 + off));
+    const ws16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(f16x8, v);
+  };
+  const unsigned zl = ZSLOT + lc;
+  for (int s = 0; s < nst; ++s) {
+    if constexpr (!(KO & 1)) {
+      issue_A(s + 1, (s + 1) & 1);                                   // (past the end: the zero block)
+      issue_B(Lbase + s * WW_STAGE_PX + (wave >> 1) * 16, wave & 1);
+    }
+    const unsigned abase = (unsigned)((s & 1) * A_STAGE + wave * PL_PLANES * 1024 + tr_off);
+    bool okx0[2][2], okx1[2][2], oky0[2][2], oky1[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        okx0[j][r] = px[j][r] != 0;
+        okx1[j][r] = px[j][r] != W - 1;
+        oky0[j][r] = py[j][r] != 0;
+        oky1[j][r] = py[j][r] != H - 1;
+      }
+    auto calc = [&](int i, unsigned (&ad)[2]) {   // ring offsets of tap-step i's two reads (the zero slot where the tap leaves the image)
+      const int j = i / 9, t = i % 9, ty = t / 3, tx = t % 3;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        bool ok = true;
+        if (ty == 0) ok = ok && oky0[j][r];
+        if (ty == 2) ok = ok && oky1[j][r];
+        if (tx == 0) ok = ok && okx0[j][r];
+        if (tx == 2) ok = ok && okx1[j][r];
+        const unsigned av = (pb[j][r] + (unsigned)shb[t]) & RMASK;
+        ad[r] = ((KO & 8) || ok) ? av : zl;
+      }
+    };
+    f16x8 ah[2], al[2], bh[2], bl[2];
+    unsigned ad[2][2];
+    calc(0, ad[0]);
+    calc(1, ad[1]);
+    if constexpr (!(KO & 2)) {
+      ah[0] = rd_pair(abase, abase + 256, 0);
+      al[0] = rd_pair(abase, abase + 256, 1024);
+      bh[0] = rd_pair(ad[0][0], ad[0][1], WIN_OFF);
+      bl[0] = rd_pair(ad[0][0], ad[0][1], WIN_OFF + WIN_PLANE);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const int j = i / 9, t = i % 9, cur = i & 1, nxt = cur ^ 1;
+      if constexpr (!(KO & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh[cur], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(KO & 2)) {
+        if (i + 1 < 18) {
+          bh[nxt] = rd_pair(ad[nxt][0], ad[nxt][1], WIN_OFF);
+          bl[nxt] = rd_pair(ad[nxt][0], ad[nxt][1], WIN_OFF + WIN_PLANE);
+        }
+        if (i == 6) {   // dy fragments of the second k-step
+          ah[1] = rd_pair(abase + 4 * PL_PLANES * 1024, abase + 4 * PL_PLANES * 1024 + 256, 0);
+          al[1] = rd_pair(abase + 4 * PL_PLANES * 1024, abase + 4 * PL_PLANES * 1024 + 256, 1024);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(KO & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl[cur], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 2 < 18) calc(i + 2, ad[cur]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(KO & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh[cur], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i >= 16) {
+        // the lane's pixels of the next stage: 32 pixels on = adv_rows rows + adv_rem pixels (k-step i - 16)
+        const int jj = i - 16;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          pb[jj][r] = (pb[jj][r] + WW_STAGE_PX * 64) & RMASK;
+          int x = px[jj][r] + adv_rem, y = py[jj][r] + adv_rows;
+          if (x >= W) {
+            x -= W;
+            ++y;
+          }
+          if (y >= H) y -= H;
+          px[jj][r] = x;
+          py[jj][r] = y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my pieces of stage s + 1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // my reads of stage s are done
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const float unscale =
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.dy) + a.dy_bytes - PL_HEADER)[2] *
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2];
+  if (a.slabs != nullptr) {
+    // piece ((wave * 9 + t) * 4 + q4) of lane l at float (piece * 64 + l) * 4: one store instruction = 1 KiB contiguous
+    float* mine = a.slabs + (size_t)lid * WW_TILE_FLOATS;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+        const f32x4 f = {acc[t][4 * q4], acc[t][4 * q4 + 1], acc[t][4 * q4 + 2], acc[t][4 * q4 + 3]};
+        *reinterpret_cast<f32x4*>(mine + (((wave * 9 + t) * 4 + q4) * 64 + lane) * 4) = f;
+      }
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const long long cj = (long long)t * a.Cs + ci0 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[t][r] * unscale);
+    }
+  }
+}
+
+// dw += unscale * sum over splits (in split order) of the slabs' partials: one thread per 16-byte accumulator piece
+__global__ __launch_bounds__(256) void wgrad_win_reduce_kernel(const WgradArgs a) {
+  constexpr int PER_TILE = WW_TILE_FLOATS / 4;
+  const int tiles = a.tiles_co * a.tiles_j;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int tile = (int)(idx / PER_TILE);
+  if (tile >= tiles) return;
+  const int q = (int)(idx - (long long)tile * PER_TILE);
+  const int lane = q & 63, piece = q >> 6;
+  const int q4 = piece & 3, t = (piece >> 2) % 9, wave = piece / 36;
+  const int co = (tile % a.tiles_co) * WW_CO + wave * 32 + 8 * q4 + 4 * (lane >> 5);
+  const long long cj = (long long)t * a.Cs + (tile / a.tiles_co) * WW_CI + (lane & 31);
+  const f32x4* sl = reinterpret_cast<const f32x4*>(a.slabs) + (size_t)tile * PER_TILE + q;
+  const size_t sstride = (size_t)tiles * PER_TILE;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= a.splits; s += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(sl + (size_t)(s + u) * sstride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum = sum + v[u];
+  }
+  for (; s < a.splits; ++s) sum = sum + __builtin_nontemporal_load(sl + (size_t)s * sstride);
+  const float unscale =
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.dy) + a.dy_bytes - PL_HEADER)[2] *
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a.dw[(long long)(co + e) * a.ldw + cj] += sum[e] * unscale;
+}
+
+bool wgrad_win_supported(const WgradArgs& a) {
+  if (a.ntaps != 9 || a.kw != 3 || a.sy != 1 || a.sx != 1 || a.pad_t != 1 || a.pad_l != 1) return false;
+  if (a.Hg != a.Hs || a.Wg != a.Ws) return false;
+  if ((a.Cout % WW_CO) != 0 || (a.Cs % WW_CI) != 0 || a.ldw != 9 * a.Cs) return false;
+  // ring: the loads of stage s + 1 must not land on the slots stage s reads (RING >= 2 W + 81); the per-stage advance of a
+  // lane's (x, y) is one conditional step each (32 / W + 2 <= H)
+  if (a.Ws < 4 || 2 * a.Ws + 81 > 512 || 32 / a.Ws + 2 > a.Hs) return false;
+  if (a.M < 64 || a.M >= (1LL << 31) - 4096) return false;
+  return true;
+}
+
+template <int RING, int KO>
+static int launch_ww(WgradArgs& a, hipStream_t st) {
+  a.tiles_co = a.Cout / WW_CO;
+  a.tiles_j = a.Cs / WW_CI;
+  const long long tiles = (long long)a.tiles_co * a.tiles_j;
+  constexpr size_t lds = 2 * (2 * 4 * PL_PLANES * 1024) + 2 * (RING * 64 + 64);
+  static int resident = 0;
+  if (resident == 0) {
+    int per_cu = 0, dev = 0, cus = 0;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_win_kernel<RING, KO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wgrad_win_kernel<RING, KO>), 256, lds) ==
+            hipSuccess &&
+        hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
+      resident = per_cu * cus;
+    if (resident <= 0) resident = 512;
+  }
+  // one round of the workgroups the chip holds; at least 8 stages per workgroup
+  static const long long target_env = [] { const char* e = getenv("YOLO_WGRAD_WIN_TARGET"); return e ? atoll(e) : 0LL; }();
+  const long long target = target_env > 0 ? target_env : resident;
+  long long splits = target / tiles;
+  const long long max_splits = (a.M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  a.slabs = nullptr;
+  static const bool det_env = [] { const char* e = getenv("YOLO_WGRAD_DETERMINISTIC"); return !(e && atoi(e) == 0); }();
+  size_t ws_bytes = 0;
+  void* ws = wgrad_workspace(&ws_bytes);
+  if (det_env && ws != nullptr && ws_bytes > WGRAD_WS_COLSUM_BYTES) {
+    const long long cap = (long long)((ws_bytes - WGRAD_WS_COLSUM_BYTES) / ((size_t)WW_TILE_FLOATS * 4));
+    if (cap >= tiles) {
+      if (tiles * splits > cap) splits = cap / tiles;
+      a.slabs = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(ws) + WGRAD_WS_COLSUM_BYTES);
+    }
+  }
+  long long chunk = (a.M + splits - 1) / splits;
+  chunk = (chunk + 31) / 32 * 32;
+  splits = (a.M + chunk - 1) / chunk;
+  a.chunk = chunk;
+  a.splits = (int)splits;
+  a.nblocks = (int)(tiles * splits);
+  hipLaunchKernelGGL((wgrad_win_kernel<RING, KO>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
+  if (int rc = check_launch("wgrad_win_kernel")) return rc;
+  if (a.slabs != nullptr) {
+    const long long pieces = tiles * (WW_TILE_FLOATS / 4);
+    hipLaunchKernelGGL(wgrad_win_reduce_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, a);
+    return check_launch("wgrad_win_reduce_kernel");
+  }
+  return YOLO_OK;
+}
+
+int launch_wgrad_win(WgradArgs& a, hipStream_t st) {
+  const bool small = 2 * a.Ws + 81 <= 256;
+#ifdef YOLO_PLANES_KNOCKOUTS   // diagnostic build (make KNOCKOUTS=1)
+  static const int ko = [] { const char* e = getenv("YOLO_WGRAD_KO"); return e ? atoi(e) : 0; }();
+  if (small) switch (ko) {
+      case 1: return launch_ww<256, 1>(a, st);
+      case 2: return launch_ww<256, 2>(a, st);
+      case 3: return launch_ww<256, 3>(a, st);
+      case 4: return launch_ww<256, 4>(a, st);
+      case 7: return launch_ww<256, 7>(a, st);
+      case 8: return launch_ww<256, 8>(a, st);
+      default: break;
+    }
+#endif
+  return small ? launch_ww<256, 0>(a, st) : launch_ww<512, 0>(a, st);
+}
+
+}  // namespace yolo

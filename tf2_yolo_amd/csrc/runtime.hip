@@ -31,6 +31,9 @@ static void options_from_env() {
   // 3x3 stride-1 window kernel on 2-D patches (conv_win.hip, GEO = 1): 0 off, 1 automatic, 2 wherever the shape allows
   e = getenv("YOLO_CONV_PATCH");
   g_opt[OPT_CONV_PATCH] = e ? atoi(e) : 1;
+  // 3x3 stride-1 filter gradient with the input window in LDS (conv_wgrad_win.hip): 0 off, 1 wherever the shape allows
+  e = getenv("YOLO_WGRAD_WIN");
+  g_opt[OPT_WGRAD_WIN] = e ? atoi(e) : 1;
 }
 void init_options() {
   static bool done = false;
