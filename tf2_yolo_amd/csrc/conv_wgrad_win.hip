@@ -32,7 +32,7 @@ constexpr int WW_STAGE_PX = 32;  // pixels per stage (two MFMA k-steps)
 constexpr int WW_TILE_FLOATS = WW_CO * 9 * WW_CI;
 
 // KO: diagnostic knock-outs (wrong results): 1 = no DMAs in the loop, 2 = no fragment reads, 4 = no MFMAs, 8 = no border masks
-template <int RING, int KO = 0>
+template <int RING, int KO = 0, int PF = 1>
 __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradArgs a) {
   constexpr int A_STAGE = 2 * 4 * PL_PLANES * 1024;   // [k-step][filter block][plane][1 KiB piece]
   constexpr int WIN_PLANE = RING * 64 + 64;           // ring + one all-zero slot
@@ -179,28 +179,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradArgs a) {
         ad[r] = ((KO & 8) || ok) ? av : zl;
       }
     };
-    f16x8 ah[2], al[2], bh[2], bl[2];
-    unsigned ad[2][2];
-    calc(0, ad[0]);
-    calc(1, ad[1]);
+    constexpr int NS = PF + 1;   // fragment / address register sets: the reads of tap-step i + PF are issued during tap-step i
+    f16x8 ah[2], al[2], bh[NS], bl[NS];
+    unsigned ad[NS][2];
+#pragma unroll
+    for (int k = 0; k <= PF; ++k) calc(k, ad[k]);
     if constexpr (!(KO & 2)) {
       ah[0] = rd_pair(abase, abase + 256, 0);
       al[0] = rd_pair(abase, abase + 256, 1024);
-      bh[0] = rd_pair(ad[0][0], ad[0][1], WIN_OFF);
-      bl[0] = rd_pair(ad[0][0], ad[0][1], WIN_OFF + WIN_PLANE);
+#pragma unroll
+      for (int k = 0; k < PF; ++k) {
+        bh[k] = rd_pair(ad[k][0], ad[k][1], WIN_OFF);
+        bl[k] = rd_pair(ad[k][0], ad[k][1], WIN_OFF + WIN_PLANE);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 18; ++i) {
-      const int j = i / 9, t = i % 9, cur = i & 1, nxt = cur ^ 1;
+      const int j = i / 9, t = i % 9, cur = i % NS, nxt = (i + PF) % NS;
       if constexpr (!(KO & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[j], bh[cur], acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(KO & 2)) {
-        if (i + 1 < 18) {
+        if (i + PF < 18) {
           bh[nxt] = rd_pair(ad[nxt][0], ad[nxt][1], WIN_OFF);
           bl[nxt] = rd_pair(ad[nxt][0], ad[nxt][1], WIN_OFF + WIN_PLANE);
         }
-        if (i == 6) {   // dy fragments of the second k-step
+        if (i == 6 - PF) {   // dy fragments of the second k-step
           ah[1] = rd_pair(abase + 4 * PL_PLANES * 1024, abase + 4 * PL_PLANES * 1024 + 256, 0);
           al[1] = rd_pair(abase + 4 * PL_PLANES * 1024, abase + 4 * PL_PLANES * 1024 + 256, 1024);
         }
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(KO & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bl[cur], acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      if (i + 2 < 18) calc(i + 2, ad[cur]);
+      if (i + PF + 1 < 18) calc(i + PF + 1, ad[cur]);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (!(KO & 4)) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[j], bh[cur], acc[t], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -303,7 +307,7 @@ bool wgrad_win_supported(const WgradArgs& a) {
   return true;
 }
 
-template <int RING, int KO>
+template <int RING, int KO, int PF = 1>
 static int launch_ww(WgradArgs& a, hipStream_t st) {
   a.tiles_co = a.Cout / WW_CO;
   a.tiles_j = a.Cs / WW_CI;
@@ -312,9 +316,9 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
   static int resident = 0;
   if (resident == 0) {
     int per_cu = 0, dev = 0, cus = 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_win_kernel<RING, KO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_win_kernel<RING, KO, PF>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wgrad_win_kernel<RING, KO>), 256, lds) ==
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wgrad_win_kernel<RING, KO, PF>), 256, lds) ==
             hipSuccess &&
         hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
       resident = per_cu * cus;
@@ -344,7 +348,7 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
   a.chunk = chunk;
   a.splits = (int)splits;
   a.nblocks = (int)(tiles * splits);
-  hipLaunchKernelGGL((wgrad_win_kernel<RING, KO>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((wgrad_win_kernel<RING, KO, PF>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
   if (int rc = check_launch("wgrad_win_kernel")) return rc;
   if (a.slabs != nullptr) {
     const long long pieces = tiles * (WW_TILE_FLOATS / 4);
@@ -368,6 +372,7 @@ int launch_wgrad_win(WgradArgs& a, hipStream_t st) {
       default: break;
     }
 #endif
+  if (small && g_opt[OPT_WGRAD_WIN] == 2) return launch_ww<256, 0, 2>(a, st);   // fragment reads two tap-steps ahead
   return small ? launch_ww<256, 0>(a, st) : launch_ww<512, 0>(a, st);
 }
 
