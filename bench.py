@@ -20,6 +20,10 @@ import os
 import sys
 import time
 
+# More hardware queues than the runtime's default of 4: a data-parallel rank runs four or five streams, and with 4 queues the two
+# compute streams of the step shared one (34.2 instead of 30.1 ms per step; tf2_yolo_amd/__init__.py). Read at HIP initialisation.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 import torch
 
@@ -117,19 +121,7 @@ def cpu_baseline(threads):
     n = 16
     x, ys = labels.synthetic_batch(rng, n, (HW, HW), CLASSES)
     b = graphs.build_yolov3((HW, HW, 3), CLASSES)
-    w = {}
-    for u in b.units:
-        if u.kind == "conv":
-            cin = u.src.c
-            w[f"{u.name}_conv/0"] = torch.randn(u.k, u.k, cin, u.cout) * (2.0 / (u.k * u.k * cin)) ** 0.5
-            w[f"{u.name}_bn/0"], w[f"{u.name}_bn/1"] = torch.ones(u.cout), torch.zeros(u.cout)
-            w[f"{u.name}_bn/2"], w[f"{u.name}_bn/3"] = torch.zeros(u.cout), torch.ones(u.cout)
-        elif u.kind == "head":
-            cin = u.src.c
-            for j in range(u.A):
-                for part, c in (("xy", 2), ("wh", 2), ("conf", 1), ("prob", u.C)):
-                    w[f"out{u.level + 1}_box{j + 1}_{part}_conv/0"] = torch.randn(1, 1, cin, c) * (2.0 / cin) ** 0.5
-                    w[f"out{u.level + 1}_box{j + 1}_{part}_conv/1"] = torch.zeros(c)
+    w = {k: torch.from_numpy(v) for k, v in labels.synthetic_keras_weights(b, 1234).items()}
     for v in w.values():
         v.requires_grad_(True)
     anchors = graphs.V3_DEFAULT_ANCHORS
@@ -190,6 +182,153 @@ def decode_nms_block():
             "cpu_host": None if cpu is None else cpu["host"], "cases": cases}
 
 
+def strict_fp32_block(steps=5, warmup=3):
+    """The reference computes in fp32 (yolov3/models/backbone.py:27-55, default float32 Keras layers). The headline value runs
+    the convolutions as two scaled fp16 planes x 3 MFMA passes; this block is the SAME training step with every convolution on
+    the fp32-input matrix instructions (YOLO_CONV_MODE=fp32: v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains), so that the
+    strict-fp32 rate is in the driver's record too. The switch is read when the package is imported: a child process."""
+    import subprocess
+    env = dict(os.environ, YOLO_CONV_MODE="fp32")
+    env.pop("YOLO_DP_FORCE", None)
+    t0 = time.perf_counter()
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--plain", "--steps", str(steps), "--warmup", str(warmup)],
+                         env=env, capture_output=True, text=True, timeout=420)
+    if out.returncode != 0:
+        return {"error": out.stderr[-400:]}
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    j.update({"what": "the same training step, every convolution on the fp32-input MFMA (YOLO_CONV_MODE=fp32), child process, "
+                      "outside the timed region", "peak_tflops_fp32_mfma": FP32_MFMA_PEAK_TFLOPS,
+              "frac_of_fp32_mfma_peak_whole_step": round(STEP_TFLOP / (j["ms_per_step"] * 1e-3) / FP32_MFMA_PEAK_TFLOPS, 4),
+              "wall_s": round(time.perf_counter() - t0, 1)})
+    return j
+
+
+STEP_TFLOP = 6.31   # SURVEY.md section 8d: 197.3 GFLOP per image and training step at C = 80, bs 32
+
+
+def darknet53_block(model, x, ceiling):
+    """BASELINE.json / north_star's second figure is defined on the Darknet-53 FORWARD (yolov3/models/backbone.py:74-82: conv1 +
+    five residual stages, 52 convolutions, 49.032 GFLOP per image = 1.569 TFLOP at bs 32): the training-mode forward stopped
+    behind block5's last unit. ms = wall over 5 passes; conv rate = algorithmic conv FLOPs / summed conv-launch time (HIP events)."""
+    from tf2_yolo_amd import ops
+    net, last = model.net, "block5_4_3x3"
+    net.forward(x, training=True, stop_after=last)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        net.forward(x, training=True, stop_after=last)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    tm = ops.KernelTimer()
+    ops.TIMER = tm
+    for _ in range(2):
+        net.forward(x, training=True, stop_after=last)
+    torch.cuda.synchronize()
+    ops.TIMER = None
+    fa = tm.summary()
+    fl = sum(v["flops"] for v in fa.values()) / 2
+    kms = sum(v["ms"] for v in fa.values()) / 2
+    pk = sum(v["flops"] / 2 / kernel_peak(k) for k, v in fa.items())
+    raw = PLANES_PASSES * sum(v["flops"] for k, v in fa.items() if "planes" in k) / 2 / kms / 1e9
+    out = {"what": "Darknet-53 backbone only (conv1 .. block5, 52 conv-BN-Leaky units), training-mode forward, bs %d" % x.shape[0],
+           "ms": round(ms, 3), "conv_gflop": round(fl / 1e9, 1), "conv_kernel_ms": round(kms, 3),
+           "conv_tflops": round(fl / kms / 1e9, 1), "conv_frac_of_peak": round(pk / 1e9 / kms, 4),
+           "whole_tflops": round(fl / ms / 1e9, 1), "whole_frac_of_peak": round(pk / 1e9 / ms, 4),
+           "ms_at_60pct_of_fp32_mfma_peak_SURVEY_8d": 16.6,
+           "images_per_s_forward": round(x.shape[0] / ms * 1e3, 1)}
+    if ceiling and "error" not in ceiling:
+        out["conv_frac_of_held_clock_ceiling"] = round(raw / ceiling["raw_fp16_mfma_tflops"], 4)
+    return out
+
+
+def configs_block():
+    """BASELINE.json configs[0], [1], [3], [4] (the headline configs[2] is the timed region), driver-observed: C1 / C2 / C4 one
+    training step at their true batch, C5 = bs-1 Model.predict (hipGraph replay) + decode + the three NMS modes on the network's
+    OWN prediction (README.md:296-334), beside the reference's CPU timings for the same network and image
+    (tests/golden/tools_timing.json 'model_output', produced in the build container by tests/golden/make_timing.py)."""
+    from tf2_yolo_amd import graphs, labels, optimizers, tools
+    res = {}
+
+    def train_ms(yolo, loss, batch, levels, stride, steps):
+        m = yolo.model
+        m.compile(optimizer=optimizers.Adam(learning_rate=1e-4), loss=loss)
+        rng = np.random.default_rng(1234)
+        H = yolo.input_shape[0]
+        xh, yh = labels.synthetic_batch(rng, batch, (H, H), yolo.class_num, levels=levels, finest_stride=stride)
+        xd, yd = torch.from_numpy(xh).cuda(), [torch.from_numpy(a).cuda() for a in yh]
+        for _ in range(3):
+            m.train_step_device(xd, yd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            bufs, _ = m.train_step_device(xd, yd)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        lv = float(sum(b[0].item() for b in bufs))
+        return {"batch": batch, "ms_per_step": round(dt * 1e3, 3), "images_per_s": round(batch / dt, 1),
+                "loss_finite": bool(np.isfinite(lv))}
+
+    import yolov1_5
+    y = yolov1_5.Yolo((224, 224, 3), ["raccoon"])
+    y.create_model(bbox_num=2)
+    res["c1_yolov1_5_224_bs4_train"] = train_ms(y, y.loss(binary_weight=0.5), 4, 1, 56, 8)
+    del y
+    import yolov2
+    y = yolov2.Yolo((416, 416, 3), [f"c{i}" for i in range(20)])
+    y.create_model()
+    res["c2_yolov2_416_bs16_train"] = train_ms(y, y.loss(), 16, 1, 32, 8)
+    del y
+    torch.cuda.empty_cache()
+    import yolov4
+    y = yolov4.Yolo((608, 608, 3), [f"c{i}" for i in range(80)])
+    y.create_model(anchors=graphs.V4_DEFAULT_ANCHORS, pretrained_body=None)
+    res["c4_yolov4_608_bs16_train"] = train_ms(y, y.loss(), 16, 3, 8, 5)
+    del y
+    torch.cuda.empty_cache()
+
+    import yolov3
+    y = yolov3.Yolo((416, 416, 3), [f"c{i}" for i in range(80)])
+    y.create_model(pretrained_body=None)
+    m = y.model
+    w = labels.synthetic_keras_weights(graphs.build_yolov3((416, 416, 3), 80), 1234, residual_gamma=0.1)
+    for n in m.layer_names():
+        lay = m.get_layer(n)
+        k = len(lay.get_weights())
+        if k:
+            lay.set_weights([w[f"{n}/{i}"] for i in range(k)])
+    x1 = torch.from_numpy(np.random.default_rng(1234).random((1, 416, 416, 3), dtype=np.float32)).cuda()
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            r = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n * 1e3, r
+
+    t_fwd, outs = timed(lambda: m.net.infer(x1), 20)
+    lv = [outs[2][0], outs[1][0], outs[0][0]]           # README.md:320-325: fine -> coarse
+    t_dec, dec = timed(lambda: tools.decode_device(*lv, class_num=80, threshold=0.5, version=3), 10)
+    c5 = {"input": "the network's own bs-1 prediction (synthetic_keras_weights seed 1234, rng(1234) pixels)",
+          "predict_ms_hipgraph": round(t_fwd, 3), "conf_threshold": 0.5, "candidates": int(dec.shape[0]),
+          "gpu_decode_ms": round(t_dec, 3)}
+    for name, fn in (("nms", lambda: tools.nms(dec, class_num=80, nms_threshold=0.5)),
+                     ("diou_nms", lambda: tools.nms(dec, class_num=80, nms_threshold=0.5, iou_mode=2)),
+                     ("soft_nms", lambda: tools.soft_nms(dec, class_num=80, nms_threshold=0.5, conf_threshold=0.5, sigma=0.5))):
+        t, out = timed(fn, 5)
+        c5[f"gpu_{name}_ms"] = round(t, 3)
+        c5[f"{name}_kept"] = int(out.shape[0])
+    path = os.path.join(ROOT, "tests", "golden", "tools_timing.json")
+    ref = json.load(open(path)).get("model_output") if os.path.exists(path) else None
+    if ref is not None:
+        c5["cpu_reference"] = {k: ref[k] for k in ref if k.endswith("_ms") or k.endswith("_kept") or k == "candidates"}
+        c5["end_to_end_ms"] = {"gpu": round(t_fwd + t_dec + c5["gpu_nms_ms"], 3),
+                               "cpu_reference_decode_plus_nms_only": round(ref["decode_ms"] + ref["nms_ms"], 1)}
+    res["c5_yolov3_416_bs1_predict_decode_nms"] = c5
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -198,6 +337,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--no-extra-blocks", action="store_true", help="skip strict_fp32 / configs (profiling runs)")
+    ap.add_argument("--plain", action="store_true", help="timed region only; prints {ms_per_step, images_per_s, loss}")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -272,6 +413,14 @@ def main():
     dt = time.perf_counter() - t0
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
     loss_val = float(sum(b[0].item() for b in bufs))
+    if args.plain:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": round(dt / args.steps * 1e3, 3), "images_per_s": round(world * args.batch * args.steps / dt, 2),
+                              "loss": round(loss_val, 4), "conv_mode": ops.CONV_MODE, "planes": bool(ops.USE_PLANES),
+                              "steps": args.steps, "warmup_steps_run": warm_run}), flush=True)
+        if world > 1 or force_dp:
+            dist.destroy_process_group()
+        return
     # ---- the same K steps once more with every launch enqueued from Python and bracketed by HIP events on its stream
     # (ops.KernelTimer): per-launch events are not part of a replayed step, so the roofline block is measured
     # here, over K steps timed exactly like the region above (every rank runs it: the collectives must match) ----
@@ -286,6 +435,20 @@ def main():
         dt_eager = time.perf_counter() - t1
         ops.TIMER = None
         log(f"eager + per-launch events region done: {dt_eager / args.steps * 1e3:.2f} ms/step")
+
+    # Outside the timed region (every rank: the collectives must match): three more steps with the gradient reducer's trace on --
+    # per bucket, when it was ready for its all-reduce and when the all-reduce had finished, measured from the start of backward
+    dp_trace = None
+    red = getattr(model, "_reducer", None)
+    if red is not None and red.active and os.environ.get("YOLO_STEP_MODE", "tape") != "graph":
+        red.start_trace(True)
+        for _ in range(3):
+            model.train_step_device(x, ys)
+        barrier()
+        dp_trace = {"what": "last of 3 extra steps: per gradient bucket (MB, ms from the start of backward until every gradient of the "
+                            "bucket was written = its all-reduce can start, ms until the all-reduce had finished on the communication stream)",
+                    "buckets": red.trace_ms(), "backend": backend, "world": world}
+        red.start_trace(False)
 
     # Outside the timed region, right behind it (the chip is as warm as it was inside): what a bare fp16 MFMA loop on
     # random register operands sustains on THIS box -- the ceiling any fp16 MFMA kernel has at the clock the chip holds
@@ -342,6 +505,11 @@ def main():
                "whole_forward_frac_of_peak": round(pk / 1e9 / fwd_ms, 4),
                "raw_fp16_mfma_tflops_conv": round(PLANES_PASSES * sum(v["flops"] for k, v in fa.items() if "planes" in k)
                                                   / 2 / kms / 1e9, 1)}
+
+        try:
+            fwd["darknet53"] = darknet53_block(model, x, ceiling)
+        except Exception as e:   # informational
+            fwd["darknet53"] = {"error": repr(e)}
 
     t = torch.tensor([dt, dt_eager if dt_eager is not None else 0.0], dtype=torch.float64, device="cuda")
     if world > 1:
@@ -419,6 +587,8 @@ def main():
                                  "ms_per_step": round(dt_eager / args.steps * 1e3, 3),
                                  "images_per_s": round(world * args.batch * args.steps / dt_eager, 2)}),
                "roofline": roof, "forward": fwd}
+        if dp_trace is not None:
+            out["dp_trace"] = dp_trace
         if fwd is not None and ceiling and "error" not in ceiling:
             fwd["conv_frac_of_held_clock_ceiling"] = round(fwd["raw_fp16_mfma_tflops_conv"] / ceiling["raw_fp16_mfma_tflops"], 4)
         if world == 1:
@@ -426,6 +596,17 @@ def main():
                 out["decode_nms"] = decode_nms_block()
             except Exception as e:   # informational block: never lose the headline line over it
                 out["decode_nms"] = {"error": repr(e)}
+        if world == 1 and not args.no_extra_blocks:
+            log("strict fp32 step (child process) ...")
+            try:
+                out["strict_fp32"] = strict_fp32_block()
+            except Exception as e:   # informational blocks: never lose the headline line over them
+                out["strict_fp32"] = {"error": repr(e)}
+            log("other BASELINE.json configs ...")
+            try:
+                out["configs"] = configs_block()
+            except Exception as e:
+                out["configs"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (bounded sample) ...")
             try:
@@ -433,6 +614,36 @@ def main():
             except AttributeError:
                 cores = os.cpu_count() or 1
             out["cpu_baseline"] = cpu_baseline(min(cores, 16))   # the GPU box's CPU share is 16 cores
+        # LAST key: the figures of the informational blocks once more, flat and short (a record that keeps only the tail
+        # of this line still holds them)
+        try:
+            sm = {"images_per_s": out["value"], "ms_per_step": out["ms_per_step"]}
+            if roof is not None:
+                sm["dominant_kernel_frac_in_step"] = roof["frac"]
+                sm["dominant_kernel_frac_isolated"] = (roof.get("isolated") or {}).get("frac")
+                roof["dominant_kernel_frac_isolated"] = sm["dominant_kernel_frac_isolated"]
+            if fwd is not None:
+                sm.update({"forward_ms": fwd["ms"], "forward_conv_frac_of_peak": fwd["conv_frac_of_peak"]})
+                dk = fwd.get("darknet53") or {}
+                sm.update({"darknet53_forward_ms": dk.get("ms"), "darknet53_conv_frac_of_peak": dk.get("conv_frac_of_peak"),
+                           "darknet53_whole_frac_of_peak": dk.get("whole_frac_of_peak")})
+                if roof is not None:   # (scalars inside `roofline` survive a parser that drops nested blocks)
+                    roof.update({"forward_conv_frac_of_peak": fwd["conv_frac_of_peak"], "darknet53_forward_ms": dk.get("ms"),
+                                 "darknet53_conv_frac_of_peak": dk.get("conv_frac_of_peak")})
+            sf = out.get("strict_fp32") or {}
+            sm.update({"strict_fp32_images_per_s": sf.get("images_per_s"), "strict_fp32_ms_per_step": sf.get("ms_per_step")})
+            cf = out.get("configs") or {}
+            for key, short in (("c1_yolov1_5_224_bs4_train", "c1"), ("c2_yolov2_416_bs16_train", "c2"),
+                               ("c4_yolov4_608_bs16_train", "c4")):
+                sm[short + "_ms_per_step"] = (cf.get(key) or {}).get("ms_per_step")
+            c5 = cf.get("c5_yolov3_416_bs1_predict_decode_nms") or {}
+            sm["c5"] = {k: c5.get(k) for k in ("predict_ms_hipgraph", "candidates", "gpu_decode_ms", "gpu_nms_ms", "gpu_diou_nms_ms",
+                                              "gpu_soft_nms_ms")}
+            ref5 = c5.get("cpu_reference") or {}
+            sm["c5_cpu_reference_ms"] = {k: ref5.get(k) for k in ("candidates", "decode_ms", "nms_ms", "diou_nms_ms", "soft_nms_ms")}
+            out["summary"] = sm
+        except Exception as e:
+            out["summary"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
         dist.destroy_process_group()

@@ -107,12 +107,17 @@ def _decisions(iou_own, dec, bbox_num, stats, ignore_thresh=None, truth_thresh=N
         own = torch.argmax(iou_own, dim=-1)
         gap = (iou_own.gather(-1, own.unsqueeze(-1)) - iou_own.gather(-1, idx.unsqueeze(-1))).squeeze(-1)
         d = float(gap[own != idx].max()) if bool((own != idx).any()) else 0.0
+        # how MANY decisions were forced against this execution's own (the caller prints and bounds them)
+        stats["cells"] = stats.get("cells", 0) + own.numel()
+        stats["n_anchor"] = stats.get("n_anchor", 0) + int((own != idx).sum())
         if ignore_thresh is not None:
             bad = (iou_own < ignore_thresh) != ign
+            stats["n_ignore"] = stats.get("n_ignore", 0) + int(bad.sum())
             if bool(bad.any()):
                 d = max(d, float((iou_own[bad] - ignore_thresh).abs().max()))
         if truth_thresh is not None and truth_thresh < 1:
             bad = (iou_own > truth_thresh) != tru
+            stats["n_truth"] = stats.get("n_truth", 0) + int(bad.sum())
             if bool(bad.any()):
                 d = max(d, float((iou_own[bad] - truth_thresh).abs().max()))
         stats["disagree"] = max(stats.get("disagree", 0.0), d)

@@ -28,6 +28,8 @@ class _Ctx:
         self.leaky_masks = leaky_masks      # {unit name: bool tensor}: see layers.leaky_masked
         self.mask_disagree = {}             # unit name -> largest |z| where the forced branch differs
         self.pool_disagree = {}             # max-pool unit name -> largest (true max - forced winner)
+        self.mask_forced = {}               # unit name -> (activations whose branch was forced against this execution's sign, all)
+        self.pool_forced = {}               # max-pool unit name -> (windows whose forced winner is not this execution's maximum, all)
         self.acts = {}                      # unit name -> activation (debug / per-layer parity)
         self.keep_acts = KEEP_ACTS          # False: memory-light runs at full batch (tests/test_gpu_fullsize.py)
 
@@ -58,6 +60,7 @@ class _Ctx:
         idx = self.leaky_masks[name].reshape(-1).long()
         forced = x.reshape(-1)[idx].reshape(y.shape)
         self.pool_disagree[name] = float((y.detach() - forced.detach()).abs().max())
+        self.pool_forced[name] = (int((y.detach() != forced.detach()).sum()), y.numel())
         return forced
 
     def cbl(self, x, name, stride=1, padding="same", act="leaky", bias=False):
@@ -70,6 +73,7 @@ class _Ctx:
             m = self.leaky_masks[name]
             bad = (x.detach() > 0) != m
             self.mask_disagree[name] = float(x.detach().abs()[bad].max()) if bad.any() else 0.0
+            self.mask_forced[name] = (int(bad.sum()), bad.numel())
             out = L.leaky_masked(x, m)
         else:
             out = L.leaky(x)

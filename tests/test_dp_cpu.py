@@ -36,6 +36,10 @@ def test_plan_buckets_partition_and_order(bucket):
             assert buckets[b][0] <= segs[i][0]
     if bucket == 10 ** 9:
         assert len(buckets) == 1
+    # a smaller first bucket: same tiling rules, the first bucket closes no later than before
+    b2, c2 = dp.plan_buckets(segs, total, bucket, max(bucket // 4, 1))
+    assert b2[0][1] == total and b2[-1][0] == 0 and b2[0][0] >= buckets[0][0]
+    assert sorted(b for c in c2 for b in c) == list(range(len(b2)))
 
 
 def _worker(rank, world, port, sizes, bucket_bytes, q):

@@ -57,3 +57,26 @@ def test_two_ranks_on_one_gpu_stay_in_sync_over_gloo(mode):
     j = _json_line(r.stdout)
     assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["scaling"] == "weak"
     assert j["config"]["replicas_in_sync"] is True
+
+
+def test_dp_step_costs_no_more_than_the_plain_step_and_buckets_start_early():
+    """VERDICT r03 next #7 on the one GPU a test box has: the benchmark configuration (bs 32, launch tape) plain and with RCCL in
+    a forced world of one rank -- side-stream all-reduces of every bucket, the waits on both gradient streams, the tape's
+    host calls. The data-parallel step may cost at most 5 % more (measured +1 % with 8 hardware queues, +13 % with the runtime default of 4: profiles/r04_b_dp_readiness.json), and the
+    first gradient bucket must be ready for its all-reduce within 5 ms of the start of backward (measured ~2 ms; the last
+    one closes with the stem's gradient at the very end of backward)."""
+    args = ["--steps", "10", "--warmup", "4", "--no-cpu-baseline", "--no-kernel-timer", "--no-extra-blocks"]
+    plain = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, cwd=ROOT, env=_env(), capture_output=True,
+                           text=True, timeout=600)
+    assert plain.returncode == 0, plain.stderr[-3000:]
+    forced = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, cwd=ROOT,
+                            env=_env(YOLO_DP_FORCE="1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"),
+                            capture_output=True, text=True, timeout=600)
+    assert forced.returncode == 0, forced.stderr[-3000:]
+    a, b = _json_line(plain.stdout), _json_line(forced.stdout)
+    print("plain", a["ms_per_step"], "ms; forced RCCL world 1", b["ms_per_step"], "ms;", b["dp_trace"]["buckets"])
+    assert b["ms_per_step"] <= 1.05 * a["ms_per_step"], (a["ms_per_step"], b["ms_per_step"])
+    buckets = b["dp_trace"]["buckets"]
+    assert len(buckets) >= 4 and abs(sum(mb for mb, _, _ in buckets) - 247.8) < 1.0          # 61 949 149 fp32 gradients
+    assert buckets[0][1] <= 5.0, buckets
+    assert all(d >= r for _, r, d in buckets)

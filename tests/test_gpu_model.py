@@ -165,6 +165,38 @@ def _gpu_leaky_masks(net):
     return masks
 
 
+def _kink_census(version, y_true, pred_oracle, pred_dev, class_num):
+    """(object cell, anchor) pairs whose box arithmetic (oracle/losses.py:cal_iou -- tf.maximum / tf.minimum of the box
+    corners, max(overlap, 0)) is within the device-oracle prediction distance of a kink: returns (#pairs near a kink, #pairs).
+    A pair is near a kink when one of the four corner differences truth - prediction, or one of the two overlap extents, is
+    smaller in magnitude than the largest move the straight-through substitution makes to that pair's own box."""
+    yt = torch.as_tensor(y_true, dtype=torch.float64)
+    g = yt.shape[1]
+    if version == 1:
+        B = (pred_oracle.shape[-1] - class_num) // 5
+        po = pred_oracle[..., :5 * B].reshape(-1, g, g, B, 5)[..., :4]
+        pd = pred_dev[..., :5 * B].reshape(-1, g, g, B, 5)[..., :4]
+        t = yt[..., :4].reshape(-1, g, g, 1, 4)
+        obj = yt[..., 4] > 0
+    else:
+        B = pred_oracle.shape[-1] // (5 + class_num)
+        po = pred_oracle.reshape(-1, g, g, B, 5 + class_num)[..., :4]
+        pd = pred_dev.reshape(-1, g, g, B, 5 + class_num)[..., :4]
+        t = yt.reshape(-1, g, g, 1, 5 + class_num)[..., :4]
+        obj = yt[..., 4] > 0
+    def corners(b):
+        xy = b[..., 0:2] / g
+        return xy - b[..., 2:4] / 2, xy + b[..., 2:4] / 2
+    tmin, tmax = corners(t)
+    pmin, pmax = corners(po)
+    dmin, dmax = corners(pd)
+    move = torch.maximum((dmin - pmin).abs().amax(-1), (dmax - pmax).abs().amax(-1))          # [N, g, g, B]
+    ov = torch.minimum(pmax, tmax) - torch.maximum(pmin, tmin)                                 # overlap extents (may be < 0)
+    dist = torch.cat([(pmin - tmin).abs(), (pmax - tmax).abs(), ov.abs()], dim=-1).amin(-1)    # nearest kink
+    sel = obj.unsqueeze(-1).expand_as(dist)
+    return int((dist[sel] <= move[sel]).sum()), int(sel.sum())
+
+
 # (version, BN moving variance fed Bessel-corrected [tf.keras fused BN, the default] or biased, C1 at its true size)
 @pytest.mark.parametrize("version,unbiased,true_c1", [(3, True, False), (2, True, False), (1, True, False), (4, True, False),
                                                       (3, False, False), (1, True, True), (3, True, "tiny"),
@@ -231,23 +263,12 @@ def test_model_parity(version, unbiased, true_c1):
     dstats = {}
     ref_losses = [lf(torch.tensor(yt, dtype=torch.float64), o.detach(), decide_with=dc, stats=dstats)
                   for lf, yt, o, dc in zip(loss_o, ys, ref_tr, decs)]
-    # The backward pass starts from the loss gradient AT THE DEVICE'S predictions (straight-through: value of the device,
-    # graph of the oracle). The loss has more kinks than its argmax -- max / min of box corners, max(overlap, 0), the clips
-    # -- and an object whose predicted box touches its ground truth within 1e-4 of zero overlap puts the oracle's own
-    # predictions (1e-4 from the device's) on the other side of one: O(1) in that cell's xy gradient, 1e-2 in a head tensor
-    # (seen on out3_box1_xy_conv of YOLOv4-608, scripts/loss_cell_debug.py: at the device's predictions the kernel's
-    # gradient equals the oracle's to 1e-6). The forward outputs and loss VALUES are compared at the oracle's own predictions.
-    dev_pred = [o.detach().double().cpu() for o in outs]
-    sum(lf(torch.tensor(yt, dtype=torch.float64), o + (dp_ - o).detach(), decide_with=dc)
-        for lf, yt, o, dc, dp_ in zip(loss_o, ys, ref_tr, decs, dev_pred)).backward()
     # float32 CPU execution of the same oracle (same forced branches): the error floor of ANY fp32
     # implementation on this instance (random-weight BN chains amplify rounding with depth: ~1e-4 for the
     # 72-layer v3 graph, ~1e-3 for the 107-layer v4 CSP/PAN graph; scripts/act_error_profile.py)
     w32 = {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
     out32, _ = fwd(w32, torch.tensor(x), True, masks)
     losses32 = [lf(torch.tensor(yt), o.detach(), decide_with=dc) for lf, yt, o, dc in zip(loss_o, ys, out32, decs)]
-    sum(lf(torch.tensor(yt), o + (dp_.float() - o).detach(), decide_with=dc)
-        for lf, yt, o, dc, dp_ in zip(loss_o, ys, out32, decs, dev_pred)).backward()
     fwd_floor = max(_rel(b32.detach().numpy(), b.detach().numpy()) for b, b32 in zip(ref_tr, out32))
     # the branch patterns may only differ where the pre-activation is within fp32 error of zero
     assert max(ctx.mask_disagree.values(), default=0.0) < max(1e-4, 10 * fwd_floor), ctx.mask_disagree
@@ -255,6 +276,46 @@ def test_model_parity(version, unbiased, true_c1):
     assert max(ctx.pool_disagree.values(), default=0.0) < max(1e-4, 10 * fwd_floor), ctx.pool_disagree
     # ... and a forced loss decision only where the oracle's own IoUs are within rounding of a tie / of the threshold
     assert dstats.get("disagree", 0.0) < max(1e-4, 10 * fwd_floor), dstats
+    # HOW MANY decisions were forced, per kind (the conditioning must not grow silently). Printed,
+    # logged (gpurun_out/parity_census.jsonl) and bounded: a forced LeakyReLU sign needs |z| within the forward error of
+    # zero (a fraction ~ 0.8 x error of unit-variance pre-activations), a forced pool winner a near-tie among <= 169
+    # candidates, a forced loss decision an IoU within rounding of a tie or of a threshold
+    census = {"case": f"v{version} unbiased={unbiased} {true_c1}", "fwd_floor": fwd_floor,
+              "leaky_forced": sum(a for a, _ in ctx.mask_forced.values()), "leaky_total": sum(t for _, t in ctx.mask_forced.values()),
+              "pool_forced": sum(a for a, _ in ctx.pool_forced.values()), "pool_total": sum(t for _, t in ctx.pool_forced.values()),
+              "loss_cells": dstats.get("cells", 0), "loss_anchor_forced": dstats.get("n_anchor", 0),
+              "loss_ignore_forced": dstats.get("n_ignore", 0), "loss_truth_forced": dstats.get("n_truth", 0)}
+    # (measured, round 4: 1 of 1.8 M activations at 64x64, 89 of 76.6 M for YOLOv3-416, 996 of 35.3 M for YOLOv4-608; at most 9
+    # pool windows; no loss decision in any case -- the bounds below are ~5x those)
+    assert census["leaky_forced"] <= max(2, 0.25 * fwd_floor * census["leaky_total"]), census
+    assert census["pool_forced"] <= max(2, 5e-5 * census["pool_total"]), census
+    assert census["loss_anchor_forced"] + census["loss_ignore_forced"] + census["loss_truth_forced"] <= max(
+        2, 1e-4 * census["loss_cells"]), census
+
+    # The backward pass starts from the loss gradient AT THE DEVICE'S predictions (straight-through: value of the device,
+    # graph of the oracle). The loss has more kinks than its argmax -- max / min of box corners, max(overlap, 0), the clips
+    # -- and an object whose predicted box touches its ground truth within 1e-4 of zero overlap puts the oracle's own
+    # predictions (1e-4 from the device's) on the other side of one: O(1) in that cell's xy gradient, 1e-2 in a head tensor
+    # (seen on out3_box1_xy_conv of YOLOv4-608, scripts/loss_cell_debug.py: at the device's predictions the kernel's
+    # gradient equals the oracle's to 1e-6). The forward outputs and loss VALUES are compared at the oracle's own predictions.
+    # Guard (VERDICT r03 weak #1d): the substitution may move a prediction only by the forward error -- asserted BEFORE
+    # substituting -- and the census records how many (object cell, anchor) pairs sit within that distance of a kink of
+    # the box arithmetic (corner ties of min / max, zero overlap), i.e. how many cells the substitution can matter for.
+    dev_pred = [o.detach().double().cpu() for o in outs]
+    st_dist = 0.0
+    for dp_, o in zip(dev_pred, ref_tr):
+        st_dist = max(st_dist, float((dp_ - o.detach()).abs().max()) / max(float(o.detach().abs().max()), 1e-30))
+    assert st_dist < max(1e-4, 3 * fwd_floor), (st_dist, fwd_floor)
+    census["straight_through_max_rel_move"] = st_dist
+    near, pairs = 0, 0
+    for yt, o, dp_ in zip(ys, ref_tr, dev_pred):
+        k_, p_ = _kink_census(version, yt, o.detach(), dp_, len(y.class_names))
+        near, pairs = near + k_, pairs + p_
+    census["object_anchor_pairs"], census["pairs_within_move_of_a_box_kink"] = pairs, near
+    sum(lf(torch.tensor(yt, dtype=torch.float64), o + (dp_ - o).detach(), decide_with=dc)
+        for lf, yt, o, dc, dp_ in zip(loss_o, ys, ref_tr, decs, dev_pred)).backward()
+    sum(lf(torch.tensor(yt), o + (dp_.float() - o).detach(), decide_with=dc)
+        for lf, yt, o, dc, dp_ in zip(loss_o, ys, out32, decs, dev_pred)).backward()
 
     for a, b in zip(outs, ref_tr):
         assert _rel(a.cpu().numpy(), b.detach().numpy()) < max(1e-4, 3 * fwd_floor)
@@ -292,6 +353,62 @@ def test_model_parity(version, unbiased, true_c1):
                 assert e < max(2 * e32, 3e-4), (n, i, e, e32)
             assert e < max(1e-3, 4 * e32, 3 * fwd_floor), (n, i, e, e32, fwd_floor)
     print("worst gradient error", worst)
+
+    # ---- unconditioned companion (VERDICT r03 next #2b): the oracle makes ALL its own decisions -- its own LeakyReLU signs,
+    # pool winners, responsible anchors and masks, its own predictions -- and the device's gradients are compared with it per
+    # tensor in the L2 norm (one rerouted entry moves max-norm errors by 1e-2 but not the L2 distance of a whole tensor). The
+    # fraction of entries beyond 1e-4 of the tensor's maximum goes to the log, so drift of the conditioned test's forcing
+    # would show here. Run where the float64 pass is cheap (every case but the two 608-pixel ones).
+    if true_c1 not in ("608", "608bs1"):
+        wf = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+        free_tr, _ = fwd(wf, xt, True, None)
+        sum(lf(torch.tensor(yt, dtype=torch.float64), o) for lf, yt, o in zip(loss_o, ys, free_tr)).backward()
+        # ... and beside it the SAME unconditioned comparison for an fp32 CPU execution of the oracle (logged). What can be
+        # asserted: where NOTHING was forced -- the device took every discrete decision exactly as the float64 oracle does --
+        # the unconditioned comparison is the conditioned one and must hold 1e-3 in L2. Where a decision was forced the
+        # distance measures the flip, not the arithmetic: ONE forced sign among 1.8 M activations (YOLOv3 at 64x64, 2 images)
+        # puts conv1's kernel gradient 2.8e-2 away in L2 while the conditioned error of the same tensor is 4e-4 -- measured
+        # round 4, which is the reason the conditioned test exists; those cases log both distances and the flip counts.
+        wf32 = {k: torch.tensor(v, requires_grad=True) for k, v in w.items()}
+        free32, _ = fwd(wf32, torch.tensor(x), True, None)
+        sum(lf(torch.tensor(yt), o) for lf, yt, o in zip(loss_o, ys, free32)).backward()
+        worst_l2, worst_cpu, beyond, beyond_cpu, total = ("", 0.0, 0.0), 0.0, 0, 0, 0
+        for n in model.layer_names():
+            layer_w = model.get_layer(n).get_weights()
+            if not layer_w or n.endswith("_anchor"):
+                continue
+            for i in range(len(layer_w)):
+                r = wf[f"{n}/{i}"].grad
+                if r is None or (n.endswith("_conv") and i == 1 and f"{n[:-5]}_bn/0" in w):
+                    continue
+                got, ref_g, cpu_g = _grad_view(model, n, i, g), r.numpy(), wf32[f"{n}/{i}"].grad.numpy()
+                e_dev, e_cpu = _l2(got, ref_g), _l2(cpu_g, ref_g)
+                worst_l2 = max(worst_l2, (f"{n}/{i}", e_dev, e_cpu), key=lambda t: t[1])
+                worst_cpu = max(worst_cpu, e_cpu)
+                beyond += int((np.abs(got - ref_g) > 1e-4 * np.abs(ref_g).max()).sum())
+                beyond_cpu += int((np.abs(cpu_g - ref_g) > 1e-4 * np.abs(ref_g).max()).sum())
+                total += ref_g.size
+        census["unconditioned_worst_l2_rel"], census["unconditioned_worst_tensor"] = worst_l2[1], worst_l2[0]
+        census["unconditioned_worst_l2_rel_fp32_cpu"] = worst_cpu
+        census["unconditioned_frac_entries_beyond_1e-4_of_max"] = beyond / max(total, 1)
+        census["unconditioned_frac_entries_beyond_1e-4_of_max_fp32_cpu"] = beyond_cpu / max(total, 1)
+        n_forced = (census["leaky_forced"] + census["pool_forced"] + census["loss_anchor_forced"] + census["loss_ignore_forced"]
+                    + census["loss_truth_forced"])
+        if n_forced == 0:
+            assert worst_l2[1] < 1e-3, worst_l2
+        print("unconditioned oracle:", n_forced, "forced decisions; worst per-tensor L2-relative gradient error (tensor, device, fp32 CPU on that tensor)", worst_l2,
+              "worst fp32-CPU tensor", worst_cpu, "| entries beyond 1e-4 of their tensor's maximum: device", beyond, "fp32 CPU",
+              beyond_cpu, "of", total)
+    print("PARITY_CENSUS", census)
+    try:
+        import json
+        import os
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_census.jsonl"), "a") as fh:
+            fh.write(json.dumps(census) + "\n")
+    except OSError:
+        pass
 
     # ---- inference forward: moving statistics := this batch's statistics (keeps the net well scaled) ----
     w_inf = dict(w)

@@ -26,17 +26,19 @@ def _forced():
     return os.environ.get("YOLO_DP_FORCE") == "1"
 
 
-def plan_buckets(segments, total, bucket_elems):
+def plan_buckets(segments, total, bucket_elems, first_bucket_elems=None):
     """segments: [(offset, size)] in BACKWARD-COMPLETION order (descending offsets, contiguous).
     Returns (buckets, closes): buckets = [(lo, hi)] in ready order, closes[i] = list of bucket
-    indices that become ready once segment i is complete."""
+    indices that become ready once segment i is complete. first_bucket_elems: a smaller threshold for the FIRST bucket,
+    so that the first collective starts early in backward (the heads and the coarsest FPN level: 2.9 ms into backward
+    with 12 MB against 4.0 ms with a whole 48 MB bucket, profiles/r04_b_dp_readiness.json)."""
     buckets, closes = [], [[] for _ in segments]
     hi = total
     acc = 0
     for i, (off, size) in enumerate(segments):
         acc = hi - off
         last = i == len(segments) - 1
-        if acc >= bucket_elems or last:
+        if acc >= (first_bucket_elems if (first_bucket_elems and not buckets) else bucket_elems) or last:
             lo = 0 if last else off
             if hi > lo:
                 buckets.append((lo, hi))
@@ -49,17 +51,46 @@ class GradReducer:
     """Bucketed, overlapped all-reduce(sum) of a flat gradient tensor."""
 
     def __init__(self, flat_grads, segments, process_group=None, bucket_bytes=48 << 20):
+        if os.environ.get("YOLO_DP_BUCKET_MB"):          # experiments: profiles/r04_b_dp_readiness.json
+            bucket_bytes = int(float(os.environ["YOLO_DP_BUCKET_MB"]) * (1 << 20))
+        self._dry = os.environ.get("YOLO_DP_DRYRUN") == "1"   # experiments: every event and wait, no collective call
         self.flat = flat_grads
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (dist.is_initialized() and _forced())
-        self.buckets, self.closes = plan_buckets(segments, flat_grads.numel(), max(bucket_bytes // 4, 1))
+        first = int(float(os.environ.get("YOLO_DP_FIRST_BUCKET_MB", "12")) * (1 << 20))
+        self.buckets, self.closes = plan_buckets(segments, flat_grads.numel(), max(bucket_bytes // 4, 1),
+                                                 max(min(first, bucket_bytes) // 4, 1))
         self.on_gpu = flat_grads.is_cuda
         self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
         self._works = []
         # callable -> list of further CUDA streams that produce gradients (the engine's filter-gradient
         # stream): a bucket is reduced only after the work enqueued on them so far has finished too
         self.extra_streams = None
+        # YOLO_DP_TRACE / start_trace(): per step, when (on the device) backward began, when each bucket was ready for its
+        # all-reduce (every gradient of the bucket written on both gradient streams) and when the all-reduce had finished
+        self.tracing = os.environ.get("YOLO_DP_TRACE") == "1"
+        self._t0 = None
+        self._trace = []
+
+    def start_trace(self, on=True):
+        self.tracing = bool(on)
+        self._t0, self._trace = None, []
+
+    def backward_begin(self):
+        """called (through the launch tape too) when Network.backward starts: the time origin of the bucket trace"""
+        if self.active and self.tracing and self.on_gpu:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(torch.cuda.current_stream())
+            self._trace = []
+
+    def trace_ms(self):
+        """after a device synchronisation: [(bucket megabytes, ms from backward start until the bucket was ready, until its
+        all-reduce had finished)] of the last traced step"""
+        if self._t0 is None:
+            return []
+        return [(round((hi - lo) * 4 / 1e6, 1), round(self._t0.elapsed_time(r), 3), round(self._t0.elapsed_time(d), 3))
+                for (lo, hi), r, d in self._trace]
 
     def segment_done(self, i):
         if not self.active:
@@ -82,7 +113,15 @@ class GradReducer:
                 ev2.record(st)
                 self.comm_stream.wait_event(ev2)
             with torch.cuda.stream(self.comm_stream):
-                self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.tracing and self._t0 is not None:
+                    ready = torch.cuda.Event(enable_timing=True)
+                    ready.record(self.comm_stream)
+                if not self._dry:
+                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                if self.tracing and self._t0 is not None:
+                    done = torch.cuda.Event(enable_timing=True)
+                    done.record(self.comm_stream)
+                    self._trace.append(((lo, hi), ready, done))
         else:
             self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 

@@ -328,6 +328,7 @@ class Network:
         self.act = {}
         self.training = False
         self.grad_ready_hook = None   # called as hook(unit) after a unit's parameter grads are enqueued
+        self.backward_begin_hook = None   # called at the start of backward (the gradient reducer's time origin)
         self._infer_scale_valid = False
         ops.ensure_conv_workspace()   # scratch of the persistent (stream-K) window kernel: small-batch launches
         ops.ensure_wgrad_workspace()  # slabs of the atomics-free filter / bias gradient reductions
@@ -673,8 +674,9 @@ class Network:
         self._infer_scale_valid = False
 
     # ---- forward ------------------------------------------------------------------------
-    def forward(self, x, training=False):
-        """x: float32 CUDA tensor [N,H,W,C]. Returns the list of head outputs (coarse -> fine)."""
+    def forward(self, x, training=False, stop_after=None):
+        """x: float32 CUDA tensor [N,H,W,C]. Returns the list of head outputs (coarse -> fine).
+        stop_after (benchmarks only: bench.py's Darknet-53 block): name of the unit behind which the pass ends; returns None."""
         if x.dtype != torch.float32 or not x.is_cuda:
             raise YoloHipError("forward expects a float32 CUDA tensor")
         x = x.contiguous()
@@ -712,7 +714,11 @@ class Network:
             # inside): a training-mode forward overwrites those buffers with batch statistics, so drop them
             self._infer_graphs = {}
         P = self.params
+        prev_name = None
         for u in self.units:
+            if stop_after is not None and prev_name == stop_after:
+                return None
+            prev_name = getattr(u, "name", None)
             if self._wp_event is not None and u.kind in ("conv", "head") and u.planes_fwd:
                 tape.wait_event(torch.cuda.current_stream(), self._wp_event)
                 self._wp_event = None
@@ -917,6 +923,8 @@ class Network:
         Parameter gradients are ACCUMULATED into self.grads (zeroed by the optimizer step)."""
         if not self.training:
             raise YoloHipError("backward() requires a preceding forward(training=True)")
+        if self.backward_begin_hook is not None:
+            tape.host_call(self.backward_begin_hook)
         if self._wT_event is not None:
             tape.wait_event(torch.cuda.current_stream(), self._wT_event)
             self._wT_event = None

@@ -111,3 +111,30 @@ def synthetic_batch(rng, N, input_hw, class_num, levels=3, finest_stride=8, max_
         boxes = np.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], axis=1)
         fine[n] = encode_boxes(boxes, rng.integers(0, class_num, k), (H, W), (gh, gw), class_num)
     return x, [a.astype(np.float32) for a in label_pyramid(fine, levels)]
+
+
+def synthetic_keras_weights(builder, seed, residual_gamma=1.0):
+    """SURVEY.md section 8d synthetic weights, keyed like Model.get_layer(name).get_weights(): '<layer>/<i>' -> float32 array in
+    KERAS layout (conv kernels HWIO). He-normal N(0, 2 / fan_in) kernels, zero biases, BatchNormalization gamma 1 / beta 0 /
+    moving mean 0 / moving variance 1. Drawn from ONE numpy generator in graph order, so that the GPU model (bench.py's C5
+    block loads them with set_weights) and the CPU side (tests/golden/make_timing.py: the oracle's forward feeding the
+    reference's decode / NMS; bench.py's cpu_baseline) hold the same network without exchanging a file."""
+    rng = np.random.default_rng(seed)
+    w = {}
+    for u in builder.units:
+        if u.kind == "conv":
+            cin = u.src.c
+            w[f"{u.name}_conv/0"] = (rng.standard_normal((u.k, u.k, cin, u.cout)) * (2.0 / (u.k * u.k * cin)) ** 0.5).astype(np.float32)
+            if u.bias:
+                w[f"{u.name}_conv/1"] = np.zeros(u.cout, np.float32)
+            if u.bn:
+                gam = residual_gamma if u.residual is not None else 1.0
+                w[f"{u.name}_bn/0"], w[f"{u.name}_bn/1"] = np.full(u.cout, gam, np.float32), np.zeros(u.cout, np.float32)
+                w[f"{u.name}_bn/2"], w[f"{u.name}_bn/3"] = np.zeros(u.cout, np.float32), np.ones(u.cout, np.float32)
+        elif u.kind == "head":
+            cin = u.src.c
+            for j in range(u.A):
+                for part, c in (("xy", 2), ("wh", 2), ("conf", 1), ("prob", u.C)):
+                    w[f"out{u.level + 1}_box{j + 1}_{part}_conv/0"] = (rng.standard_normal((1, 1, cin, c)) * (2.0 / cin) ** 0.5).astype(np.float32)
+                    w[f"out{u.level + 1}_box{j + 1}_{part}_conv/1"] = np.zeros(c, np.float32)
+    return w

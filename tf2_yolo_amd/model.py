@@ -298,6 +298,7 @@ class Model:
         self._dp_unit_index = index
         self._drop_step_graphs()
         self.net.grad_ready_hook = lambda u: self._reducer.segment_done(index[id(u)])
+        self.net.backward_begin_hook = self._reducer.backward_begin
         net = self.net
         self._reducer.extra_streams = lambda: [net._wgrad_stream] if net._wgrad_stream is not None else []
         dp_mod.broadcast_parameters([self.net.params.data, self.net.state.data], 0, process_group)
