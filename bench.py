@@ -67,6 +67,11 @@ def hbm_traffic_from_profile(kernel):
     base, _, rest = kernel.partition("<")
     dims = rest.rstrip(">").split(",")
     flat = "true" if "flat" in dims else "false"
+    if base == "wgrad_win_planes_kernel":   # timer name <128,288[,mfma16]> = rocprof wgrad_win_kernel<ring,..> / wgrad_win16_kernel<ring,..>
+        pre = "wgrad_win16_kernel<" if "mfma16" in dims else "wgrad_win_kernel<"
+        fam = [v for n, v in prof.items() if n.startswith(pre)]
+        cnt = sum(v["launches"] for v in fam)
+        return int(sum(v["hbm_bytes_per_launch"] * v["launches"] for v in fam) / cnt) if cnt else None
     if base == "conv_win_planes_kernel":   # timer name <rows,128> = rocprof conv_win_kernel<rows/64, window chunks, false>
         fam = [v for n, v in prof.items() if n.startswith(f"conv_win_kernel<{int(dims[0]) // 64},")]
         cnt = sum(v["launches"] for v in fam)
@@ -90,7 +95,8 @@ def pmc_from_profile(kernel):
     paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_pmc.json")))
     if not paths:
         return None
-    fam = ("wgrad128x128" if kernel.startswith("wgrad_planes_kernel<128,128") else
+    fam = ("wgradwin" if kernel.startswith("wgrad_win_planes_kernel") else
+           "wgrad128x128" if kernel.startswith("wgrad_planes_kernel<128,128") else
            "wgrad64x128" if kernel.startswith("wgrad_planes_kernel<64,128") else
            "win128" if kernel.startswith("conv_win_planes_kernel<128") else
            "win256" if kernel.startswith("conv_win_planes_kernel<256") else

@@ -65,7 +65,8 @@ int yolo_mfma_probe(const void* operands_f16, float* sink, int workgroups, int i
  * key 5 = YOLO_OPT_CONV_PATCH (YOLO_CONV_PATCH): the window kernel on 2-D patches of 8 x 16 (16 x 16 for Cout <= 64) output
  * pixels for 3x3 stride-1 layers: 0 = off, 1 = automatic (rows longer than 64 pixels, Cout <= 64), 2 = wherever possible.
  * key 6 = YOLO_OPT_WGRAD_WIN (env YOLO_WGRAD_WIN, default 1): the 3x3 stride-1 filter gradient that streams the input once through an
- * LDS ring and takes all nine taps from it (conv_wgrad_win.hip): 0 = the per-tap kernel everywhere, 1 = wherever the shape allows.
+ * LDS ring and takes all nine taps from it (conv_wgrad_win.hip): 0 = the per-tap kernel everywhere; wherever the shape allows: 1 = on
+ * v_mfma_f32_32x32x16_f16, 3 = on v_mfma_f32_16x16x32_f16 (holds a higher clock on random data).
  * key -1 resets every option to its default. */
 enum { YOLO_OPT_CONV_WIN = 0, YOLO_OPT_STAMPS = 1, YOLO_OPT_CONV_SK = 2, YOLO_OPT_CONV_PATCH = 5, YOLO_OPT_WGRAD_WIN = 6 };
 int yolo_set_option(int key, int value);

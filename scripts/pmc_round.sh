@@ -25,8 +25,16 @@ run_one patch128x128_104 conv_win_kernel 1 fwd 104,64,128,3,1,32
 run_one planes128x128_1x1_52 gather_conv_planes_kernel 1 fwd 52,256,128,1,1,32
 run_one planes128x64_1x1_104 gather_conv_planes_kernel 1 fwd 104,128,64,1,1,32
 run_one planes128x32_1x1_208 gather_conv_planes_kernel 1 fwd 208,64,32,1,1,32
+# filter gradients: the x-window kernel (conv_wgrad_win.hip, the default for 3x3 stride-1 layers; slabs + ordered reduce as in
+# the training step) and, with YOLO_WGRAD_WIN=0, the per-tap kernel it replaced
+export CONV_BENCH_WGRAD_WS=1
+run_one wgradwin_52 wgrad_win_kernel 1 wgrad 52,128,256,3,1,32
+run_one wgradwin_26 wgrad_win_kernel 1 wgrad 26,256,512,3,1,32
+run_one wgradwin_13 wgrad_win_kernel 1 wgrad 13,512,1024,3,1,32
+export YOLO_WGRAD_WIN=0
 run_one wgrad128x128_52 wgrad_planes_kernel 1 wgrad 52,128,256,3,1,32
 run_one wgrad128x128_26 wgrad_planes_kernel 1 wgrad 26,256,512,3,1,32
 run_one wgrad128x256_13 wgrad_planes_kernel 1 wgrad 13,512,1024,3,1,32
+unset YOLO_WGRAD_WIN
 run_one wgrad64x128_208 wgrad_planes_kernel 1 wgrad 208,32,64,3,1,32
 python3 $R/scripts/pmc_json.py $OUT > $R/gpurun_out/${TAG}_conv_pmc.json

@@ -955,8 +955,9 @@ WGRAD_WIN_CASES = [
 ]
 
 
+@pytest.mark.parametrize("variant", [1, 3])      # 1: v_mfma_f32_32x32x16_f16, 3: the same kernel on v_mfma_f32_16x16x32_f16
 @pytest.mark.parametrize("case", WGRAD_WIN_CASES)
-def test_conv_wgrad_window_kernel(case):
+def test_conv_wgrad_window_kernel(case, variant):
     """wgrad_win_kernel: all nine taps of 32 input channels from ONE ring of x pixels in LDS, borders by pointing invalid
     (pixel, tap) pairs at a zero slot. Against the float64 oracle (1e-4), against the per-tap kernel (fp32 summation order),
     accumulation into dw, and -- with the workspace registered -- bit-identical from run to run."""
@@ -986,14 +987,14 @@ def test_conv_wgrad_window_kernel(case):
         _lib.check(lib.yolo_set_wgrad_workspace(None, 0), "yolo_set_wgrad_workspace")     # atomics
         ops._WGRAD_WS = None
         dw_old, _ = run(0)
-        dw_at, db_at = run(1)
+        dw_at, db_at = run(variant)
         assert _relerr(dw_at.double().cpu(), want) < TOL
         assert _relerr(dw_at.double(), dw_old.double()) < 1e-5
         if bias:
             assert _relerr(db_at.double().cpu(), dy.sum((0, 1, 2))) < TOL
         ops.ensure_wgrad_workspace()                                                      # slabs + ordered reduce
-        dw1, _ = run(1, 0.5)
-        dw2, _ = run(1, 0.5)
+        dw1, _ = run(variant, 0.5)
+        dw2, _ = run(variant, 0.5)
         assert torch.equal(dw1, dw2)
         assert _relerr((dw1 - 0.5).double().cpu(), want) < TOL
         # border handling, element by element: the corner taps of the first / last filter rows

@@ -296,6 +296,281 @@ __global__ __launch_bounds__(256) void wgrad_win_reduce_kernel(const WgradArgs a
   for (int e = 0; e < 4; ++e) a.dw[(long long)(co + e) * a.ldw + cj] += sum[e] * unscale;
 }
 
+
+// ---- the same kernel on v_mfma_f32_16x16x32_f16 ----
+// Why: the kernel runs at the clock the chip holds under it (zero-filled operands 107 us, random 142 us), and in the probe of
+// its inner loop (scripts/hip_probe/wgrad_shape_probe.cpp: every fragment re-read from LDS by transposing reads, same bytes per
+// FLOP) the 16x16x32 shape sustains 1645 raw TFLOP/s on random data where 32x32x16 sustains 1433 -- half the accumulator
+// register traffic per FLOP. Same tile (128 filters x 9 taps x 32 channels per workgroup, 32 filters per wave), same ring,
+// same DMA pieces; what changes is the k -> pixel map of a fragment (four 8-pixel octets, one per 16-lane group) and with it
+// two LDS images, so that the two groups of a 32-lane half never share a bank:
+//   dy pieces: sub-block S of pixel quad Q stored at S ^ 2 (Q >> 1) (the two 16-filter records swapped for pixels 8..15);
+//   x ring:    8-channel chunk c of slot s stored at c ^ 2 ((s >> 3) & 1) (the two 16-channel halves swapped in every
+//              other octet of slots) -- the swap lives in the DMA's per-lane SOURCE address and in the readers' addresses.
+// Accumulators: acc[tap][channel half][filter block] of 16 x 16; slab piece (((wave * 9 + t) * 2 + hf) * 2 + m).
+template <int RING, int KO = 0>
+__global__ __launch_bounds__(256, 2) void wgrad_win16_kernel(const WgradArgs a) {
+  constexpr int A_STAGE = 2 * 4 * PL_PLANES * 1024;
+  constexpr int WIN_PLANE = RING * 64 + 64;
+  constexpr int WIN_OFF = 2 * A_STAGE;
+  constexpr unsigned RMASK = RING * 64 - 1;
+  constexpr unsigned ZSLOT = RING * 64;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const unsigned lds_base = (unsigned)(size_t)smem;
+  if (lds_base != 0) __builtin_trap();
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lid = xcd_remap(blockIdx.x, a.nblocks);
+  const int tiles = a.tiles_co * a.tiles_j;
+  const int split = lid / tiles;
+  const int tile = lid - split * tiles;
+  const int co0 = (tile % a.tiles_co) * WW_CO;
+  const int ci0 = (tile / a.tiles_co) * WW_CI;
+  const int p_begin = (int)((long long)split * a.chunk);
+  int p_end = p_begin + (int)a.chunk;
+  if (p_end > (int)a.M) p_end = (int)a.M;
+  if (p_begin >= p_end) return;
+  const int nst = (p_end - p_begin + WW_STAGE_PX - 1) / WW_STAGE_PX;
+  const int W = a.Ws, H = a.Hs, M = (int)a.M;
+  if (tid < 32) reinterpret_cast<unsigned*>(smem + WIN_OFF + (tid >> 4) * WIN_PLANE + ZSLOT)[tid & 15] = 0u;
+
+  const unsigned strideA = (unsigned)((a.Cout >> 4) * PL_RECORD);
+  const unsigned strideB = (unsigned)((a.Cs >> 4) * PL_RECORD);
+  const unsigned zeroA = (unsigned)a.zero_blk_dy * strideA, zeroB = (unsigned)a.zero_blk_src * strideB;
+  const i32x4 rsrcA = planes_rsrc(a.dy, a.dy_bytes), rsrcB = planes_rsrc(a.src, a.src_bytes);
+  // dy piece: LDS position (quad Q = l >> 4, sub-block position (l >> 2) & 3, pixel l & 3) holds sub-block pos ^ 2 (Q >> 1)
+  const int lq = lane >> 4, lpix = 4 * lq + (lane & 3), lsb = ((lane >> 2) & 3) ^ (2 * (lq >> 1));
+  const unsigned a_lane = (unsigned)(((co0 + wave * 32) >> 4) + (lsb >> 1)) * PL_RECORD + (lsb & 1) * 256 + lpix * 16;
+  auto issue_A = [&](int stage, int buf) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int pb16 = p_begin + stage * WW_STAGE_PX + j * 16;
+      const unsigned v = (pb16 < p_end) ? (unsigned)(pb16 >> 4) * strideA + a_lane : zeroA;
+#pragma unroll
+      for (int p = 0; p < PL_PLANES; ++p) {
+        const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + buf * A_STAGE + ((j * 4 + wave) * PL_PLANES + p) * 1024);
+        dma16(rsrcA, v, (unsigned)(p * 512), l);
+      }
+    }
+  };
+  // x piece: LDS position (pixel l >> 2, chunk position l & 3) holds chunk pos ^ 2 (pixel >> 3) (slot bit 3 = pixel bit 3: pieces
+  // start at multiples of 16)
+  const int bpx = lane >> 2, bch = (lane & 3) ^ (2 * (bpx >> 3));
+  const unsigned b_lane = (unsigned)((ci0 >> 4) + (bch >> 1)) * PL_RECORD + (bch & 1) * 256;
+  auto issue_B = [&](int P0, int plane) {
+    const int P = P0 + bpx;
+    const unsigned v = ((unsigned)P < (unsigned)M) ? (unsigned)(P >> 4) * strideB + b_lane + (P & 15) * 16 : zeroB;
+    const unsigned l = __builtin_amdgcn_readfirstlane(lds_base + WIN_OFF + plane * WIN_PLANE + (unsigned)((P0 & (RING - 1)) * 64));
+    dma16(rsrcB, v, (unsigned)(plane * 512), l);
+  };
+  const int lo = (p_begin - W - 1) & ~15;
+  const int Lbase = (p_begin + W + 33 + 15) & ~15;
+  {
+    const int npieces = ((Lbase - lo) >> 4) * PL_PLANES;
+    for (int idx = wave; idx < npieces; idx += 4) issue_B(lo + (idx >> 1) * 16, idx & 1);
+  }
+  issue_A(0, 0);
+
+  // reader roles: 16-lane group g = pixel octet g of the 32-pixel stage; lane (qq, pq) of the group supplies pixel 8 g + 4 r + qq
+  // of read r, channels 4 pq .. 4 pq + 3 of the 16-channel block
+  const int grp = lane >> 4, i16 = lane & 15;
+  const int qq = i16 >> 2, pq = i16 & 3;
+  typedef ws16x4 __attribute__((address_space(3))) * lds_p;
+  auto rd_pair = [&](unsigned a0, unsigned a1, int off) -> f16x8 {
+    const ws16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(size_t)(a0 + off));
+    const ws16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_p)(size_t)(a1 + off));
+    const ws16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return __builtin_bit_cast(f16x8, v);
+  };
+  // dy fragment of filter block m: piece j = g >> 1, quad 2 (g & 1) + r, sub-block (2 m + (pq >> 1)) ^ 2 (g & 1)
+  unsigned abase[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+    abase[m] = (unsigned)((grp >> 1) * 4 * PL_PLANES * 1024 + wave * PL_PLANES * 1024 + 512 * (grp & 1) +
+                          64 * ((2 * m + (pq >> 1)) ^ (2 * (grp & 1))) + 16 * qq + 8 * (pq & 1));
+  const unsigned lc = (unsigned)((pq >> 1) * 16 + (pq & 1) * 8);   // inside a 32-byte half of a window slot
+  unsigned pb[2];
+  int px[2], py[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int p = p_begin + 8 * grp + 4 * r + qq;
+    pb[r] = (((unsigned)p & (RING - 1)) << 6) + lc;
+    const int row = p / W;
+    px[r] = p - row * W;
+    py[r] = row % H;
+  }
+  const int adv_rows = WW_STAGE_PX / W, adv_rem = WW_STAGE_PX - adv_rows * W;
+  int shb[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) shb[t] = ((t / 3 - 1) * W + (t % 3 - 1)) * 64;
+
+  f32x4 acc[9][2][2];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[t][hf][m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const unsigned zl = ZSLOT + lc;
+  for (int s = 0; s < nst; ++s) {
+    if constexpr (!(KO & 1)) {
+      issue_A(s + 1, (s + 1) & 1);
+      issue_B(Lbase + s * WW_STAGE_PX + (wave >> 1) * 16, wave & 1);
+    }
+    const unsigned aoff = (unsigned)((s & 1) * A_STAGE);
+    bool okx0[2], okx1[2], oky0[2], oky1[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      okx0[r] = px[r] != 0;
+      okx1[r] = px[r] != W - 1;
+      oky0[r] = py[r] != 0;
+      oky1[r] = py[r] != H - 1;
+    }
+    // addresses of tap t: [read r][channel half]; the half's 32 bytes swap with bit 3 of the slot (= bit 9 of the byte offset)
+    auto calc = [&](int t, unsigned (&ad)[2][2]) {
+      const int ty = t / 3, tx = t % 3;
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {
+        bool ok = true;
+        if (ty == 0) ok = ok && oky0[r];
+        if (ty == 2) ok = ok && oky1[r];
+        if (tx == 0) ok = ok && okx0[r];
+        if (tx == 2) ok = ok && okx1[r];
+        unsigned b = (pb[r] + (unsigned)shb[t]) & RMASK;
+        b = ((KO & 8) || ok) ? b : zl;
+        ad[r][0] = b + (((b >> 9) & 1u) << 5);
+        ad[r][1] = ad[r][0] ^ 32u;
+      }
+    };
+    f16x8 ah[2], al[2], bh[2], bl[2];
+    unsigned adt[2][2][2];   // [tap parity][read][half]
+    calc(0, adt[0]);
+    if constexpr (!(KO & 2)) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        ah[m] = rd_pair(abase[m] + aoff, abase[m] + aoff + 256, 0);
+        al[m] = rd_pair(abase[m] + aoff, abase[m] + aoff + 256, 1024);
+      }
+      bh[0] = rd_pair(adt[0][0][0], adt[0][1][0], WIN_OFF);
+      bl[0] = rd_pair(adt[0][0][0], adt[0][1][0], WIN_OFF + WIN_PLANE);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {   // i = tap * 2 + channel half
+      const int t = i >> 1, hf = i & 1, cur = i & 1, nxt = cur ^ 1;
+      if constexpr (!(KO & 4)) {
+        acc[t][hf][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[0], bh[cur], acc[t][hf][0], 0, 0, 0);
+        acc[t][hf][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[1], bh[cur], acc[t][hf][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(KO & 2)) {
+        if (i + 1 < 18) {   // the fragments of step i + 1 = (tap (i + 1) / 2, half (i + 1) & 1)
+          const int tn = (i + 1) >> 1, hn = (i + 1) & 1;
+          bh[nxt] = rd_pair(adt[tn & 1][0][hn], adt[tn & 1][1][hn], WIN_OFF);
+          bl[nxt] = rd_pair(adt[tn & 1][0][hn], adt[tn & 1][1][hn], WIN_OFF + WIN_PLANE);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(KO & 4)) {
+        acc[t][hf][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bl[cur], acc[t][hf][0], 0, 0, 0);
+        acc[t][hf][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bl[cur], acc[t][hf][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (hf == 0 && t + 1 < 9) calc(t + 1, adt[(t + 1) & 1]);   // (tap t + 1's addresses: read from step (t, 1) on)
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (!(KO & 4)) {
+        acc[t][hf][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[0], bh[cur], acc[t][hf][0], 0, 0, 0);
+        acc[t][hf][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[1], bh[cur], acc[t][hf][1], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 17) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          pb[r] = (pb[r] + WW_STAGE_PX * 64) & RMASK;
+          int x = px[r] + adv_rem, y = py[r] + adv_rows;
+          if (x >= W) {
+            x -= W;
+            ++y;
+          }
+          if (y >= H) y -= H;
+          px[r] = x;
+          py[r] = y;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+  const float unscale =
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.dy) + a.dy_bytes - PL_HEADER)[2] *
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2];
+  if (a.slabs != nullptr) {
+    float* mine = a.slabs + (size_t)lid * WW_TILE_FLOATS;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          *reinterpret_cast<f32x4*>(mine + (((((wave * 9 + t) * 2 + hf) * 2 + m) * 64) + lane) * 4) = acc[t][hf][m];
+    return;
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const long long cj = (long long)t * a.Cs + ci0 + 16 * hf + (lane & 15);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int co = co0 + wave * 32 + 16 * m + 4 * (lane >> 4) + e;
+          atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[t][hf][m][e] * unscale);
+        }
+    }
+}
+
+// the ordered reduce for the 16x16 accumulator order: piece (((wave * 9 + t) * 2 + hf) * 2 + m), lane l = filter rows
+// 4 (l >> 4) .. + 3 of block m, channel 16 hf + (l & 15)
+__global__ __launch_bounds__(256) void wgrad_win16_reduce_kernel(const WgradArgs a) {
+  constexpr int PER_TILE = WW_TILE_FLOATS / 4;
+  const int tiles = a.tiles_co * a.tiles_j;
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int tile = (int)(idx / PER_TILE);
+  if (tile >= tiles) return;
+  const int q = (int)(idx - (long long)tile * PER_TILE);
+  const int lane = q & 63, piece = q >> 6;
+  const int m = piece & 1, hf = (piece >> 1) & 1, t = (piece >> 2) % 9, wave = piece / 36;
+  const int co = (tile % a.tiles_co) * WW_CO + wave * 32 + 16 * m + 4 * (lane >> 4);
+  const long long cj = (long long)t * a.Cs + (tile / a.tiles_co) * WW_CI + 16 * hf + (lane & 15);
+  const f32x4* sl = reinterpret_cast<const f32x4*>(a.slabs) + (size_t)tile * PER_TILE + q;
+  const size_t sstride = (size_t)tiles * PER_TILE;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 8 <= a.splits; s += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(sl + (size_t)(s + u) * sstride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sum = sum + v[u];
+  }
+  for (; s < a.splits; ++s) sum = sum + __builtin_nontemporal_load(sl + (size_t)s * sstride);
+  const float unscale =
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.dy) + a.dy_bytes - PL_HEADER)[2] *
+      reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.src) + a.src_bytes - PL_HEADER)[2];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) a.dw[(long long)(co + e) * a.ldw + cj] += sum[e] * unscale;
+}
+
 bool wgrad_win_supported(const WgradArgs& a) {
   if (a.ntaps != 9 || a.kw != 3 || a.sy != 1 || a.sx != 1 || a.pad_t != 1 || a.pad_l != 1) return false;
   if (a.Hg != a.Hs || a.Wg != a.Ws) return false;
@@ -307,8 +582,10 @@ bool wgrad_win_supported(const WgradArgs& a) {
   return true;
 }
 
-template <int RING, int KO, int PF = 1>
+template <int RING, int KO, int PF = 1, bool M16 = false>
 static int launch_ww(WgradArgs& a, hipStream_t st) {
+  const void* kfn = M16 ? reinterpret_cast<const void*>(&wgrad_win16_kernel<RING, KO>)
+                        : reinterpret_cast<const void*>(&wgrad_win_kernel<RING, KO, PF>);
   a.tiles_co = a.Cout / WW_CO;
   a.tiles_j = a.Cs / WW_CI;
   const long long tiles = (long long)a.tiles_co * a.tiles_j;
@@ -316,9 +593,8 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
   static int resident = 0;
   if (resident == 0) {
     int per_cu = 0, dev = 0, cus = 0;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_win_kernel<RING, KO, PF>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)lds);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(&wgrad_win_kernel<RING, KO, PF>), 256, lds) ==
+    (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) ==
             hipSuccess &&
         hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess)
       resident = per_cu * cus;
@@ -348,11 +624,13 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
   a.chunk = chunk;
   a.splits = (int)splits;
   a.nblocks = (int)(tiles * splits);
-  hipLaunchKernelGGL((wgrad_win_kernel<RING, KO, PF>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
+  if constexpr (M16) hipLaunchKernelGGL((wgrad_win16_kernel<RING, KO>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((wgrad_win_kernel<RING, KO, PF>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
   if (int rc = check_launch("wgrad_win_kernel")) return rc;
   if (a.slabs != nullptr) {
     const long long pieces = tiles * (WW_TILE_FLOATS / 4);
-    hipLaunchKernelGGL(wgrad_win_reduce_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, a);
+    if constexpr (M16) hipLaunchKernelGGL(wgrad_win16_reduce_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(wgrad_win_reduce_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, a);
     return check_launch("wgrad_win_reduce_kernel");
   }
   return YOLO_OK;
@@ -373,6 +651,7 @@ int launch_wgrad_win(WgradArgs& a, hipStream_t st) {
     }
 #endif
   if (small && g_opt[OPT_WGRAD_WIN] == 2) return launch_ww<256, 0, 2>(a, st);   // fragment reads two tap-steps ahead
+  if (g_opt[OPT_WGRAD_WIN] == 3) return small ? launch_ww<256, 0, 1, true>(a, st) : launch_ww<512, 0, 1, true>(a, st);   // 16x16x32 MFMA
   return small ? launch_ww<256, 0>(a, st) : launch_ww<512, 0>(a, st);
 }
 

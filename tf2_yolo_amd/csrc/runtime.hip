@@ -31,7 +31,8 @@ static void options_from_env() {
   // 3x3 stride-1 window kernel on 2-D patches (conv_win.hip, GEO = 1): 0 off, 1 automatic, 2 wherever the shape allows
   e = getenv("YOLO_CONV_PATCH");
   g_opt[OPT_CONV_PATCH] = e ? atoi(e) : 1;
-  // 3x3 stride-1 filter gradient with the input window in LDS (conv_wgrad_win.hip): 0 off, 1 wherever the shape allows
+  // 3x3 stride-1 filter gradient with the input window in LDS (conv_wgrad_win.hip): 0 off, wherever the shape allows: 1 = on
+  // v_mfma_f32_32x32x16_f16, 2 = that with fragment reads two tap-steps ahead, 3 = on v_mfma_f32_16x16x32_f16 (default 1: 3 is 4 % faster alone, equal in the step)
   e = getenv("YOLO_WGRAD_WIN");
   g_opt[OPT_WGRAD_WIN] = e ? atoi(e) : 1;
 }

@@ -82,8 +82,21 @@ def planes_wgrad_ok(cin, cout, taps, stride=1):
 _WGRAD_WIDE = int(_os.environ.get("YOLO_WGRAD_WIDE", "2"))
 
 
-def _wgrad_planes_variant(cout, cols, taps=1, pixels=1 << 40):
-    """mirrors launch_wgrad_planes() in csrc/conv_wgrad_planes.hip"""
+WGRAD_WIN = int(_os.environ.get("YOLO_WGRAD_WIN", "1"))
+
+
+def _wgrad_win_covers(d):
+    """mirrors wgrad_win_supported() in csrc/conv_wgrad_win.hip: 3x3 stride-1 'same', 128-filter x 32-channel tiles"""
+    return (WGRAD_WIN != 0 and d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.pad_t == 1 and d.pad_l == 1
+            and d.H == d.Ho and d.W == d.Wo and d.Cout % 128 == 0 and d.Cin % 32 == 0 and d.W >= 4
+            and 2 * d.W + 81 <= 512 and 32 // d.W + 2 <= d.H and d.N * d.Ho * d.Wo >= 64)
+
+
+def _wgrad_planes_variant(cout, cols, taps=1, pixels=1 << 40, d=None):
+    """mirrors launch_wgrad_planes() in csrc/conv_wgrad_planes.hip (names used by bench.py's roofline report)"""
+    if d is not None and _wgrad_win_covers(d):
+        # conv_wgrad_win.hip: 128 filters x (9 taps x 32 channels) per workgroup, x streamed once through an LDS ring
+        return "wgrad_win_planes_kernel<128,288%s>" % (",mfma16" if WGRAD_WIN == 3 else "")
     if cout > 64 and cols >= 256 and (_WGRAD_WIDE == 1 or (_WGRAD_WIDE == 2 and taps > 1 and pixels <= 8192)):
         return "wgrad_planes_kernel<128,256,2,2>"
     big = "4,2" if _os.environ.get("YOLO_WGRAD_WAVES") == "8" else "2,2"
@@ -515,7 +528,7 @@ def conv2d_wgrad_planes(d, xp, dyp, dw, dy=None, dbias=None):
         check(_lib.load().yolo_conv2d_wgrad_planes(byref(d), _p(xp), _p(dyp), _p(dw), _stream()),
               "yolo_conv2d_wgrad_planes")
     if TIMER is not None:
-        TIMER.bracket(_wgrad_planes_variant(d.Cout, d.kh * d.kw * d.Cin, d.kh * d.kw, d.N * d.Ho * d.Wo), _conv_flops(d), 1, run,
+        TIMER.bracket(_wgrad_planes_variant(d.Cout, d.kh * d.kw * d.Cin, d.kh * d.kw, d.N * d.Ho * d.Wo, d), _conv_flops(d), 1, run,
                       _layer_key(d, "wgrad"))
     else:
         run()
