@@ -359,6 +359,8 @@ def main():
     backend = os.environ.get("YOLO_DIST_BACKEND", "nccl")
     dev_index = 0 if single_dev else local_rank
     torch.cuda.set_device(dev_index)
+    from tf2_yolo_amd import ops as _ops_early
+    _ops_early.create_side_streams()   # BEFORE RCCL creates its streams: the step's two compute streams get hardware queues of their own
     import torch.distributed as dist
     # YOLO_DP_FORCE=1: initialise RCCL and run the gradient exchange in a world of ONE rank too
     # (tests/test_gpu_dp.py: the RCCL calls, side stream and bucket views on a single GPU)

@@ -62,7 +62,11 @@ class GradReducer:
         self.buckets, self.closes = plan_buckets(segments, flat_grads.numel(), max(bucket_bytes // 4, 1),
                                                  max(min(first, bucket_bytes) // 4, 1))
         self.on_gpu = flat_grads.is_cuda
-        self.comm_stream = torch.cuda.Stream() if self.on_gpu else None
+        if self.on_gpu:   # a stream that demonstrably runs beside the compute stream and the filter-gradient stream (ops.concurrent_stream)
+            from . import ops
+            self.comm_stream = ops.concurrent_stream("comm", [torch.cuda.current_stream(), ops.concurrent_stream("wgrad")])
+        else:
+            self.comm_stream = None
         self._works = []
         # callable -> list of further CUDA streams that produce gradients (the engine's filter-gradient
         # stream): a bucket is reduced only after the work enqueued on them so far has finished too

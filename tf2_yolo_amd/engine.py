@@ -330,6 +330,7 @@ class Network:
         self.grad_ready_hook = None   # called as hook(unit) after a unit's parameter grads are enqueued
         self.backward_begin_hook = None   # called at the start of backward (the gradient reducer's time origin)
         self._infer_scale_valid = False
+        ops.create_side_streams()     # the process's filter-gradient / communication streams (one per role, fixed creation order)
         ops.ensure_conv_workspace()   # scratch of the persistent (stream-K) window kernel: small-batch launches
         ops.ensure_wgrad_workspace()  # slabs of the atomics-free filter / bias gradient reductions
         # consumers per tensor decide whether a tensor needs a gradient at all
@@ -695,7 +696,7 @@ class Network:
             # the filters' planes (needed by the first planes conv) and their transposed forms (needed by backward) are
             # made on the second stream while the stem runs: 0.45 ms of HBM-bound launches beside MFMA-bound ones
             if self._wgrad_stream is None:
-                self._wgrad_stream = torch.cuda.Stream(device=self.device)
+                self._wgrad_stream = ops.concurrent_stream("wgrad")
             side = self._wgrad_stream
             tape.wait_stream(side, torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -1071,7 +1072,7 @@ class Network:
             yield
             return
         if self._wgrad_stream is None:
-            self._wgrad_stream = torch.cuda.Stream(device=self.device)
+            self._wgrad_stream = ops.concurrent_stream("wgrad")
         side = self._wgrad_stream
         tape.wait_stream(side, torch.cuda.current_stream())
         for t in tensors:

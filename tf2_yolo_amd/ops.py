@@ -197,6 +197,59 @@ def ensure_wgrad_workspace():
     return _WGRAD_WS
 
 
+# ---- side streams of the process: created ONCE, EARLY, in a fixed order ----
+# The ROCm runtime maps HIP streams onto a few hardware queues (GPU_MAX_HW_QUEUES; tf2_yolo_amd/__init__.py raises the default
+# of 4 to 8) in creation order, wrapping around, and two streams on one queue execute one after the other. Measured (round 4,
+# profiles/r04_b_dp_*): with RCCL initialised first, the filter-gradient stream -- created lazily in the first forward pass --
+# landed on the compute stream's queue: 34.2 instead of 30.1 ms per step; as the fourth model of one process, YOLOv4-608's own
+# filter-gradient stream did the same: 58.8 instead of 39.7 ms. So the process has ONE stream per role, shared by every model,
+# and the roles are created together, filter gradients first: call create_side_streams() before anything else creates streams
+# (bench.py does, before init_process_group; Network.__init__ does for single-process use). YOLO_STREAM_PROBE=1 additionally
+# checks with two spin kernels that the new stream overlaps the current one and warns if not (diagnostic; the probe's extra
+# streams shift later assignments, so it is off by default).
+_SIDE_STREAMS = {}
+
+
+def _overlaps(a, b, cycles=6000000):   # ~3 ms per spin kernel: far above the ~50 us of the cross-stream waits around them
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        e0.record(a)
+        torch.cuda._sleep(cycles)
+        e1.record(a)
+    torch.cuda.synchronize()
+    one = e0.elapsed_time(e1)
+    with torch.cuda.stream(a):
+        e0.record(a)
+    b.wait_event(e0)
+    with torch.cuda.stream(b):
+        torch.cuda._sleep(cycles)
+    with torch.cuda.stream(a):
+        torch.cuda._sleep(cycles)
+    a.wait_stream(b)
+    e2.record(a)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e2) < 1.5 * one
+
+
+def create_side_streams():
+    """the process's filter-gradient and communication streams, in that order (idempotent)"""
+    for role in ("wgrad", "comm"):
+        if role not in _SIDE_STREAMS:
+            st = torch.cuda.Stream()
+            if _os.environ.get("YOLO_STREAM_PROBE") == "1" and not _overlaps(torch.cuda.current_stream(), st):
+                import warnings
+                warnings.warn(f"tf2_yolo_amd: the {role} stream shares a hardware queue with the compute stream: the step "
+                              "will run them one after the other (create_side_streams() earlier, or raise GPU_MAX_HW_QUEUES)")
+            _SIDE_STREAMS[role] = st
+    return _SIDE_STREAMS
+
+
+def concurrent_stream(role, beside=None):
+    """the process-wide side stream of `role` ('wgrad', 'comm')"""
+    return create_side_streams()[role]
+
+
 def set_option(key, value):
     """yolo_set_option: run-time kernel-variant switches of the library (benchmarks, tests)"""
     check(_lib.load().yolo_set_option(int(key), int(value)), "yolo_set_option")
