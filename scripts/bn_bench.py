@@ -8,6 +8,9 @@ from tf2_yolo_amd.ops import _p, _stream
 
 SHAPES = [(32 * 208 * 208, 64), (32 * 104 * 104, 128), (32 * 52 * 52, 256), (32 * 26 * 26, 512), (32 * 13 * 13, 1024),
           (32 * 52 * 52, 128), (32 * 416 * 416, 32)]
+if os.environ.get("BN_BENCH_SHAPES") == "c4":   # YOLOv4-608 bs 16: CSP stages (Mish) and neck (LeakyReLU)
+    SHAPES = [(16 * 304 * 304, 64), (16 * 152 * 152, 64), (16 * 152 * 152, 128), (16 * 76 * 76, 128), (16 * 76 * 76, 256),
+              (16 * 38 * 38, 256), (16 * 38 * 38, 512), (16 * 19 * 19, 512), (16 * 19 * 19, 1024)]
 
 
 def timeit(f, iters=20):
