@@ -234,7 +234,11 @@ int yolo_stem_fwd_infer_unit(const yolo_conv_desc* d, const float* x, const floa
 int yolo_split_planes_concat(const float* const* srcs_host, const int* channels_host, const float* const* bounds_host,
                              int nsrc, long long rows, void* planes, float* dst32, float* out_bound, void* stream);
 /* yolo_conv2d_wgrad on pre-split operands (dw += ..., same contract; the bias gradient stays with
- * yolo_conv2d_wgrad_bias on the fp32 dy). Requires Cin % 16 == 0, Cout % 16 == 0, Cout >= 32, kh*kw*Cin >= 64. */
+ * yolo_conv2d_wgrad_bias on the fp32 dy). Requires Cin % 16 == 0, Cout % 16 == 0, Cout >= 32, kh*kw*Cin >= 64.
+ * Two kernels behind it, same results to fp32 summation order: 3x3 stride-1 'same' layers with Cout % 128 == 0 and
+ * Cin % 32 == 0 (rows of 4 .. 215 pixels) stream x ONCE through a ring of pixel slots in LDS and take all nine taps from it
+ * (csrc/conv_wgrad_win.hip; yolo_set_option key 6); everything else takes one tap per tile (csrc/conv_wgrad_planes.hip).
+ * Reference op: TensorFlow's autodiff of Conv2D, yolov3/models/backbone.py:27-36. */
 int yolo_conv2d_wgrad_planes(const yolo_conv_desc* d, const void* x_planes, const void* dy_planes,
                              float* dw, void* stream);
 
