@@ -359,6 +359,18 @@ int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, long long P,
                                  const float* scale, const float* shift, const float* save_mean,
                                  const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,
                                  float* dx, void* planes, const unsigned* bound_aux, void* stream);
+/* The same two passes with dout given as a CHANNEL SLICE of a wider tensor: row p of dout starts at dout + p * ld_dout
+ * (floats; ld_dout >= C, a multiple of 4, dout 16-byte aligned; the apply pass needs C % 8 == 0 for a pitch other than C).
+ * This is how the gradient of a Concatenate (yolov3/models/darknet.py:88,93; the CSP / SPP / PAN concats of
+ * yolov4/models/backbone.py:141,183 and yolov4/models/darknet.py:97-127) reaches the BatchNormalization backward of its
+ * sources without being copied out slice by slice first (TensorFlow's autodiff of Concatenate is a split: views too). */
+int yolo_bn_act_bwd_reduce_bound_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
+                                    const float* scale, const float* shift, const float* save_mean,
+                                    const float* save_invstd, int act, double* red, unsigned* bound_aux, void* stream);
+int yolo_bn_act_bwd_apply_planes_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
+                                    const float* gamma, const float* scale, const float* shift, const float* save_mean,
+                                    const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,
+                                    float* dx, void* planes, const unsigned* bound_aux, void* stream);
 
 /* plain activation (no BN) forward / backward on [n] elements; used by conv(+bias)+act
  * units without BN, if any */

@@ -65,6 +65,44 @@ def test_bn_act_train_fwd_bwd(C, act, use_res):
     assert _rel(mv2, 0.99 + 0.01 * var.detach() * P / (P - 1)) < TOL
 
 
+@pytest.mark.parametrize("C,act", [(32, 1), (64, 2), (24, 1)])
+def test_bn_act_bwd_reads_a_channel_slice_in_place(C, act):
+    """yolo_bn_act_bwd_reduce_bound_ld / _apply_planes_ld: dout given as channels [off, off + C) of a wider tensor (the
+    gradient of a Concatenate, ops.ChannelSlice) -- the same arithmetic on the same values in the same order as on the dense
+    copy, so dx, its planes, dgamma, dbeta and the bound words must be BIT-identical to the dense call; pixel counts that are
+    not multiples of 16, slices at the start / middle / end of the wide tensor."""
+    from tf2_yolo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(40 + C)
+    N, H, W = 2, 9, 7
+    P = N * H * W
+    Cw = C + 48 + 16
+    x = torch.randn(P, C, device="cuda", generator=g) * 2 + 0.3
+    wide = torch.randn(P, Cw, device="cuda", generator=g)
+    gamma = torch.rand(C, device="cuda", generator=g) + 0.5
+    scale = torch.rand(C, device="cuda", generator=g) + 0.5
+    shift = torch.randn(C, device="cuda", generator=g) * 0.1
+    smean = torch.randn(C, device="cuda", generator=g) * 0.1
+    sinv = torch.rand(C, device="cuda", generator=g) + 0.5
+    for off in (0, 48, Cw - C):
+        dense = wide[:, off:off + C].contiguous()
+        res = []
+        for dout in (dense, ops.ChannelSlice(wide, Cw, off, C)):
+            red = torch.zeros(513 * 2 * C, device="cuda", dtype=torch.float64)
+            dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+            aux = torch.zeros(68, device="cuda", dtype=torch.int32)
+            pl = torch.zeros(ops.planes_bytes(P, C), device="cuda", dtype=torch.uint8) if C % 16 == 0 else None
+            dx = ops.bn_act_bwd(x, dout, C, gamma, scale, shift, smean, sinv, act, red, dg, db, planes=pl,
+                                bound_aux=aux if pl is not None else None)
+            torch.cuda.synchronize()
+            res.append((dx, dg, db, pl, aux))
+        for a, b in zip(*res):
+            assert (a is None and b is None) or torch.equal(a, b)
+    with pytest.raises(Exception):
+        ops.bn_act_bwd(x, ops.ChannelSlice(wide, Cw, 2, C), C, gamma, scale, shift, smean, sinv, act,
+                       torch.zeros(513 * 2 * C, device="cuda", dtype=torch.float64), torch.zeros(C, device="cuda"),
+                       torch.zeros(C, device="cuda"))
+
+
 def test_bn_inference_fold():
     from tf2_yolo_amd import ops
     C = 64

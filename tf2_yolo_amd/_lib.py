@@ -94,6 +94,9 @@ SIGNATURES = {
     "yolo_bn_finalize_offset": (c_int, [_P, _LL, c_int, _P, _P, c_float, c_float, c_int, _P, _P, _P, _P, _P, _P, _P,
                                         _P, _P, _P]),
     "yolo_bn_act_bwd_reduce_bound": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "yolo_bn_act_bwd_reduce_bound_ld": (c_int, [_P, _P, _LL, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "yolo_bn_act_bwd_apply_planes_ld": (c_int, [_P, _P, _LL, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
+                                                _P]),
     "yolo_act_fwd": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_act_bwd": (c_int, [_P, _P, _LL, c_int, _P, _P]),
     "yolo_copy_channels_in": (c_int, [_P, _LL, c_int, _P, c_int, c_int, _P]),

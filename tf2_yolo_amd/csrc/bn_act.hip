@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x,
-                                                            const float* __restrict__ dout, long long P, int C,
+                                                            const float* __restrict__ dout, long long ldd, long long P, int C,
                                                             int cw, int rpp, const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ smean,
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
           const long long pu = p + u * stride;
           const long long pc = pu < p_hi ? pu : p;
           xo[u] = *reinterpret_cast<const f32x4*>(x + pc * C + c4 * 4);
-          dO[u] = *reinterpret_cast<const f32x4*>(dout + pc * C + c4 * 4);
+          dO[u] = *reinterpret_cast<const f32x4*>(dout + pc * ldd + c4 * 4);   // (ldd: row pitch of dout, C when dense)
         }
       };
       long long p = p_lo + row_lane;
@@ -430,7 +430,7 @@ __global__ __launch_bounds__(256) void bn_act_fwd8_kernel(const float* __restric
 // (x - mean is formed first, as in the generic kernel: no cancellation between B*x and B*mean)
 template <bool PLANES, bool WRITE_DX>
 __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restrict__ x,
-                                                            const float* __restrict__ dout, long long P, int C,
+                                                            const float* __restrict__ dout, long long ldd, long long P, int C,
                                                             int wpr, long long blocks_per_wg, long long rows_total,
                                                             double invP, const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
@@ -484,7 +484,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply8_kernel(const float* __restr
     if (p < P) {
       const long long e = p * C + g8 * 8;
       const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + e), x1 = *reinterpret_cast<const f32x4*>(x + e + 4);
-      const f32x4 d0 = *reinterpret_cast<const f32x4*>(dout + e), d1 = *reinterpret_cast<const f32x4*>(dout + e + 4);
+      const long long ed = p * ldd + g8 * 8;   // (ldd: row pitch of dout, C when dense)
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(dout + ed), d1 = *reinterpret_cast<const f32x4*>(dout + ed + 4);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const float dz0 = d0[k] * act_grad(fmaf(sc[k], x0[k], sh[k]), A);
@@ -725,21 +726,31 @@ extern "C" int yolo_bn_act_fwd(const float* x, long long P, int C, const float* 
   return yolo_bn_act_fwd_planes(x, P, C, scale, shift, act, residual, out, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-extern "C" int yolo_bn_act_bwd_reduce_bound(const float* x, const float* dout, long long P, int C, const float* scale,
-                                            const float* shift, const float* save_mean, const float* save_invstd,
-                                            int act, double* red, unsigned* bound_aux, void* stream) {
+extern "C" int yolo_bn_act_bwd_reduce_bound_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
+                                               const float* scale, const float* shift, const float* save_mean,
+                                               const float* save_invstd, int act, double* red, unsigned* bound_aux,
+                                               void* stream) {
   YOLO_REQUIRE(x && dout && scale && shift && save_mean && save_invstd && red && P > 0 && C > 0,
                "bn_act_bwd_reduce: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_reduce: C=%d must be a multiple of 4", C);
+  YOLO_REQUIRE(ld_dout >= C && ld_dout % 4 == 0 && (reinterpret_cast<size_t>(dout) & 15) == 0,
+               "bn_act_bwd_reduce: dout row pitch %lld must be >= C, a multiple of 4, dout 16-byte aligned", ld_dout);
+  const long long ldd = ld_dout;
   const ColGeom g = col_geom(C / 4);
   int gx = reduce_grid_x(P, g.rpp);
   if (gx > YOLO_BN_RED_SLOTS) gx = YOLO_BN_RED_SLOTS;   // every workgroup owns one slot of `red`
   dim3 grid(gx, (C / 4 + g.cw - 1) / g.cw);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, dout, P, C, g.cw, g.rpp, scale,
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, dout, ldd, P, C, g.cw, g.rpp, scale,
                      shift, save_mean, save_invstd, act, red, bound_aux);
   hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), C, red, gx, P, scale,
                      bound_aux);
   return check_launch("bn_bwd_reduce_kernel");
+}
+
+extern "C" int yolo_bn_act_bwd_reduce_bound(const float* x, const float* dout, long long P, int C, const float* scale,
+                                            const float* shift, const float* save_mean, const float* save_invstd,
+                                            int act, double* red, unsigned* bound_aux, void* stream) {
+  return yolo_bn_act_bwd_reduce_bound_ld(x, dout, C, P, C, scale, shift, save_mean, save_invstd, act, red, bound_aux, stream);
 }
 
 extern "C" int yolo_bn_act_bwd_reduce(const float* x, const float* dout, long long P, int C, const float* scale,
@@ -753,7 +764,20 @@ extern "C" int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, l
                                             const float* save_invstd, int act, double* red, float* dgamma,
                                             float* dbeta, float* dx, void* planes, const unsigned* bound_aux,
                                             void* stream) {
+  return yolo_bn_act_bwd_apply_planes_ld(x, dout, C, P, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta,
+                                         dx, planes, bound_aux, stream);
+}
+
+extern "C" int yolo_bn_act_bwd_apply_planes_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
+                                               const float* gamma, const float* scale, const float* shift,
+                                               const float* save_mean, const float* save_invstd, int act, double* red,
+                                               float* dgamma, float* dbeta, float* dx, void* planes,
+                                               const unsigned* bound_aux, void* stream) {
   (void)gamma;
+  YOLO_REQUIRE(ld_dout == C || (C % 8 == 0 && ld_dout > C && ld_dout % 4 == 0 && (reinterpret_cast<size_t>(dout) & 15) == 0),
+               "bn_act_bwd_apply: a dout row pitch (%lld) other than C needs C %% 8 == 0, pitch %% 4 == 0, dout 16-byte aligned",
+               ld_dout);
+  const long long ldd = ld_dout;
   YOLO_REQUIRE(x && dout && scale && shift && save_mean && save_invstd && red && (dx || planes) && P > 0 && C > 0,
                "bn_act_bwd_apply: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_apply: C=%d must be a multiple of 4", C);
@@ -768,7 +792,7 @@ extern "C" int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, l
     const RowGeom g = row_geom(rows, C);
     unsigned char* pl = reinterpret_cast<unsigned char*>(planes);
 #define YOLO_BWD8(PL, DX)                                                                                            \
-  hipLaunchKernelGGL((bn_bwd_apply8_kernel<PL, DX>), dim3(g.gx, g.gy), dim3(256), 0, st, x, dout, P, C, g.wpr,       \
+  hipLaunchKernelGGL((bn_bwd_apply8_kernel<PL, DX>), dim3(g.gx, g.gy), dim3(256), 0, st, x, dout, ldd, P, C, g.wpr,  \
                      g.blocks_per_wg, rows, 1.0 / (double)P, scale, shift, save_mean, save_invstd, act, redsum, dx, pl,  \
                      bound_aux, dgamma, dbeta)
     if (planes && dx) YOLO_BWD8(true, true);

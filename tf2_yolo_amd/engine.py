@@ -335,6 +335,15 @@ class Network:
         ops.ensure_wgrad_workspace()  # slabs of the atomics-free filter / bias gradient reductions
         # consumers per tensor decide whether a tensor needs a gradient at all
         self._needs_grad = self._compute_needs_grad()
+        self._n_consumers = {}
+        for u in self.units:
+            for t in u.inputs:
+                self._n_consumers[t.tid] = self._n_consumers.get(t.tid, 0) + 1
+        for t in self.outputs:
+            self._n_consumers[t.tid] = self._n_consumers.get(t.tid, 0) + 1
+        # the gradient of a Concatenate reaches the BatchNormalization backward of its sources as a channel SLICE of the
+        # concat's gradient (ops.ChannelSlice: read in place with its row pitch) instead of being copied out per source
+        self._concat_grad_slices = os.environ.get("YOLO_CONCAT_GRAD_SLICE", "1") != "0"
         # pre-split ("planes") copies of the filters for the LDS-DMA conv kernels: [Cout][taps*Cin] for
         # forward, [Cin][taps*Cout] for dgrad; refreshed when the parameters change
         wp = 0
@@ -886,6 +895,16 @@ class Network:
         return True
 
     # ---- backward -----------------------------------------------------------------------
+    def _takes_grad_slice(self, u):
+        """can unit u's backward read dL/d(out) as a channel slice of a wider tensor? conv + BatchNormalization units without a
+        residual Add (bn_act_bwd reads dout twice and nothing else does), not the fused stem path"""
+        if u.kind != "conv" or not u.bn or u.residual is not None or u.cout % 8 != 0:
+            return False
+        need_pl = u.planes_wgrad or u.planes_dgrad
+        if self._stem_fused and not need_pl and not self._needs_grad[u.src.tid] and ops.stem_bn_bwd_supported(u.desc):
+            return False
+        return True
+
     def _add_grad(self, grads, t, buf):
         """Contribute `buf` (same shape as tensor t) to dL/dt: alias if first, else add in place."""
         if not self._needs_grad[t.tid]:
@@ -939,6 +958,8 @@ class Network:
             dout = grads.pop(u.out.tid, None)
             if dout is None:
                 continue  # output unused by the loss
+            if isinstance(dout, ops.ChannelSlice) and not self._takes_grad_slice(u):
+                dout = dout.dense((N, u.out.h, u.out.w, u.out.c))
             if u.kind == "conv":
                 xin = self.act[u.src.tid]
                 if u.bn:
@@ -1019,6 +1040,12 @@ class Network:
                 for s in u.srcs:
                     if self._needs_grad[s.tid]:
                         cur = grads.get(s.tid)
+                        if (cur is None and self._concat_grad_slices and self._n_consumers.get(s.tid, 0) == 1
+                                and s.producer is not None and self._takes_grad_slice(s.producer)
+                                and s.c % 8 == 0 and off % 4 == 0 and u.out.c % 4 == 0):
+                            grads[s.tid] = ops.ChannelSlice(dout, u.out.c, off, s.c)   # read in place by bn_act_bwd
+                            off += s.c
+                            continue
                         if cur is None:
                             cur = torch.empty((N, s.h, s.w, s.c), device=self.device, dtype=torch.float32)
                             ops.copy_channels_out(dout, u.out.c, off, cur, s.c, accumulate=False)

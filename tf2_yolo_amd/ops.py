@@ -705,10 +705,35 @@ def bn_act_fwd(x, C, scale, shift, act, residual=None, out=None, planes=None, bn
     return out
 
 
+class ChannelSlice:
+    """dL/d(tensor) given as channels [c_off, c_off + C) of a wider dense tensor `base` [P][ld]: what the gradient of a
+    Concatenate IS for each of its sources. bn_act_bwd reads it in place (row pitch ld); dense() copies it out for every other
+    consumer."""
+    __slots__ = ("base", "ld", "c_off", "C")
+
+    def __init__(self, base, ld, c_off, C):
+        self.base, self.ld, self.c_off, self.C = base, ld, c_off, C
+
+    def view(self):
+        """flat view starting at the slice's first element (row p of the slice starts at p * ld)"""
+        return self.base.reshape(-1)[self.c_off:]
+
+    def dense(self, shape):
+        out = torch.empty(shape, device=self.base.device, dtype=torch.float32)
+        copy_channels_out(self.base, self.ld, self.c_off, out, self.C, accumulate=False)
+        return out
+
+
 def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dx=None,
                planes=None, want_dx=True, bound_aux=None):
     """returns dx (None when want_dx is False and only the planes of dx are produced). planes needs bound_aux:
-    int32 CUDA tensor of 68 zeroed words (filled by the reduce step, read by the apply step)."""
+    int32 CUDA tensor of 68 zeroed words (filled by the reduce step, read by the apply step). dout may be a ChannelSlice
+    (C % 8 == 0): the two passes then read it in place with its row pitch."""
+    ld = C
+    if isinstance(dout, ChannelSlice):
+        if dout.C != C or C % 8 != 0 or dout.c_off % 4 != 0 or dout.ld % 4 != 0:
+            raise YoloHipError("bn_act_bwd: channel slice does not fit (C % 8, offset % 4, pitch % 4)")
+        ld, dout = dout.ld, dout.view()
     P = x.numel() // C
     if planes is not None and planes.numel() < planes_bytes(P, C):
         raise YoloHipError("bn_act_bwd: planes buffer too small")
@@ -719,11 +744,11 @@ def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red
     if dx is None and want_dx:
         dx = torch.empty_like(x)
     lib = _lib.load()
-    check(lib.yolo_bn_act_bwd_reduce_bound(_p(x), _p(dout), P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
-                                           act, _p(red), _p(bound_aux), _stream()), "yolo_bn_act_bwd_reduce")
-    check(lib.yolo_bn_act_bwd_apply_planes(_p(x), _p(dout), P, C, _p(gamma), _p(scale), _p(shift), _p(save_mean),
-                                           _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta),
-                                           _p(dx if want_dx else None), _p(planes), _p(bound_aux), _stream()),
+    check(lib.yolo_bn_act_bwd_reduce_bound_ld(_p(x), _p(dout), ld, P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
+                                              act, _p(red), _p(bound_aux), _stream()), "yolo_bn_act_bwd_reduce")
+    check(lib.yolo_bn_act_bwd_apply_planes_ld(_p(x), _p(dout), ld, P, C, _p(gamma), _p(scale), _p(shift), _p(save_mean),
+                                              _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta),
+                                              _p(dx if want_dx else None), _p(planes), _p(bound_aux), _stream()),
           "yolo_bn_act_bwd_apply")
     return dx if want_dx else None
 
