@@ -187,10 +187,9 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
     }
 
     // ---- sweep the prediction channels ----
-    for (int base = 0; base < PD; base += 64) {
-      const bool active = (base + lane) < PD;
-      const int idx = active ? (base + lane) : (PD - 1);
-      int b, k;  // anchor, channel within anchor (k >= 5: class k-5)
+    // (the loads of chunk i + 1 -- the prediction and, for a class channel, its target -- are issued before chunk i is worked on:
+    // one wave per cell had ONE load in flight per 64 channels; 52x52 level 227 -> 179 us for 206 MB)
+    auto chan_of = [&](int idx, int& b, int& k) {   // anchor, channel within anchor (k >= 5: class k-5)
       if (VER == 1) {
         if (idx < 5 * A) {
           b = idx / 5;
@@ -203,7 +202,28 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
         b = idx / TD;
         k = idx - b * TD;
       }
-      const float p = Pc[idx];
+    };
+    float p_nxt, tk_nxt;
+    {
+      const int idx0 = lane < PD ? lane : (PD - 1);
+      int b0, k0;
+      chan_of(idx0, b0, k0);
+      p_nxt = Pc[idx0];
+      tk_nxt = T[k0 >= 5 ? k0 : 4];
+    }
+    for (int base = 0; base < PD; base += 64) {
+      const bool active = (base + lane) < PD;
+      const int idx = active ? (base + lane) : (PD - 1);
+      int b, k;
+      chan_of(idx, b, k);
+      const float p = p_nxt, tk_cur = tk_nxt;
+      if (base + 64 < PD) {
+        const int idn = (base + 64 + lane) < PD ? (base + 64 + lane) : (PD - 1);
+        int bn, kn;
+        chan_of(idn, bn, kn);
+        p_nxt = Pc[idn];
+        tk_nxt = T[kn >= 5 ? kn : 4];
+      }
       // all cross-lane traffic happens here, with every lane participating
       const float iou_b = __shfl(iou, b, 64);
       const float d0 = __shfl(dI[0], b, 64), d1 = __shfl(dI[1], b, 64);
@@ -293,15 +313,18 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
           const float cc = fminf(fmaxf(p, LEPS), ONE_M_EPS);
           const float pass = (p >= LEPS && p <= ONE_M_EPS) ? 1.f : 0.f;
           const float gm = c.focal_gamma;
-          const float a1 = powf(1.f - cc, gm), l1 = logf(cc);
-          const float a0 = powf(cc, gm), l0 = logf(1.f - cc);
+          // (gamma = 2, the reference's default: x^2 and x^1 without libm's powf -- the ONE confidence lane of a 64-channel
+          // chunk ran it four times while 63 lanes waited)
+          const bool g2 = gm == 2.f;
+          const float a1 = g2 ? (1.f - cc) * (1.f - cc) : powf(1.f - cc, gm), l1 = logf(cc);
+          const float a0 = g2 ? cc * cc : powf(cc, gm), l0 = logf(1.f - cc);
           const float lo = -obj * a1 * l1;
           const float ln = -noobj * a0 * l0;
           part[3] += (double)lo;
           part[4] += (double)ln;
           part[0] += (double)c.loss_weight[2] * ((double)lo + (double)c.binary_weight * (double)ln);
-          const float d1 = -obj * (-gm * powf(1.f - cc, gm - 1.f) * l1 + a1 / cc);
-          const float d0 = -noobj * (gm * powf(cc, gm - 1.f) * l0 - a0 / (1.f - cc));
+          const float d1 = -obj * (-gm * (g2 ? (1.f - cc) : powf(1.f - cc, gm - 1.f)) * l1 + a1 / cc);
+          const float d0 = -noobj * (gm * (g2 ? cc : powf(cc, gm - 1.f)) * l0 - a0 / (1.f - cc));
           g = c.loss_weight[2] * (d1 + c.binary_weight * d0) * pass;
         } else {  // VER == 4
           const float cc = fminf(fmaxf(p, LEPS), ONE_M_EPS);
@@ -321,23 +344,29 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
             deo = -1.f;
             den = 1.f;
           }
-          const float ao = powf(eo, gm), lo_ = logf(1.f - eo);
-          const float an_ = powf(en, gm), ln_ = logf(1.f - en);
+          const bool g2 = gm == 2.f;   // (see the focal branch above)
+          const float ao = g2 ? eo * eo : powf(eo, gm), lo_ = logf(1.f - eo);
+          const float an_ = g2 ? en * en : powf(en, gm), ln_ = logf(1.f - en);
           const float lo = -obj * ao * lo_;
           const float ln = -noobj * an_ * ln_;
           part[3] += (double)lo;
           part[4] += (double)ln;
           part[0] += (double)c.loss_weight[1] * ((double)lo + (double)c.binary_weight * (double)ln);
-          const float dfo = gm * powf(eo, gm - 1.f) * lo_ - ao / (1.f - eo);  // d/de [e^g log(1-e)]
-          const float dfn = gm * powf(en, gm - 1.f) * ln_ - an_ / (1.f - en);
+          const float dfo = gm * (g2 ? eo : powf(eo, gm - 1.f)) * lo_ - ao / (1.f - eo);  // d/de [e^g log(1-e)]
+          const float dfn = gm * (g2 ? en : powf(en, gm - 1.f)) * ln_ - an_ / (1.f - en);
           g = c.loss_weight[1] * (-obj * dfo * deo - c.binary_weight * noobj * dfn * den) * pass;
         }
       } else {  // class channel
-        const float tk = T[k];
+        const float tk = tk_cur;
         const float pc = fminf(fmaxf(p, LEPS), ONE_M_EPS);
         const float pass = (p >= LEPS && p <= ONE_M_EPS) ? 1.f : 0.f;
         const float wcls = (VER == 4) ? c.loss_weight[2] : c.loss_weight[3];
-        if (VER == 3 || VER == 4) {
+        if (VER != 1 && obj == 0.f) {
+          // every class term carries the factor obj: loss part and gradient are (signed) zeros -- 99.7 % of the slots of a
+          // 52x52 level -- so the two logarithms and two divisions per element are skipped; adding -0.0 to the sums and
+          // storing -0.0 instead of +0.0 would change nothing either
+          g = 0.f;
+        } else if (VER == 3 || VER == 4) {
           const float l = -obj * (tk * logf(pc) + (1.f - tk) * logf(1.f - pc));
           part[5] += (double)l;
           part[0] += (double)wcls * (double)l;
