@@ -63,18 +63,20 @@ def check(loss_fn, cfg, yt, yp):
     assert (dp - ypt.grad).abs().max().item() <= TOL * gscale, ((dp - ypt.grad).abs().max().item(), gscale)
 
 
-@pytest.mark.parametrize("focal,use_scale,level", [(False, True, 0), (True, True, 1), (False, False, 2), (True, False, 0)])
-def test_v3_loss(focal, use_scale, level):
+# (gamma = 2, the reference's default, takes the x * x form of the focal terms; 1.5 keeps libm's powf: both are checked)
+@pytest.mark.parametrize("focal,use_scale,level,gamma", [(False, True, 0, 2), (True, True, 1, 2), (False, False, 2, 2),
+                                                          (True, False, 0, 2), (True, True, 0, 1.5)])
+def test_v3_loss(focal, use_scale, level, gamma):
     from tf2_yolo_amd import ops
     g = 13 * 2 ** level if level < 2 else 20
     N, A, C = 3, 3, 6
     anchors = ANCH9[3 * level:3 * level + 3]
     yt, yp = make_case(N, g, A, C, anchors, seed=10 + level)
     kw = dict(binary_weight=0.7, loss_weight=[1.5, 1.2, 5, 0.8], ignore_thresh=0.6, use_focal_loss=focal,
-              focal_loss_gamma=2, use_scale=use_scale)
+              focal_loss_gamma=gamma, use_scale=use_scale)
     fn = OL.wrap_yolo_loss_v3((g, g), A, C, anchors=anchors, **kw)
     cfg = ops.make_loss_cfg(3, N, g, g, A, C, anchors, binary_weight=0.7, loss_weight=[1.5, 1.2, 5, 0.8],
-                            ignore_thresh=0.6, use_focal_loss=focal, focal_gamma=2, use_scale=use_scale)
+                            ignore_thresh=0.6, use_focal_loss=focal, focal_gamma=gamma, use_scale=use_scale)
     check(fn, cfg, yt, yp)
 
 
