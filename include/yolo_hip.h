@@ -372,6 +372,27 @@ int yolo_bn_act_bwd_apply_planes_ld(const float* x, const float* dout, long long
                                     const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,
                                     float* dx, void* planes, const unsigned* bound_aux, void* stream);
 
+/* The reduction of yolo_bn_act_bwd_reduce_bound FUSED INTO THE DATA GRADIENT THAT COMPLETES dout (round 5). In a training
+ * step the tensor dL/d(a), a = act(BatchNormalization(y)) (yolov3/models/backbone.py:52-55: DarknetConv2D_BN_Leaky;
+ * yolov4/models/backbone.py:76-111), is finished by the data gradient of a's LAST consumer -- the 3x3 convolution behind a
+ * residual block's 1x1 (plain form) or the next block's 1x1 adding into the gradient its Add already holds (accumulate
+ * form, yolov3/models/backbone.py:58-71: resblock_body). yolo_conv2d_dgrad_planes_bnred is yolo_conv2d_dgrad_planes whose
+ * epilogue, while it stores its tile of dx = dL/d(a), also reads the same tile of y (laid out like dx) and leaves the tile's
+ * per-channel sums of dz = dx * act'(scale * y + shift) and dz * xhat in ITS OWN slot of `partials`
+ * ([slot][2][Cin] floats; plain stores, fixed order: bit-reproducible like the standalone pass), and max|dz| in bound_aux.
+ * The standalone pass reads dx and y again from HBM (8 B per element); the fused form reads y once (4 B) beside stores the
+ * kernel makes anyway. *nslots receives the number of slots written (all of them are); slots_cap = room in `partials`
+ * (yolo_bnred_slots_cap gives a sufficient value). Stride 1, or stride 2 with the parity classes in one launch.
+ * yolo_bn_act_bwd_sum_partials then folds the slots in order into red's final sums (fp64) and completes bound_aux exactly
+ * as yolo_bn_act_bwd_reduce_bound does, after which yolo_bn_act_bwd_apply_planes(_ld) runs unchanged. */
+int yolo_bnred_slots_cap(const yolo_conv_desc* d);
+int yolo_conv2d_dgrad_planes_bnred(const yolo_conv_desc* d, const void* dy_planes, const void* wT_planes, float* dx,
+                                   int accumulate, const float* y, const float* scale, const float* shift,
+                                   const float* save_mean, const float* save_invstd, int act, float* partials,
+                                   int slots_cap, unsigned* bound_aux, int* nslots, void* stream);
+int yolo_bn_act_bwd_sum_partials(const float* partials, int nslots, long long P, int C, const float* scale, double* red,
+                                 unsigned* bound_aux, void* stream);
+
 /* plain activation (no BN) forward / backward on [n] elements; used by conv(+bias)+act
  * units without BN, if any */
 int yolo_act_fwd(const float* x, long long n, int act, float* out, void* stream);

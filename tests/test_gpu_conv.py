@@ -1056,3 +1056,114 @@ def test_split_planes_padded_equals_split_of_the_zero_padded_tensor():
         assert a.numel() == b.numel() and torch.equal(a[:n], b[:n]), (rows, c)
     with pytest.raises(Exception):
         ops.split_planes_padded(torch.zeros(4, 256, device="cuda"), 4, 250)
+
+
+# ---- BatchNormalization-backward reduction fused into the data gradient that completes dL/d(a) (round 5:
+# yolo_conv2d_dgrad_planes_bnred + yolo_bn_act_bwd_sum_partials; planes_epilogue.hpp) ----
+BNRED_CASES = [
+    # (N, H, W, Cin, Cout, k, stride, padding, bias), forced options {key: value}
+    ((2, 20, 17, 128, 256, 3, 1, "same", False), {}),                       # window kernel, 128 columns
+    ((3, 13, 13, 64, 128, 3, 1, "same", False), {}),                        # per-tap kernel (Cin = 64 columns), tiles cross images
+    ((2, 26, 26, 256, 128, 1, 1, "same", False), {}),                       # 1x1: the residual blocks' accumulate form
+    ((2, 16, 16, 32, 64, 1, 1, "same", False), {}),                         # 1x1 into 32 channels: the 128 x 32 tile
+    ((2, 17, 13, 32, 64, 3, 2, "darknet_s2", False), {}),                   # stride 2: four parity classes in one launch, odd sizes
+    ((2, 16, 16, 64, 128, 3, 2, "darknet_s2", False), {}),
+    ((2, 14, 14, 64, 64, 3, 2, "same", False), {}),                         # v1.5: 3x3 s2 'same' (asymmetric pad)
+    ((2, 40, 72, 128, 64, 3, 1, "same", False), {5: 2}),                    # 2-D patch window (128 x 128 tiles on 8 x 16 patches)
+    ((1, 152, 152, 64, 64, 3, 1, "same", False), {5: 2}),                   # patch, 256 x 64 tiles, ragged patches
+    ((1, 104, 104, 64, 128, 3, 1, "same", False), {}),                      # > 256 slots: the sum kernel's chunks + last arriver
+    ((32, 13, 13, 512, 1024, 3, 1, "same", False), {}),                     # a benchmark layer (split-K is off for the fused form)
+]
+
+
+@pytest.mark.parametrize("act", [1, 2])
+@pytest.mark.parametrize("case,opts", BNRED_CASES)
+def test_dgrad_fused_bn_backward_reduction(case, opts, act):
+    """The fused form against the two separate passes it replaces, on the same inputs: dx BIT-identical to
+    yolo_conv2d_dgrad_planes (plain and accumulate form), the folded sums of dz and dz * xhat within 2e-6 of the standalone
+    reduction's (fp32 tile sums folded in fp64 against per-element fp64 accumulation; relative to sum |dz|), max|dz| and the
+    apply step's output (dx of the BatchNorm, its planes, dgamma, dbeta) within fp32 rounding of the standalone path's, and the
+    whole thing bit-identical run to run (no atomics in the sums)."""
+    from tf2_yolo_amd import ops
+    from tf2_yolo_amd._lib import ACT_LEAKY
+    ops.ensure_conv_workspace()
+    n, h, w, cin, cout, k, s, pad, bias = case
+    g = torch.Generator(device="cuda").manual_seed(100 + cin + cout + k + s)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    P, C = n * h * w, cin
+    wk = torch.randn(cout, k, k, cin, device="cuda", generator=g) / (k * k * cin) ** 0.5
+    wT = ops.filter_transpose(wk, cout, k * k, cin)
+    dy = torch.randn(n, d.Ho, d.Wo, cout, device="cuda", generator=g)
+    dyp = ops.split_planes(dy, n * d.Ho * d.Wo, cout)
+    wTp = ops.split_planes(wT, cin, k * k * cout)
+    y = torch.randn(P, C, device="cuda", generator=g) * 1.5 + 0.2          # pre-BN tensor of the producer
+    gamma = torch.rand(C, device="cuda", generator=g) + 0.5
+    smean, var = y.mean(0), y.var(0, unbiased=False)
+    sinv = (1.0 / torch.sqrt(var + 1e-3)).contiguous()
+    scale = (gamma * sinv).contiguous()
+    shift = (torch.randn(C, device="cuda", generator=g) * 0.1 - smean * scale).contiguous()
+    old = torch.randn(n, h, w, cin, device="cuda", generator=g)            # what the accumulate form adds into
+    # (split-K off: the fused form never splits -- its reduction lives in the tile epilogue -- and the bit-identity of dx is
+    # between the same kernels)
+    ops.set_option(ops.OPT_CONV_SK, 0)
+    for key, val in opts.items():
+        ops.set_option(key, val)
+    try:
+        for accumulate in (False, True):
+            def standalone():
+                dx = old.clone() if accumulate else None
+                dx = ops.conv2d_dgrad_planes(d, dyp, wTp, dx=dx, accumulate=accumulate)
+                red = torch.zeros(513 * 2 * C, device="cuda", dtype=torch.float64)
+                aux = torch.zeros(68, device="cuda", dtype=torch.int32)
+                dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+                pl = torch.zeros(ops.planes_bytes(P, C), device="cuda", dtype=torch.uint8) if C % 16 == 0 else None
+                dyy = ops.bn_act_bwd(y, dx, C, gamma, scale, shift, smean, sinv, act, red, dg, db, planes=pl,
+                                     bound_aux=aux if pl is not None else None)
+                torch.cuda.synchronize()
+                return dx, red[512 * 2 * C:].clone(), aux, dg, db, pl, dyy
+
+            def fused():
+                cap = ops.bnred_slots_cap(d)
+                part = torch.full((cap * 2 * C,), float("nan"), device="cuda")   # every slot used must have been written
+                aux = torch.zeros(68, device="cuda", dtype=torch.int32)
+                b = ops.BnReduce(y, scale, shift, smean, sinv, act, part, cap, aux)
+                dx = old.clone() if accumulate else None
+                dx = ops.conv2d_dgrad_planes(d, dyp, wTp, dx=dx, accumulate=accumulate, bnred=b)
+                assert 0 < b.nslots <= cap
+                red = torch.zeros(513 * 2 * C, device="cuda", dtype=torch.float64)
+                dg, db = torch.zeros(C, device="cuda"), torch.zeros(C, device="cuda")
+                pl = torch.zeros(ops.planes_bytes(P, C), device="cuda", dtype=torch.uint8) if C % 16 == 0 else None
+                dyy = ops.bn_act_bwd(y, dx, C, gamma, scale, shift, smean, sinv, act, red, dg, db, planes=pl, bound_aux=aux,
+                                     fused=b)
+                torch.cuda.synchronize()
+                assert int(aux[3]) == 0                                          # the ticket word is back at zero
+                return dx, red[512 * 2 * C:].clone(), aux, dg, db, pl, dyy
+
+            s_dx, s_red, s_aux, s_dg, s_db, s_pl, s_dyy = standalone()
+            f_dx, f_red, f_aux, f_dg, f_db, f_pl, f_dyy = fused()
+            assert torch.equal(s_dx, f_dx)
+            # reference for the sums' scale: sum |dz| per channel, from the standalone tensors in float64
+            z = scale.double() * y.double() + shift.double()
+            if act == ACT_LEAKY:
+                dact = torch.where(z > 0, 1.0, 0.1)
+            else:
+                sp = torch.nn.functional.softplus(z)
+                t = torch.tanh(sp)
+                dact = t + z * (1 - t * t) * torch.sigmoid(z)
+            dz = s_dx.reshape(P, C).double() * dact
+            xh = (y.double() - smean.double()) * sinv.double()
+            ref = torch.stack([dz.sum(0), (dz * xh).sum(0)]).reshape(-1)
+            mag = torch.stack([dz.abs().sum(0), (dz * xh).abs().sum(0)]).reshape(-1)
+            assert ((f_red - ref).abs() / mag).max().item() < 2e-6
+            assert ((s_red - ref).abs() / mag).max().item() < 2e-6
+            assert f_aux.view(torch.float32)[0].item() == pytest.approx(dz.abs().max().item(), rel=1e-5)
+            assert s_aux.view(torch.float32)[0].item() == pytest.approx(f_aux.view(torch.float32)[0].item(), rel=1e-6) or s_pl is None
+            scl = max(s_dyy.abs().max().item(), 1e-30)
+            assert (s_dyy - f_dyy).abs().max().item() / scl < 1e-5
+            assert (s_dg - f_dg).abs().max().item() / max(s_dg.abs().max().item(), 1e-30) < 1e-5
+            assert (s_db - f_db).abs().max().item() / max(s_db.abs().max().item(), 1e-30) < 1e-5
+            again = fused()
+            for a_, b_ in zip((f_dx, f_red, f_dg, f_db, f_pl, f_dyy), (again[0], again[1], again[3], again[4], again[5], again[6])):
+                assert (a_ is None and b_ is None) or torch.equal(a_, b_)
+    finally:
+        ops.reset_options()

@@ -531,3 +531,50 @@ def test_planes_path_agrees_with_exact_kernels_at_full_layer_sizes():
     for oa, ob in zip(a["out_abs_sum"], b["out_abs_sum"]):
         assert abs(oa - ob) <= 1e-4 * abs(ob), (a["out_abs_sum"], b["out_abs_sum"])
     assert abs(a["grad_l2"] - b["grad_l2"]) <= 1e-3 * b["grad_l2"], (a["grad_l2"], b["grad_l2"])
+
+
+@pytest.mark.parametrize("version", [3, 4])
+def test_fused_bn_backward_reduction_option_gives_the_same_gradients(version, monkeypatch):
+    """YOLO_BN_FUSED_REDUCE=1 (the BatchNormalization-backward sums made by the data gradient that completes dL/d(a):
+    engine._plan_fused_reduce, include/yolo_hip.h: yolo_conv2d_dgrad_planes_bnred) against the default (standalone
+    reduction): same weights, same batch, one forward + loss + backward. Every parameter gradient within 2e-5 of the
+    largest gradient of its tensor (fp32 tile sums folded in fp64 against per-element fp64 accumulation; split-K data
+    gradients run unsplit in the fused form), the losses equal, and the fused form actually in use."""
+    import numpy as np
+    from tf2_yolo_amd import graphs, labels
+    import yolov3, yolov4
+    hw, cls = 96, 5
+    rng = np.random.default_rng(11)
+    x_h, ys_h = labels.synthetic_batch(rng, 3, (hw, hw), cls)
+    x = torch.from_numpy(x_h).cuda()
+    ys = [torch.from_numpy(y).cuda() for y in ys_h]
+    res = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("YOLO_BN_FUSED_REDUCE", mode)
+        if version == 3:
+            y = yolov3.Yolo((hw, hw, 3), [f"c{i}" for i in range(cls)])
+            y.create_model(pretrained_body=None, seed=5)
+        else:
+            y = yolov4.Yolo((hw, hw, 3), [f"c{i}" for i in range(cls)])
+            y.create_model(anchors=graphs.V4_DEFAULT_ANCHORS, pretrained_body=None, seed=5)
+        m = y.model
+        lossf = y.loss()
+        net = m.net
+        outs = net.forward(x, training=True)
+        dpred = [torch.empty_like(o) for o in outs]
+        lb = [torch.zeros(8, device="cuda", dtype=torch.float64) for _ in outs]
+        for i, (o, yt) in enumerate(zip(outs, ys)):
+            lossf[i].fwd_bwd(yt, o, grad_scale=1.0, dpred=dpred[i], loss_out=lb[i])
+        net.grads.zero_()
+        net.backward(dpred)
+        torch.cuda.synchronize()
+        fused_units = sum(1 for u in net.units if getattr(u, "bnred", None) is not None)
+        res.append((net.grads.clone(), [float(b[0]) for b in lb], fused_units, net))
+    (g0, l0, n0, net0), (g1, l1, n1, _) = res
+    assert n0 == 0 and n1 >= 20
+    assert l0 == pytest.approx(l1, rel=1e-12)   # (the forward pass is the same code in both: fp64 sums, atomic order aside)
+    for name in net0.params.order:
+        s = net0.params.specs[name]
+        a, b = g0[s.offset:s.offset + s.size], g1[s.offset:s.offset + s.size]
+        scale = max(a.abs().max().item(), 1e-30)
+        assert (a - b).abs().max().item() / scale < 2e-5, name

@@ -9,4 +9,12 @@ must be in the environment before that: import this package (or set the variable
 """
 import os as _os
 
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+    import sys as _sys
+    _t = _sys.modules.get("torch")
+    if _t is not None and _t.cuda.is_initialized():    # too late for this process: say so instead of silently doing nothing
+        import warnings as _w
+        _w.warn("tf2_yolo_amd: the HIP runtime was initialised before this import, so GPU_MAX_HW_QUEUES=8 does not apply to "
+                "this process (the training step's two compute streams may share a hardware queue: ~13 % slower steps). "
+                "Import tf2_yolo_amd, or set GPU_MAX_HW_QUEUES, before the first torch.cuda call.")

@@ -97,6 +97,10 @@ SIGNATURES = {
     "yolo_bn_act_bwd_reduce_bound_ld": (c_int, [_P, _P, _LL, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "yolo_bn_act_bwd_apply_planes_ld": (c_int, [_P, _P, _LL, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
                                                 _P]),
+    "yolo_bnred_slots_cap": (c_int, [POINTER(ConvDesc)]),
+    "yolo_conv2d_dgrad_planes_bnred": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P,
+                                               POINTER(c_int), _P]),
+    "yolo_bn_act_bwd_sum_partials": (c_int, [_P, c_int, _LL, c_int, _P, _P, _P, _P]),
     "yolo_act_fwd": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_act_bwd": (c_int, [_P, _P, _LL, c_int, _P, _P]),
     "yolo_copy_channels_in": (c_int, [_P, _LL, c_int, _P, c_int, c_int, _P]),
@@ -138,7 +142,7 @@ SIGNATURES = {
 _lib = None
 
 # functions that only answer a question on the host: never part of a recorded step (tape.py)
-_QUERIES = {"yolo_last_error", "yolo_abi_version", "yolo_device_available", "yolo_conv_workspace_bytes", "yolo_planes_bytes",
+_QUERIES = {"yolo_last_error", "yolo_abi_version", "yolo_bnred_slots_cap", "yolo_device_available", "yolo_conv_workspace_bytes", "yolo_planes_bytes",
             "yolo_stem_bwd_scratch_bytes", "yolo_loss_workspace_bytes", "yolo_decode_workspace_bytes",
             "yolo_nms_workspace_bytes", "yolo_pr_curve_workspace_bytes", "yolo_wgrad_workspace_bytes", "yolo_adam_lr_t",
             "yolo_set_option", "yolo_set_debug_buffer", "yolo_set_conv_workspace", "yolo_set_wgrad_workspace"}

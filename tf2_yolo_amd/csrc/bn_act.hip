@@ -586,6 +586,134 @@ __global__ __launch_bounds__(256) void bn_bwd_sum_kernel(int C, double* __restri
   }
 }
 
+// The slots of a reduction FUSED into a data gradient (planes_epilogue.hpp: GatherConvArgs::bwd_part, [nslots][2][C]
+// floats, one slot per row tile of that launch -- 43 for a 13x13 layer at batch 32, 10 816 for a 208x208 one) folded in
+// slot order into the final fp64 sums of `red`, plus the bound words, as bn_bwd_sum_kernel does for the standalone pass.
+// grid (C / 16, chunks): a workgroup = 16 channels x 16 slot groups over `chunk` slots. One chunk: the workgroup writes
+// the final sums. Several: it writes its chunk's sums to slot blockIdx.y of `red`, and the LAST workgroup to arrive
+// (ticket aux[3]; the chunk sums cross XCDs: fence before the ticket, acquire behind it) adds the chunks IN ORDER for
+// every channel -- who arrives last changes nothing in the arithmetic.
+__global__ __launch_bounds__(256) void bn_bwd_sum_part_kernel(int C, const float* __restrict__ part, int nslots, int chunk,
+                                                              double* red, long long P, const float* __restrict__ scale,
+                                                              unsigned* aux) {
+  __shared__ double s_part[2][16][16];
+  __shared__ unsigned s_ticket;
+  const int ch = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + ch;
+  const int r_lo = blockIdx.y * chunk;
+  const int r_hi = (r_lo + chunk < nslots) ? r_lo + chunk : nslots;
+  const bool single = gridDim.y == 1;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < C) {
+    int r = r_lo + grp;
+    for (; r + 112 < r_hi; r += 128) {   // eight slots (sixteen loads) in flight per round trip
+      float v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v0[u] = part[((long long)(r + 16 * u) * 2 + 0) * C + c];
+        v1[u] = part[((long long)(r + 16 * u) * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a0 += (double)v0[u];
+        a1 += (double)v1[u];
+      }
+    }
+    for (; r < r_hi; r += 16) {
+      a0 += (double)part[((long long)r * 2 + 0) * C + c];
+      a1 += (double)part[((long long)r * 2 + 1) * C + c];
+    }
+  }
+  s_part[0][grp][ch] = a0;
+  s_part[1][grp][ch] = a1;
+  __syncthreads();
+  float t1 = 0.f, t2 = 0.f;
+  if (grp == 0 && c < C) {
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      s0 += s_part[0][g][ch];
+      s1 += s_part[1][g][ch];
+    }
+    const long long dst = single ? (long long)YOLO_BN_RED_SLOTS : (long long)blockIdx.y;
+    red[dst * 2 * C + c] = s0;
+    red[dst * 2 * C + C + c] = s1;
+    if (single && aux != nullptr) {
+      const double asc = fabs((double)scale[c]);
+      t1 = (float)asc;
+      t2 = (float)(asc * (fabs(s1 / (double)P) * sqrt((double)P) + fabs(s0 / (double)P)) * 1.001);
+    }
+  }
+  if (single) {
+    if (aux != nullptr && threadIdx.x < 64) {   // wave 0 holds the 16 channel results in lanes 0..15
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        t1 = fmaxf(t1, __shfl_xor(t1, o, 64));
+        t2 = fmaxf(t2, __shfl_xor(t2, o, 64));
+      }
+      if (threadIdx.x == 0) {
+        if (t1 > __builtin_bit_cast(float, aux[1])) atomicMax(&aux[1], __builtin_bit_cast(unsigned, t1));
+        if (t2 > __builtin_bit_cast(float, aux[2])) atomicMax(&aux[2], __builtin_bit_cast(unsigned, t2));
+      }
+    }
+    if (aux != nullptr && blockIdx.x == 0 && threadIdx.x >= 64 && threadIdx.x < 128) {   // fold the 64 slots of max|dz|
+      unsigned m = aux[4 + (threadIdx.x & 63)];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned v = __shfl_xor(m, o, 64);
+        m = v > m ? v : m;
+      }
+      if ((threadIdx.x & 63) == 0) aux[0] = m;
+    }
+    return;
+  }
+  // ---- several chunks: ticket, the last arriver finishes every channel ----
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0)
+    s_ticket = __hip_atomic_fetch_add(&aux[3], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (s_ticket != gridDim.x * gridDim.y - 1) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const int nch = (int)gridDim.y;
+  for (int cc = threadIdx.x; cc < ((C + 63) & ~63); cc += 256) {
+    float u1 = 0.f, u2 = 0.f;
+    if (cc < C) {
+      double s0 = 0.0, s1 = 0.0;
+      for (int k = 0; k < nch; ++k) {   // chunk order
+        s0 += red[(long long)k * 2 * C + cc];
+        s1 += red[(long long)k * 2 * C + C + cc];
+      }
+      red[(long long)YOLO_BN_RED_SLOTS * 2 * C + cc] = s0;
+      red[(long long)YOLO_BN_RED_SLOTS * 2 * C + C + cc] = s1;
+      const double asc = fabs((double)scale[cc]);
+      u1 = (float)asc;
+      u2 = (float)(asc * (fabs(s1 / (double)P) * sqrt((double)P) + fabs(s0 / (double)P)) * 1.001);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      u1 = fmaxf(u1, __shfl_xor(u1, o, 64));
+      u2 = fmaxf(u2, __shfl_xor(u2, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(&aux[1], __builtin_bit_cast(unsigned, u1));
+      atomicMax(&aux[2], __builtin_bit_cast(unsigned, u2));
+    }
+  }
+  if (threadIdx.x < 64) {
+    unsigned m = aux[4 + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned v = __shfl_xor(m, o, 64);
+      m = v > m ? v : m;
+    }
+    if (threadIdx.x == 0) {
+      aux[0] = m;
+      __hip_atomic_store(&aux[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the ticket word, for the next use
+    }
+  }
+}
+
 __global__ void bn_bwd_params_kernel(int C, const double* __restrict__ redsum, float* __restrict__ dgamma,
                                      float* __restrict__ dbeta) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -745,6 +873,19 @@ extern "C" int yolo_bn_act_bwd_reduce_bound_ld(const float* x, const float* dout
   hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), C, red, gx, P, scale,
                      bound_aux);
   return check_launch("bn_bwd_reduce_kernel");
+}
+
+extern "C" int yolo_bn_act_bwd_sum_partials(const float* partials, int nslots, long long P, int C, const float* scale,
+                                            double* red, unsigned* bound_aux, void* stream) {
+  YOLO_REQUIRE(partials && red && scale && nslots > 0 && P > 0 && C > 0, "bn_act_bwd_sum_partials: bad args");
+  int chunk = 128;
+  while ((nslots + chunk - 1) / chunk > YOLO_BN_RED_SLOTS) chunk *= 2;
+  int nchunks = (nslots + chunk - 1) / chunk;
+  if (nslots <= 256) { chunk = nslots; nchunks = 1; }
+  YOLO_REQUIRE(nchunks == 1 || bound_aux != nullptr, "bn_act_bwd_sum_partials: %d slots need the ticket word of bound_aux", nslots);
+  hipLaunchKernelGGL(bn_bwd_sum_part_kernel, dim3((C + 15) / 16, nchunks), dim3(256), 0, as_stream(stream), C, partials,
+                     nslots, chunk, red, P, scale, bound_aux);
+  return check_launch("bn_bwd_sum_part_kernel");
 }
 
 extern "C" int yolo_bn_act_bwd_reduce_bound(const float* x, const float* dout, long long P, int C, const float* scale,

@@ -1037,8 +1037,27 @@ extern "C" int yolo_split_planes_padded(const float* x, long long rows, int C_sr
   return launch_split_planes_padded(x, rows, C_src, C, planes, as_stream(stream));
 }
 
+// the fused BatchNorm-backward reduction of yolo_conv2d_dgrad_planes_bnred (GatherConvArgs::bwd_*)
+struct BnRedArgs {
+  const float* y;
+  const float* scale;
+  const float* shift;
+  const float* mean;
+  const float* invstd;
+  int act;
+  float* part;
+  int cap;
+  unsigned* aux;
+  int nslots;   // out
+};
+static void set_bnred(GatherConvArgs& a, const BnRedArgs* b) {
+  if (b == nullptr) return;
+  a.bwd_y = b->y; a.bwd_scale = b->scale; a.bwd_shift = b->shift; a.bwd_mean = b->mean; a.bwd_invstd = b->invstd;
+  a.bwd_act = b->act; a.bwd_part = b->part; a.bwd_cap = b->cap; a.bwd_aux = b->aux;
+}
+
 static int dgrad_impl(const yolo_conv_desc* d, const float* dy, const float* wT, float* dx, int accumulate,
-                      void* stream, bool planes) {
+                      void* stream, bool planes, BnRedArgs* bnred = nullptr) {
   if (int rc = validate_desc(d)) return rc;
   YOLO_REQUIRE(dy && wT && dx, "conv_dgrad: null pointer");
   // hi = ho*sh + r - pad_t  =>  for input-row parity class py (hi = y*sh + py) the taps with
@@ -1087,9 +1106,14 @@ static int dgrad_impl(const yolo_conv_desc* d, const float* dy, const float* wT,
       a.ncls = nc;
       a.M = a.cls[0].M; a.Hg = a.cls[0].Hg; a.Wg = a.cls[0].Wg; a.ooy = 0; a.oox = 0; a.ntaps = a.cls[0].ntaps;
       YOLO_REQUIRE(gather_planes_supported(a), "conv_dgrad_planes: needs Cout %% 16 == 0 and Cin >= 32");
-      return launch_gather_planes(a, as_stream(stream));
+      set_bnred(a, bnred);
+      const int rc = launch_gather_planes(a, as_stream(stream));
+      if (bnred != nullptr) bnred->nslots = a.bwd_nslots;
+      return rc;
     }
   }
+  YOLO_REQUIRE(bnred == nullptr || d->sh * d->sw == 1,
+               "conv_dgrad_planes_bnred: a strided data gradient needs its parity classes in one launch");
   for (int py = 0; py < d->sh; ++py) {
     for (int px = 0; px < d->sw; ++px) {
       GatherConvArgs a{};
@@ -1132,7 +1156,9 @@ static int dgrad_impl(const yolo_conv_desc* d, const float* dy, const float* wT,
       }
       if (planes) {
         YOLO_REQUIRE(gather_planes_supported(a), "conv_dgrad_planes: needs Cout %% 16 == 0 and Cin >= 32");
+        set_bnred(a, bnred);
         if (int rc = launch_gather_planes(a, as_stream(stream))) return rc;
+        if (bnred != nullptr) bnred->nslots = a.bwd_nslots;
       } else if (int rc = dispatch_gather(a, flat, as_stream(stream))) {
         return rc;
       }
@@ -1150,6 +1176,30 @@ extern "C" int yolo_conv2d_dgrad_planes(const yolo_conv_desc* d, const void* dy_
                                         int accumulate, void* stream) {
   return dgrad_impl(d, reinterpret_cast<const float*>(dy_planes), reinterpret_cast<const float*>(wT_planes), dx,
                     accumulate, stream, true);
+}
+
+extern "C" int yolo_bnred_slots_cap(const yolo_conv_desc* d) {
+  // row tiles are at least 128 output pixels of the data gradient (= input pixels of the convolution); 2-D patch tiles
+  // and parity classes round up per image row / per class: 64 pixels per slot plus slack covers every launcher
+  if (d == nullptr) return 0;
+  const long long px = (long long)d->N * d->H * d->W;
+  const long long cap = px / 64 + 2LL * d->N + 64;
+  return cap > 0x7fffffffLL ? 0 : (int)cap;
+}
+
+extern "C" int yolo_conv2d_dgrad_planes_bnred(const yolo_conv_desc* d, const void* dy_planes, const void* wT_planes, float* dx,
+                                              int accumulate, const float* y, const float* scale, const float* shift,
+                                              const float* save_mean, const float* save_invstd, int act, float* partials,
+                                              int slots_cap, unsigned* bound_aux, int* nslots, void* stream) {
+  YOLO_REQUIRE(d && y && scale && shift && save_mean && save_invstd && partials && nslots && slots_cap > 0,
+               "conv_dgrad_planes_bnred: bad args");
+  YOLO_REQUIRE(d->Cin % 4 == 0, "conv_dgrad_planes_bnred: Cin=%d must be a multiple of 4", d->Cin);
+  YOLO_REQUIRE(act >= 0 && act <= 2, "conv_dgrad_planes_bnred: bad activation %d", act);
+  BnRedArgs b{y, scale, shift, save_mean, save_invstd, act, partials, slots_cap, bound_aux, 0};
+  const int rc = dgrad_impl(d, reinterpret_cast<const float*>(dy_planes), reinterpret_cast<const float*>(wT_planes), dx,
+                            accumulate, stream, true, &b);
+  *nslots = b.nslots;
+  return rc;
 }
 
 static void fill_wgrad_args(const yolo_conv_desc* d, WgradArgs& a) {

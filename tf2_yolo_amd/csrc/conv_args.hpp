@@ -77,8 +77,30 @@ struct GatherConvArgs {
   int ncls;
   ClassGeom cls[4];
   unsigned long long* stamps;  // diagnostic builds of conv_win.hip: 8 x u64 per workgroup (s_memtime / s_memrealtime)
+  // BatchNorm-backward reduction fused into the data gradient that COMPLETES dL/d(dst) (planes_epilogue.hpp): dst is the
+  // output a = act(scale * y + shift) of a conv + BatchNormalization unit whose pre-BN tensor is bwd_y (laid out like dst).
+  // The epilogue forms dz = dst * act'(scale * y + shift) from the FINAL value it stores (the accumulate form included) and
+  // leaves the tile's per-channel sums of dz and dz * xhat in its own slot of bwd_part ([slot][2][Cout] floats, plain
+  // stores: no atomics, fixed order) -- the pass yolo_bn_act_bwd_reduce would make over dst and y (8 B per element) becomes a
+  // 4 B per element read of y beside the tile's stores. bwd_aux: the 68 bound words of yolo_bn_act_bwd_reduce_bound.
+  const float* bwd_y;
+  const float* bwd_scale;
+  const float* bwd_shift;
+  const float* bwd_mean;
+  const float* bwd_invstd;
+  float* bwd_part;
+  unsigned* bwd_aux;
+  int bwd_act;
+  int bwd_nslots;   // set by the launcher: slots of bwd_part this launch writes (every one of them)
+  int bwd_cap;      // slots bwd_part has room for
   Tap taps[MAX_TAPS];
 };
+
+#define YOLO_BNRED_CHECK(a)                                                                                          \
+  if ((a).bwd_y != nullptr && (a).bwd_nslots > (a).bwd_cap) {                                                        \
+    set_error("conv_dgrad(bn reduce): %d partial slots needed, room for %d", (a).bwd_nslots, (a).bwd_cap);           \
+    return YOLO_ERR_INVALID_ARG;                                                                                     \
+  }
 
 // Blocks b and b+8 share an XCD (round-robin dispatch): give each XCD a contiguous run of
 // logical tiles so tiles that share A rows / B columns hit the same L2. Bijective for any

@@ -288,15 +288,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   // multi-class launch (its own instantiation, DBG bit 64; a.ncls parity classes of a strided data gradient): tile =
   // (row tile, class, column tile); everything that depends on the output grid comes from the class
   constexpr bool MULTI = (DBG & 64) != 0;
+  constexpr bool BNRED = (DBG & 512) != 0;   // the fused BatchNorm-backward reduction (planes_epilogue.hpp): its own kernels
   const int tile_n = tile % a.tiles_n;
   const int cls = MULTI ? (tile / a.tiles_n) % a.ncls : 0;
   const int tile_m = MULTI ? tile / (a.tiles_n * a.ncls) : tile / a.tiles_n;
   const long long m0 = (long long)tile_m * BM;
   const int n0 = tile_n * BN;
-  const EpiGeom G = MULTI ? EpiGeom{a.cls[cls].M, a.cls[cls].Hg, a.cls[cls].Wg, a.cls[cls].ooy, a.cls[cls].oox} : epi_geom_of(a);
+  const EpiGeom G = MULTI ? EpiGeom{a.cls[cls].M, a.cls[cls].Hg, a.cls[cls].Wg, a.cls[cls].ooy, a.cls[cls].oox, 0, 0, 0,
+                                    tile_m * a.ncls + cls + 1}
+                          : epi_geom_of(a);
   const int tap0 = MULTI ? a.cls[cls].tap0 : 0;
   const int ntaps = MULTI ? a.cls[cls].ntaps : a.ntaps;
-  if (MULTI && m0 >= G.M) return;   // (classes of an odd-sized image have different tile counts)
+  if (MULTI && m0 >= G.M) {   // (classes of an odd-sized image have different tile counts)
+    if (a.bwd_y != nullptr)   // its slot of the fused BatchNorm-backward reduction still has to hold zeros
+      for (int c = tid; c < BN; c += 64 * NW)
+        if (n0 + c < a.Cout) {
+          a.bwd_part[((long long)(G.slot1 - 1) * 2 + 0) * a.Cout + n0 + c] = 0.f;
+          a.bwd_part[((long long)(G.slot1 - 1) * 2 + 1) * a.Cout + n0 + c] = 0.f;
+        }
+    return;
+  }
   const int HgWg = G.Hg * G.Wg;
 
   // ---- loader role(s) ----
@@ -480,9 +491,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, (WGM * WGN >= 4 ? 2 : 1)) void gath
   if constexpr (SPLIT)
     store_split_slab<TM, TN>(a, acc, BM * BN * 4, tile * SP + part, wave, lane);
   else if constexpr (MULTI)
-    planes_epilogue<BM, BN, WGM, WGN, NBUF * STAGE_BYTES, 0>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid, NoStamp(), &G);
+    planes_epilogue<BM, BN, WGM, WGN, NBUF * STAGE_BYTES, 0, NoStamp, false, BNRED>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid, NoStamp(), &G);
   else
-    planes_epilogue<BM, BN, WGM, WGN, NBUF * STAGE_BYTES, (DBG & 31)>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
+    planes_epilogue<BM, BN, WGM, WGN, NBUF * STAGE_BYTES, (DBG & 31), NoStamp, false, BNRED>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
 }
 
 template <int BM, int BN, int WGM, int WGN, int DBG = 0>
@@ -506,17 +517,31 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
       }
       a.nblocks = (int)nbm;
       a.split_parts = 1;
+      a.bwd_nslots = (int)(tm * a.ncls);
+      YOLO_BNRED_CHECK(a)
       static bool attr64 = false;
       if (!attr64) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN, 64>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr64 = true;
       }
+      if (a.bwd_y != nullptr) {
+        static bool attr576 = false;
+        if (!attr576) {
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN, 64 | 512>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+          attr576 = true;
+        }
+        hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN, 64 | 512>), dim3((unsigned)nbm), dim3(64 * WGM * WGN), lds, st, a);
+        return check_launch("gather_conv_planes_kernel(classes, bn reduce)");
+      }
       hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN, 64>), dim3((unsigned)nbm), dim3(64 * WGM * WGN), lds, st, a);
       return check_launch("gather_conv_planes_kernel(classes)");
     }
   }
   a.nblocks = (int)nb;
+  a.bwd_nslots = (int)tiles_m;
+  YOLO_BNRED_CHECK(a)
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN, DBG>),
@@ -541,6 +566,21 @@ static int launch_planes(GatherConvArgs& a, hipStream_t st) {
       if (int rc = check_launch("gather_conv_planes_kernel(split)")) return rc;
       return launch_split_reduce(a, BM, st);
     }
+  }
+  if constexpr ((DBG & ~(128 | 256)) == 0) {
+    if (a.bwd_y != nullptr) {
+      static bool attr_bn = false;
+      if (!attr_bn) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gather_conv_planes_kernel<BM, BN, WGM, WGN, DBG | 512>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_bn = true;
+      }
+      hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN, DBG | 512>), dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
+      return check_launch("gather_conv_planes_kernel(bn reduce)");
+    }
+  } else if (a.bwd_y != nullptr) {
+    set_error("conv(planes): this diagnostic instantiation has no fused BatchNorm-backward reduction");
+    return YOLO_ERR_INVALID_ARG;
   }
   hipLaunchKernelGGL((gather_conv_planes_kernel<BM, BN, WGM, WGN, DBG>), dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
   return check_launch("gather_conv_planes_kernel");

@@ -439,7 +439,10 @@ int launch_wgrad_planes(WgradArgs& a, hipStream_t st) {
   a.zero_blk_dy = (int)((a.M + 15) / 16);
   const int cols = a.ntaps * a.Cs;
   init_options();
-  if (g_opt[OPT_WGRAD_WIN] != 0 && wgrad_win_supported(a)) return launch_wgrad_win(a, st);
+  if (g_opt[OPT_WGRAD_WIN] != 0 && wgrad_win_supported(a)) {
+    const int rc = launch_wgrad_win(a, st);   // (1: its LDS layout assumption does not hold in this build -- per-tap kernel below)
+    if (rc <= 0) return rc;
+  }
   if (a.Cout <= 64 && cols <= 64) return launch_wp<64, 64, 2, 2>(a, st);
   if (a.Cout <= 64) return launch_wp<64, 128, 2, 4>(a, st);
   if (cols <= 64) return launch_wp<128, 64, 4, 2>(a, st);

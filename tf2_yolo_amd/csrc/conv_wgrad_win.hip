@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradArgs a) {
   const int nst = (p_end - p_begin + WW_STAGE_PX - 1) / WW_STAGE_PX;
   const int W = a.Ws, H = a.Hs, M = (int)a.M;
 
-  if (lds_base != 0) __builtin_trap();   // the window reads below address LDS from 0
+  // (the window reads below address LDS from 0: launch_ww checks on the host that the kernel has no static LDS in front of it)
   // zero slots of the two window planes
   if (tid < 32) reinterpret_cast<unsigned*>(smem + WIN_OFF + (tid >> 4) * WIN_PLANE + ZSLOT)[tid & 15] = 0u;
 
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradArgs a) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (lgkmcnt too: the zero slot above is an LDS write, and a raw s_barrier carries no implicit wait for it)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   // The stage body is scheduled by hand (sched_barrier(0) between the groups: hipcc otherwise issues a tap's four fragment
@@ -318,7 +319,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_win16_kernel(const WgradArgs a) 
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const unsigned lds_base = (unsigned)(size_t)smem;
-  if (lds_base != 0) __builtin_trap();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -414,7 +414,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_win16_kernel(const WgradArgs a) 
 #pragma unroll
       for (int m = 0; m < 2; ++m) acc[t][hf][m] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // (lgkmcnt too: the zero slot above is an LDS write, and a raw s_barrier carries no implicit wait for it)
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   const unsigned zl = ZSLOT + lc;
@@ -591,8 +592,14 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
   const long long tiles = (long long)a.tiles_co * a.tiles_j;
   constexpr size_t lds = 2 * (2 * 4 * PL_PLANES * 1024) + 2 * (RING * 64 + 64);
   static int resident = 0;
+  static bool lds_from_zero = true;
   if (resident == 0) {
     int per_cu = 0, dev = 0, cus = 0;
+    // the kernels address their dynamic LDS from 0 (immediate offsets in the window reads): true only while no static
+    // __shared__ sits in front of it. Checked here instead of trapping on the device; 1 = "not covered", the caller then
+    // runs the per-tap kernel.
+    hipFuncAttributes fa{};
+    if (hipFuncGetAttributes(&fa, kfn) != hipSuccess || fa.sharedSizeBytes != 0) lds_from_zero = false;
     (void)hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kfn, 256, lds) ==
             hipSuccess &&
@@ -600,6 +607,7 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
       resident = per_cu * cus;
     if (resident <= 0) resident = 512;
   }
+  if (!lds_from_zero) return 1;
   // one round of the workgroups the chip holds; at least 8 stages per workgroup
   static const long long target_env = [] { const char* e = getenv("YOLO_WGRAD_WIN_TARGET"); return e ? atoll(e) : 0LL; }();
   const long long target = target_env > 0 ? target_env : resident;

@@ -63,7 +63,7 @@ namespace yolo {
 // 64 pixels (104 / 208 in YOLOv3-416, 76 / 152 / 304 in YOLOv4-608).
 // WGN = 1: 64 filter columns per tile (BN = 64) with WGM = 4 waves of 64 x 64 stacked in M (256 output pixels = a
 // 16 x 16 patch): the Cout = 64 layers, which would waste half of a 128-column tile.
-template <int WGM, int NCH, bool STAMPS = false, bool SPLIT = false, bool SK = false, int WGN = 2, int GEO = 0>
+template <int WGM, int NCH, bool STAMPS = false, bool SPLIT = false, bool SK = false, int WGN = 2, int GEO = 0, bool BNRED = false>
 __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_win_kernel(const GatherConvArgs a) {
   constexpr int BM = 64 * WGM, BN = 64 * WGN;
   constexpr int NW = WGM * WGN;
@@ -439,10 +439,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void conv_win_kernel(const Gathe
       ++epi_count;
     }
   } else if constexpr (GEO == 1) {
-    const EpiGeom pg = EpiGeom{a.M, a.Hg, a.Wg, 0, 0, pn, py0, px0};
-    planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL, 0, NoStamp, true>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid, NoStamp(), &pg);
+    const EpiGeom pg = EpiGeom{a.M, a.Hg, a.Wg, 0, 0, pn, py0, px0, 0};
+    planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL, 0, NoStamp, true, BNRED>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid, NoStamp(), &pg);
   } else if constexpr (!SPLIT) {
-    if (finish) planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
+    if (finish) planes_epilogue<BM, BN, WGM, WGN, LDS_TOTAL, 0, NoStamp, false, BNRED>(a, acc, smem, m0, n0, tile_m, wm, wn, lane, tid);
   }
   __syncthreads();   // the next part's DMAs overwrite the LDS the epilogue used
   if constexpr (STAMPS) {
@@ -701,7 +701,8 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
 // it takes to give every CU two workgroups, at most 32; needs the workspace of yolo_set_conv_workspace.
 int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb, int idle_div) {
   init_options();
-  if (g_opt[OPT_CONV_SK] != 1 || a.stats != nullptr || g_sk_ws == nullptr) return 1;
+  // (a.bwd_y: the fused BatchNorm-backward reduction lives in planes_epilogue only, not in conv_split_reduce_kernel)
+  if (g_opt[OPT_CONV_SK] != 1 || a.stats != nullptr || a.bwd_y != nullptr || g_sk_ws == nullptr) return 1;
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;
@@ -739,6 +740,8 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
     return YOLO_ERR_INVALID_ARG;
   }
   a.nblocks = (int)nb;
+  a.bwd_nslots = (int)tiles_m;
+  YOLO_BNRED_CHECK(a)
   constexpr size_t lds = 2 * NCH * 4096 + 3 * 8192;
   static bool attr_set = false;
   static int resident = 0;   // workgroups the chip holds at once (occupancy x CUs)
@@ -772,6 +775,17 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
   // 190 us with 32 -- the last arriver reads the other parts one after the other; layers with fewer than 32 channel
   // blocks (26x26: 41 us, 52x52: 24 us) do not gain at any split)
   // YOLO_CONV_SK=1 (default): split-K with the reduce kernel (conv_split_parts); -1: the stream-K policy above
+  if (a.bwd_y != nullptr) {   // the fused BatchNorm-backward reduction: one workgroup per tile, its own instantiation
+    static bool attr_bn = false;
+    if (!attr_bn) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_win_kernel<WGM, NCH, false, false, false, 2, 0, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_bn = true;
+    }
+    a.split_parts = 1;
+    hipLaunchKernelGGL((conv_win_kernel<WGM, NCH, false, false, false, 2, 0, true>), dim3(grid), dim3(128 * WGM), lds, st, a);
+    return check_launch("conv_win_kernel(bn reduce)");
+  }
   a.split_parts = WGM == 2 ? conv_split_parts(a, nb, BM, 2, 2) : 1;
   if (a.split_parts > 1) {
     a.tile_order = 0;
@@ -851,6 +865,8 @@ static int launch_patch(GatherConvArgs& a, hipStream_t st) {
     return YOLO_ERR_INVALID_ARG;
   }
   a.nblocks = (int)nb;
+  a.bwd_nslots = (int)tiles_m;
+  YOLO_BNRED_CHECK(a)
   constexpr size_t lds = 2 * NCH * 4096 + 3 * 4096 * WGN;
   auto kern = &conv_win_kernel<WGM, NCH, false, false, false, WGN, 1>;
   static bool attr_set = false;
@@ -862,6 +878,16 @@ static int launch_patch(GatherConvArgs& a, hipStream_t st) {
   a.sk_grid = 0;
   a.split_parts = 1;
   a.dbg = g_opt[OPT_DBG];
+  if (a.bwd_y != nullptr) {
+    auto kern_bn = &conv_win_kernel<WGM, NCH, false, false, false, WGN, 1, true>;
+    static bool attr_bn = false;
+    if (!attr_bn) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern_bn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_bn = true;
+    }
+    hipLaunchKernelGGL(kern_bn, dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
+    return check_launch("conv_win_kernel(patch, bn reduce)");
+  }
   hipLaunchKernelGGL(kern, dim3((unsigned)nb), dim3(64 * WGM * WGN), lds, st, a);
   return check_launch("conv_win_kernel(patch)");
 }

@@ -19,9 +19,11 @@ struct EpiGeom {
   int Hg, Wg, ooy, oox;
   // PATCH tiles (conv_win.hip, 2-D patch geometry): tile row rr is output pixel (pn, py0 + rr / 16, px0 + rr % 16)
   int pn, py0, px0;
+  // slot of GatherConvArgs::bwd_part this tile owns, plus one (0 = the tile's row-tile index): multi-class launches
+  int slot1;
 };
 __device__ __forceinline__ EpiGeom epi_geom_of(const GatherConvArgs& a) {
-  return EpiGeom{a.M, a.Hg, a.Wg, a.ooy, a.oox, 0, 0, 0};
+  return EpiGeom{a.M, a.Hg, a.Wg, a.ooy, a.oox, 0, 0, 0, 0};
 }
 
 // split-K (GatherConvArgs::split_parts > 1): a part's accumulators go to its slab in accumulator order --
@@ -48,7 +50,10 @@ __device__ __forceinline__ void store_split_slab(const GatherConvArgs& a, f32x16
 // PATCH: the tile's rows are a 2-D patch of output pixels, BM / 16 rows of 16 (EpiGeom::pn / py0 / px0), not BM consecutive
 // pixels: rows outside the image do not exist, and "which rows count for the statistics" is a per-lane bit mask
 // instead of a prefix of the tile.
-template <int BM, int BN, int WGM, int WGN, int LDS_BYTES, int DBG = 0, class STAMP = NoStamp, bool PATCH = false>
+// BNRED: the instantiation that can make the fused BatchNorm-backward reduction (GatherConvArgs::bwd_y). Its own template
+// parameter, i.e. its own kernels: the reduction holds a tile of y in registers beside the accumulators, and inside the
+// forward kernels that cost registers (the 8-wave 1x1 kernel fell from 3 to 2 waves per SIMD) for a path they never take.
+template <int BM, int BN, int WGM, int WGN, int LDS_BYTES, int DBG = 0, class STAMP = NoStamp, bool PATCH = false, bool BNRED = false>
 __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
                                                 unsigned char* smem, const long long m0, const int n0, const int tile_m,
                                                 const int wm, const int wn, const int lane, const int tid,
@@ -97,6 +102,9 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
   float csum[TN], csq[TN], cmx[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) csum[j] = csq[j] = cmx[j] = 0.f;
+  [[maybe_unused]] float bs1[TN], bs2[TN];   // scalar path of the fused BatchNorm-backward reduction (bnred below)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) bs1[j] = bs2[j] = 0.f;
   asm volatile("" ::"v"(unscale));
   stampf(1);
   // rows of this tile that exist (the last row tile of a tensor is partial): row r of the tile is real iff r < rows_valid
@@ -117,6 +125,10 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
             rowmask |= 1ull << (i * 16 + q);
     }
   }
+  // BatchNorm-backward reduction of the tensor this launch completes (GatherConvArgs::bwd_y): per-channel sums of
+  // dz = v * act'(scale * y + shift) and dz * xhat over the tile's rows, from the values as they are stored
+  const bool bnred = BNRED && a.bwd_y != nullptr && a.stats == nullptr;
+  float bn_mx = 0.f;   // max |dz| seen by this lane
   // Vector path. The C/D layout of the 32x32 MFMA leaves a lane with ONE column and 16 scattered rows of its
   // sub-tile (64 dword stores per lane, 128-B row pieces); every wave instead transposes its own sub-tile through a
   // PRIVATE strip of LDS, RP rows at a time, and stores dwordx4 (whole 128..512-B row pieces per lane group): no
@@ -136,6 +148,39 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
     float* strip = smf + FIXED + wave * (RP * TLD);
     constexpr int C4 = WCOLS / 4;                  // dwordx4 pieces per row of the sub-tile
     constexpr int ITER = RP * C4 / 64;
+    // (64 % C4 == 0: a lane stores the SAME four columns in every iteration of every pass, so the reduction's per-channel
+    // coefficients and sums live in registers)
+    static_assert(64 % C4 == 0, "store loop: a lane keeps its four columns");
+    const int bcol = n0 + wn * WCOLS + (lane % C4) * 4;
+    f32x4 b_sc = {0.f, 0.f, 0.f, 0.f}, b_sh = b_sc, b_mu = b_sc, b_iv = b_sc, b_s1 = b_sc, b_s2 = b_sc;
+    // ALL the y values (and, for small sub-tiles, the old values of the accumulate form) this lane will need are requested
+    // HERE, before the first staging pass: one memory latency per tile instead of one per batch of row pieces (loaded
+    // batch by batch the fused launches ran 9-14 % longer -- exactly what the standalone reduction had cost)
+    constexpr int NPASS = TM * (32 / RP);
+    constexpr bool PRE_OLD = TM * TN <= 2;
+    [[maybe_unused]] f32x4 ypre[BNRED ? NPASS : 1][BNRED ? ITER : 1];
+    [[maybe_unused]] f32x4 opre[BNRED && PRE_OLD ? NPASS : 1][BNRED && PRE_OLD ? ITER : 1];
+    if constexpr (BNRED)
+    if (bnred) {
+      const bool cok = bcol < a.Cout;
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+          const int rl = (lane + it * 64) / C4;
+          const long long o = rowoff[(wm * TM) * 32 + ps * RP + rl];   // (pass ps = (i, hp): rows (wm TM + i) 32 + hp RP ..)
+          const bool ok = cok && o >= 0;
+          ypre[ps][it] = ok ? *reinterpret_cast<const f32x4*>(a.bwd_y + o + bcol) : f32x4{0.f, 0.f, 0.f, 0.f};
+          if constexpr (PRE_OLD)
+            opre[ps][it] = (ok && a.accumulate) ? *reinterpret_cast<const f32x4*>(a.dst + o + bcol) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      if (cok) {
+        b_sc = *reinterpret_cast<const f32x4*>(a.bwd_scale + bcol);
+        b_sh = *reinterpret_cast<const f32x4*>(a.bwd_shift + bcol);
+        b_mu = *reinterpret_cast<const f32x4*>(a.bwd_mean + bcol);
+        b_iv = *reinterpret_cast<const f32x4*>(a.bwd_invstd + bcol);
+      }
+    }
     float bvj[TN], escj[TN], eshj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -192,6 +237,47 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my strip is written (wave-private: no barrier)
+        bool bn_here = false;
+        if constexpr (BNRED) bn_here = bnred;
+        if (bn_here) {
+          if constexpr (BNRED) {
+          // (its own form of the store loop, four row pieces at a time: their y values and, in the accumulate form, the old
+          // values of dst fly together; short batches keep the epilogue inside the main loop's register budget)
+          constexpr int SUB = ITER < 4 ? ITER : 4;
+          const int ps = i * (32 / RP) + hp;
+#pragma unroll
+          for (int h0 = 0; h0 < ITER; h0 += SUB) {
+            long long o4[SUB];
+            f32x4 v4[SUB], p4[SUB];
+#pragma unroll
+            for (int k = 0; k < SUB; ++k) {
+              const int idx = lane + (h0 + k) * 64;
+              const int rl = idx / C4, c4 = idx - rl * C4;
+              o4[k] = rowoff[row0 + rl];
+              v4[k] = *reinterpret_cast<const f32x4*>(strip + rl * TLD + c4 * 4);
+              if constexpr (PRE_OLD) p4[k] = opre[ps][h0 + k];
+              else
+                p4[k] = (o4[k] >= 0 && bcol < a.Cout && a.accumulate) ? *reinterpret_cast<const f32x4*>(a.dst + o4[k] + bcol)
+                                                                     : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int k = 0; k < SUB; ++k) {
+              if (o4[k] >= 0 && bcol < a.Cout) {
+                const f32x4 v = v4[k] + p4[k];
+                *reinterpret_cast<f32x4*>(a.dst + o4[k] + bcol) = v;   // (plain store: bn_act_bwd_apply reads this tensor next)
+                const f32x4 yv = ypre[ps][h0 + k];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float dz = v[e] * act_grad(fmaf(b_sc[e], yv[e], b_sh[e]), a.bwd_act);
+                  b_s1[e] += dz;
+                  b_s2[e] = fmaf(dz, (yv[e] - b_mu[e]) * b_iv[e], b_s2[e]);
+                  bn_mx = fmaxf(bn_mx, fabsf(dz));
+                }
+              }
+            }
+          }
+          }
+        } else {
         long long offs[ITER];
         f32x4 vv[ITER];
 #pragma unroll
@@ -214,7 +300,24 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
             if (a.nt_store) __builtin_nontemporal_store(v, p); else *p = v;
           }
         }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the strip is read before the next pass rewrites it
+      }
+    }
+    if (bnred) {   // lanes l, l + C4, l + 2 C4, ... hold the same four columns: fixed-order butterfly, then one row of sred
+#pragma unroll
+      for (int o = C4; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          b_s1[e] += __shfl_xor(b_s1[e], o, 64);
+          b_s2[e] += __shfl_xor(b_s2[e], o, 64);
+        }
+      if (lane < C4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sred[(wm * BN + wn * WCOLS + lane * 4 + e) * 3 + 0] = b_s1[e];
+          sred[(wm * BN + wn * WCOLS + lane * 4 + e) * 3 + 1] = b_s2[e];
+        }
       }
     }
     stampf(2);
@@ -233,6 +336,8 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
         const float bv = (a.bias != nullptr && cok) ? a.bias[col] : 0.f;
         const float esc = (a.epi_scale != nullptr && cok) ? a.epi_scale[col] : 1.f;
         const float esh = (a.epi_scale != nullptr && cok) ? a.epi_shift[col] : 0.f;
+        const float rsc = (bnred && cok) ? a.bwd_scale[col] : 0.f, rsh = (bnred && cok) ? a.bwd_shift[col] : 0.f;
+        const float rmu = (bnred && cok) ? a.bwd_mean[col] : 0.f, riv = (bnred && cok) ? a.bwd_invstd[col] : 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           const bool ok = cok && offs[q] >= 0;
@@ -243,7 +348,14 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
             if (a.epi_res != nullptr) v += a.epi_res[offs[q] + col];
             if (a.accumulate) v += a.dst[offs[q] + col];
             if constexpr ((DBG & 16) != 0) { if (v == 1234.5678f) a.dst[offs[q] + col] = v; }
-            else if (a.nt_store) __builtin_nontemporal_store(v, &a.dst[offs[q] + col]); else a.dst[offs[q] + col] = v;
+            else if (a.nt_store && !bnred) __builtin_nontemporal_store(v, &a.dst[offs[q] + col]); else a.dst[offs[q] + col] = v;
+            if (bnred) {
+              const float yv = a.bwd_y[offs[q] + col];
+              const float dz = v * act_grad(fmaf(rsc, yv, rsh), a.bwd_act);
+              bs1[j] += dz;
+              bs2[j] = fmaf(dz, (yv - rmu) * riv, bs2[j]);
+              bn_mx = fmaxf(bn_mx, fabsf(dz));
+            }
           }
           const float vm = ok ? (a.epi_scale != nullptr ? vstat : v) : 0.f;
           csum[j] += vm;
@@ -251,6 +363,41 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
           cmx[j] = fmaxf(cmx[j], fabsf(vm));
         }
       }
+    }
+  }
+  if (bnred) {
+    if (!vec) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const float s1 = bs1[j] + __shfl_xor(bs1[j], 32, 64);
+        const float s2 = bs2[j] + __shfl_xor(bs2[j], 32, 64);
+        if (lane < 32) {
+          const int c = (wn * TN + j) * 32 + lane;
+          sred[(wm * BN + c) * 3 + 0] = s1;
+          sred[(wm * BN + c) * 3 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    const long long slot = G.slot1 > 0 ? G.slot1 - 1 : tile_m;
+    for (int c = tid; c < BN; c += NT) {
+      const int col = n0 + c;
+      if (col < a.Cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WGM; ++w) {   // fixed order
+          s1 += sred[(w * BN + c) * 3 + 0];
+          s2 += sred[(w * BN + c) * 3 + 1];
+        }
+        a.bwd_part[(slot * 2 + 0) * a.Cout + col] = s1;
+        a.bwd_part[(slot * 2 + 1) * a.Cout + col] = s2;
+      }
+    }
+    if (a.bwd_aux != nullptr) {   // max |dz| (bit patterns of non-negative floats order like integers): 64 replica words
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bn_mx = fmaxf(bn_mx, __shfl_xor(bn_mx, o, 64));
+      unsigned* w = &a.bwd_aux[4 + ((int)(slot + n0 / BN) & 63)];
+      if (lane == 0 && __builtin_bit_cast(unsigned, bn_mx) > *w) atomicMax(w, __builtin_bit_cast(unsigned, bn_mx));
     }
   }
   if (a.stats != nullptr || a.absmax != nullptr) {

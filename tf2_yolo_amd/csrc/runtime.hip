@@ -75,7 +75,7 @@ extern "C" int yolo_set_debug_buffer(void* p, size_t bytes) {
 
 extern "C" const char* yolo_last_error(void) { return yolo::g_err; }
 
-extern "C" int yolo_abi_version(void) { return 3; }   // 3: round 4 added yolo_bn_act_bwd_reduce_bound_ld / _apply_planes_ld (dout with a row pitch), option key 6; 2: round 3 added yolo_cal_iou, yolo_nms_select, yolo_adam_step_dev, yolo_bn_finalize_offset, the wgrad workspace, yolo_mfma_probe
+extern "C" int yolo_abi_version(void) { return 4; }   // 4: round 5 added yolo_conv2d_dgrad_planes_bnred, yolo_bn_act_bwd_sum_partials, yolo_bnred_slots_cap; 3: round 4 added yolo_bn_act_bwd_reduce_bound_ld / _apply_planes_ld (dout with a row pitch), option key 6; 2: round 3 added yolo_cal_iou, yolo_nms_select, yolo_adam_step_dev, yolo_bn_finalize_offset, the wgrad workspace, yolo_mfma_probe
 
 extern "C" int yolo_device_available(void) {
   int n = 0;

@@ -64,7 +64,7 @@ class GradReducer:
         self.on_gpu = flat_grads.is_cuda
         if self.on_gpu:   # a stream that demonstrably runs beside the compute stream and the filter-gradient stream (ops.concurrent_stream)
             from . import ops
-            self.comm_stream = ops.concurrent_stream("comm", [torch.cuda.current_stream(), ops.concurrent_stream("wgrad")])
+            self.comm_stream = ops.concurrent_stream("comm", device=flat_grads.device)
         else:
             self.comm_stream = None
         self._works = []
@@ -120,9 +120,17 @@ class GradReducer:
                 if self.tracing and self._t0 is not None:
                     ready = torch.cuda.Event(enable_timing=True)
                     ready.record(self.comm_stream)
+                work = None
                 if not self._dry:
-                    self._works.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+                    work = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                    self._works.append(work)
                 if self.tracing and self._t0 is not None:
+                    # The collective does NOT run on this stream: RCCL runs it on the process group's own stream, gloo on
+                    # host threads. `done` is therefore recorded behind work.wait() -- for RCCL a stream-level wait (the
+                    # communication stream waits for the collective's stream, the host does not block), for gloo a host wait
+                    # (traced steps only). Round 4 recorded `done` right behind the async call and measured nothing.
+                    if work is not None:
+                        work.wait()
                     done = torch.cuda.Event(enable_timing=True)
                     done.record(self.comm_stream)
                     self._trace.append(((lo, hi), ready, done))

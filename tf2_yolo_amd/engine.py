@@ -330,7 +330,7 @@ class Network:
         self.grad_ready_hook = None   # called as hook(unit) after a unit's parameter grads are enqueued
         self.backward_begin_hook = None   # called at the start of backward (the gradient reducer's time origin)
         self._infer_scale_valid = False
-        ops.create_side_streams()     # the process's filter-gradient / communication streams (one per role, fixed creation order)
+        ops.create_side_streams(self.device)   # this device's filter-gradient / communication streams (fixed creation order)
         ops.ensure_conv_workspace()   # scratch of the persistent (stream-K) window kernel: small-batch launches
         ops.ensure_wgrad_workspace()  # slabs of the atomics-free filter / bias gradient reductions
         # consumers per tensor decide whether a tensor needs a gradient at all
@@ -344,6 +344,16 @@ class Network:
         # the gradient of a Concatenate reaches the BatchNormalization backward of its sources as a channel SLICE of the
         # concat's gradient (ops.ChannelSlice: read in place with its row pitch) instead of being copied out per source
         self._concat_grad_slices = os.environ.get("YOLO_CONCAT_GRAD_SLICE", "1") != "0"
+        # The BatchNormalization-backward reduction of a conv + BN unit P (sums of dz and dz * xhat over dL/d(P.out)) is made
+        # by the data gradient that COMPLETES dL/d(P.out) -- the last contribution in backward order, when that is a planes
+        # data gradient (include/yolo_hip.h: yolo_conv2d_dgrad_planes_bnred): W.bnred_for = P on that writer W.
+        # YOLO_BN_FUSED_REDUCE: 0 never, 1 every planes data gradient that completes a tensor, or a set of writer classes
+        # "w" (3x3 stride-1 with enough tiles to run unsplit), "s" (stride 2), "p" (1x1), "h" (heads), "t" (the small
+        # 3x3 layers that lose their split-K), e.g. "ws"
+        # Default 0: measured (profiles/r05_a_*): the step does not get shorter with it -- the y tile costs the data gradient as
+        # much as the standalone pass cost beside the filter-gradient stream.
+        self._bn_fused_reduce = os.environ.get("YOLO_BN_FUSED_REDUCE", "0")
+        self._plan_fused_reduce()
         # pre-split ("planes") copies of the filters for the LDS-DMA conv kernels: [Cout][taps*Cin] for
         # forward, [Cin][taps*Cout] for dgrad; refreshed when the parameters change
         wp = 0
@@ -478,6 +488,48 @@ class Network:
         self._bn_f32_total = f32
         self._bn_f64_total = f64
 
+    def _plan_fused_reduce(self):
+        """static walk of backward(): who contributes to dL/d(tensor), in which order. The last contributor of a tensor
+        produced by a conv + BatchNormalization unit P gets W.bnred_for = P if it is a conv / head unit (whether its data
+        gradient is a planes kernel is known later: _dgrad checks). A skipped writer (its own gradient never arrives) simply
+        never sets the flag P's backward looks for, and P makes the reduction itself."""
+        last = {}
+        for u in reversed(self.units):
+            u.bnred_for = None
+            if u.kind == "conv":
+                if u.bn and u.residual is not None and self._needs_grad[u.residual.tid]:
+                    last[u.residual.tid] = ("add", u)
+                if self._needs_grad[u.src.tid]:
+                    last[u.src.tid] = ("dgrad", u)
+            elif u.kind == "head":
+                if self._needs_grad[u.src.tid]:
+                    last[u.src.tid] = ("dgrad", u)
+            else:
+                for t in u.inputs:
+                    if self._needs_grad[t.tid]:
+                        last[t.tid] = ("other", u)
+        mode = self._bn_fused_reduce
+        if mode == "0":
+            return
+        for tid, (how, w) in last.items():
+            p = self.tensors[tid].producer
+            # (stride 2: the four parity classes of the data gradient must be ONE launch, csrc/conv.hip: dgrad_impl)
+            k, st = (w.k, w.stride) if w.kind == "conv" else (1, 1)
+            one_launch = st == 1 or (st == 2 and k == 3 and os.environ.get("YOLO_DGRAD_CLASSES", "1") != "0")
+            if not (how == "dgrad" and one_launch and p is not None and p.kind == "conv" and p.bn and p.cout % 4 == 0):
+                continue
+            if w.kind == "head":
+                cls = "h"
+            elif st == 2:
+                cls = "s"
+            elif k == 1:
+                cls = "p"
+            else:
+                cls = "w"
+            w.bnred_class = cls
+            if mode == "1" or cls in mode or (cls == "w" and "t" in mode):
+                w.bnred_for = p
+
     def _compute_needs_grad(self):
         needs = {self.input.tid: False}
         for u in self.units:
@@ -536,6 +588,27 @@ class Network:
             else:
                 u.buf = torch.empty((N, oh, ow, oc), device=dev, dtype=torch.float32)
                 self.act[u.out.tid] = u.buf
+        # slots of the BatchNormalization-backward reductions made by data gradients (_plan_fused_reduce)
+        for u in self.units:
+            u.bnred = None
+        for w in self.units:
+            p = getattr(w, "bnred_for", None)
+            if p is None or not (w.planes_dgrad or (w.kind == "head" and w.cpad)):
+                continue
+            scale, shift, smean, sinv, _, _ = self._bn_bufs(p)
+            if getattr(w, "bnred_class", "") == "w" and self._bn_fused_reduce != "1":
+                # 3x3 stride-1 launches of at most 256 tiles run split-K (csrc/conv_win.hip: conv_split_parts), which the
+                # fused form gives up: their own class "t"
+                small = -(-N * w.src.h * w.src.w // 128) * -(-w.src.c // 128) <= 256
+                if not (("t" if small else "w") in self._bn_fused_reduce):
+                    continue
+            cap = ops.bnred_slots_cap(w.desc)   # (a head with padded channels uses desc_pad: same pixels, same Cin)
+            if cap <= 0:
+                continue
+            p.bnred = ops.BnReduce(p.y, scale, shift, smean, sinv, p.act,
+                                   torch.empty(cap * 2 * p.cout, device=dev, dtype=torch.float32), cap,
+                                   self._aux[p.aux_off + 1:p.aux_off + 69])
+            p.bnred_done = False
         # planes of the activations that feed planes-capable convs (kept from forward for the filter
         # gradient), one scratch for the planes of the current layer's dy in backward
         self._xplanes = {}
@@ -705,7 +778,7 @@ class Network:
             # the filters' planes (needed by the first planes conv) and their transposed forms (needed by backward) are
             # made on the second stream while the stem runs: 0.45 ms of HBM-bound launches beside MFMA-bound ones
             if self._wgrad_stream is None:
-                self._wgrad_stream = ops.concurrent_stream("wgrad")
+                self._wgrad_stream = ops.concurrent_stream("wgrad", device=self.device)
             side = self._wgrad_stream
             tape.wait_stream(side, torch.cuda.current_stream())
             with torch.cuda.stream(side):
@@ -727,6 +800,7 @@ class Network:
         prev_name = None
         for u in self.units:
             if stop_after is not None and prev_name == stop_after:
+                self.training = False   # an incomplete pass: backward() must not run on it
                 return None
             prev_name = getattr(u, "name", None)
             if self._wp_event is not None and u.kind in ("conv", "head") and u.planes_fwd:
@@ -950,6 +1024,9 @@ class Network:
             self._wT_event = None
         self._refresh_wT()
         self._refresh_wTplanes()
+        for u in self.units:
+            if getattr(u, "bnred", None) is not None:
+                u.bnred_done = False
         grads = {}
         for t, g in zip(self.outputs, douts):
             grads[t.tid] = g
@@ -976,7 +1053,8 @@ class Network:
                             and ops.stem_bn_bwd_supported(u.desc)):
                         # the stem: BN / activation backward apply + filter gradient in one pass, no 32-channel dy tensor
                         ops.stem_bn_bwd_wgrad(u.desc, xin, u.y, dout, scale, shift, smean, sinv, u.act, red,
-                                              self._gview(u.p_gamma), self._gview(u.p_beta), self._gview(u.p_kernel))
+                                              self._gview(u.p_gamma), self._gview(u.p_beta), self._gview(u.p_kernel),
+                                              fused=self._take_fused(u, dout))
                         if self.grad_ready_hook is not None:
                             tape.host_call(lambda u=u: self.grad_ready_hook(u))
                         continue
@@ -984,7 +1062,7 @@ class Network:
                     dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
                                         sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta),
                                         planes=dyp, want_dx=need_f32,
-                                        bound_aux=self._aux[u.aux_off + 1:u.aux_off + 69])
+                                        bound_aux=self._aux[u.aux_off + 1:u.aux_off + 69], fused=self._take_fused(u, dout))
                 else:
                     dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
                     dyp = self._dyp(u, dy)
@@ -1011,10 +1089,11 @@ class Network:
                     if self._needs_grad[u.src.tid]:
                         wTp = self._wplanes[u.wTp_pad_off:u.wTp_pad_off + u.wTp_pad_bytes]
                         cur = grads.get(u.src.tid)
+                        b = self._bnred_of(u, cur)
                         if cur is None:
-                            grads[u.src.tid] = ops.conv2d_dgrad_planes(u.desc_pad, dtp, wTp)
+                            grads[u.src.tid] = ops.conv2d_dgrad_planes(u.desc_pad, dtp, wTp, bnred=b)
                         else:
-                            ops.conv2d_dgrad_planes(u.desc_pad, dtp, wTp, dx=cur, accumulate=True)
+                            ops.conv2d_dgrad_planes(u.desc_pad, dtp, wTp, dx=cur, accumulate=True, bnred=b)
                     if self.grad_ready_hook is not None:
                         tape.host_call(lambda u=u: self.grad_ready_hook(u))
                     continue
@@ -1099,7 +1178,7 @@ class Network:
             yield
             return
         if self._wgrad_stream is None:
-            self._wgrad_stream = ops.concurrent_stream("wgrad")
+            self._wgrad_stream = ops.concurrent_stream("wgrad", device=self.device)
         side = self._wgrad_stream
         tape.wait_stream(side, torch.cuda.current_stream())
         for t in tensors:
@@ -1123,16 +1202,36 @@ class Network:
         cout = u.cout if u.kind == "conv" else u.out.c
         return ops.split_planes(dy, self.batch * u.out.h * u.out.w, cout, out=self._next_dyp_buffer())
 
+    def _bnred_of(self, w, cur):
+        """the fused reduction this writer's data gradient makes (None: none). cur = the gradient it adds into, if any: a
+        ChannelSlice or a tensor that is not dense NHWC of the source never takes the fused form"""
+        p = w.bnred_for
+        if p is None or p.bnred is None or (cur is not None and not torch.is_tensor(cur)):
+            return None
+        p.bnred_done = True
+        return p.bnred
+
+    def _take_fused(self, u, dout):
+        """the BnReduce that already holds the reduction of `dout` for unit u's BatchNormalization backward, or None"""
+        b = getattr(u, "bnred", None)
+        if b is None or not u.bnred_done:
+            return None
+        u.bnred_done = False
+        if not torch.is_tensor(dout):
+            raise YoloHipError(f"{u.name}: fused reduction made for a gradient that arrives as a channel slice")
+        return b
+
     def _dgrad(self, grads, u, dy, wsize, dyp=None):
         if not self._needs_grad[u.src.tid]:
             return
         cur = grads.get(u.src.tid)
         if u.planes_dgrad:
             wTp = self._wplanes[u.wTp_off:u.wTp_off + u.wTp_bytes]
+            b = self._bnred_of(u, cur)
             if cur is None:
-                grads[u.src.tid] = ops.conv2d_dgrad_planes(u.desc, dyp, wTp)
+                grads[u.src.tid] = ops.conv2d_dgrad_planes(u.desc, dyp, wTp, bnred=b)
             else:
-                ops.conv2d_dgrad_planes(u.desc, dyp, wTp, dx=cur, accumulate=True)
+                ops.conv2d_dgrad_planes(u.desc, dyp, wTp, dx=cur, accumulate=True, bnred=b)
             return
         wT = self._wT[u.wT_off:u.wT_off + wsize]
         if cur is None:

@@ -86,10 +86,12 @@ WGRAD_WIN = int(_os.environ.get("YOLO_WGRAD_WIN", "1"))
 
 
 def _wgrad_win_covers(d):
-    """mirrors wgrad_win_supported() in csrc/conv_wgrad_win.hip: 3x3 stride-1 'same', 128-filter x 32-channel tiles"""
+    """mirrors wgrad_win_supported() in csrc/conv_wgrad_win.hip: 3x3 stride-1 'same', 128-filter x 32-channel tiles,
+    at least 64 and fewer than 2^31 - 4096 pixels (WGRAD_WIN follows set_option / reset_options)"""
+    m = d.N * d.Ho * d.Wo
     return (WGRAD_WIN != 0 and d.kh == 3 and d.kw == 3 and d.sh == 1 and d.sw == 1 and d.pad_t == 1 and d.pad_l == 1
             and d.H == d.Ho and d.W == d.Wo and d.Cout % 128 == 0 and d.Cin % 32 == 0 and d.W >= 4
-            and 2 * d.W + 81 <= 512 and 32 // d.W + 2 <= d.H and d.N * d.Ho * d.Wo >= 64)
+            and 2 * d.W + 81 <= 512 and 32 // d.W + 2 <= d.H and 64 <= m < (1 << 31) - 4096)
 
 
 def _wgrad_planes_variant(cout, cols, taps=1, pixels=1 << 40, d=None):
@@ -232,32 +234,46 @@ def _overlaps(a, b, cycles=6000000):   # ~3 ms per spin kernel: far above the ~5
     return e0.elapsed_time(e2) < 1.5 * one
 
 
-def create_side_streams():
-    """the process's filter-gradient and communication streams, in that order (idempotent)"""
+def create_side_streams(device=None):
+    """the filter-gradient and communication streams of `device` (default: the current device), in that order (idempotent;
+    one pair per device of the process, created on that device explicitly)"""
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if dev is None:
+        dev = torch.cuda.current_device()
     for role in ("wgrad", "comm"):
-        if role not in _SIDE_STREAMS:
-            st = torch.cuda.Stream()
-            if _os.environ.get("YOLO_STREAM_PROBE") == "1" and not _overlaps(torch.cuda.current_stream(), st):
+        if (dev, role) not in _SIDE_STREAMS:
+            st = torch.cuda.Stream(device=dev)
+            if (_os.environ.get("YOLO_STREAM_PROBE") == "1" and dev == torch.cuda.current_device()
+                    and not _overlaps(torch.cuda.current_stream(), st)):
                 import warnings
                 warnings.warn(f"tf2_yolo_amd: the {role} stream shares a hardware queue with the compute stream: the step "
                               "will run them one after the other (create_side_streams() earlier, or raise GPU_MAX_HW_QUEUES)")
-            _SIDE_STREAMS[role] = st
-    return _SIDE_STREAMS
+            _SIDE_STREAMS[(dev, role)] = st
+    return {role: _SIDE_STREAMS[(dev, role)] for role in ("wgrad", "comm")}
 
 
-def concurrent_stream(role, beside=None):
-    """the process-wide side stream of `role` ('wgrad', 'comm')"""
-    return create_side_streams()[role]
+def concurrent_stream(role, beside=None, device=None):
+    """the side stream of `role` ('wgrad', 'comm') on `device` (default: the current device)"""
+    st = create_side_streams(device)[role]
+    want = torch.cuda.current_device() if device is None else torch.device(device).index
+    if want is not None and st.device.index != want:
+        raise YoloHipError(f"side stream of role {role!r} lives on cuda:{st.device.index}, not on cuda:{want}")
+    return st
 
 
 def set_option(key, value):
     """yolo_set_option: run-time kernel-variant switches of the library (benchmarks, tests)"""
+    global WGRAD_WIN
     check(_lib.load().yolo_set_option(int(key), int(value)), "yolo_set_option")
+    if int(key) == OPT_WGRAD_WIN:     # (the kernel names the timer / roofline report use follow the option)
+        WGRAD_WIN = int(value)
 
 
 def reset_options():
     """every option back to its default (the YOLO_* environment variables)"""
+    global WGRAD_WIN
     check(_lib.load().yolo_set_option(-1, 0), "yolo_set_option")
+    WGRAD_WIN = int(_os.environ.get("YOLO_WGRAD_WIN", "1"))
 
 
 def _stream():
@@ -552,16 +568,46 @@ def split_planes_concat(srcs, channels, bounds, rows, planes, dst32=None, out_bo
     return planes
 
 
-def conv2d_dgrad_planes(d, dyp, wTp, dx=None, accumulate=False):
+class BnReduce:
+    """What yolo_conv2d_dgrad_planes_bnred needs to fold the BatchNormalization-backward reduction of the tensor it
+    completes into its epilogue (include/yolo_hip.h): the pre-BN tensor y of the unit that PRODUCED the tensor, that unit's
+    scale / shift / saved mean / saved 1/std and activation, a partials buffer ([cap][2][C] floats) and the 68 bound words.
+    nslots is filled in by the launch."""
+    __slots__ = ("y", "scale", "shift", "mean", "invstd", "act", "partials", "cap", "aux", "nslots")
+
+    def __init__(self, y, scale, shift, mean, invstd, act, partials, cap, aux):
+        self.y, self.scale, self.shift, self.mean, self.invstd, self.act = y, scale, shift, mean, invstd, act
+        self.partials, self.cap, self.aux, self.nslots = partials, cap, aux, 0
+
+
+def bnred_slots_cap(d):
+    return int(_lib.load().yolo_bnred_slots_cap(byref(d)))
+
+
+def conv2d_dgrad_planes(d, dyp, wTp, dx=None, accumulate=False, bnred=None):
     if dx is None:
         dx = torch.empty((d.N, d.H, d.W, d.Cin), device=dyp.device, dtype=torch.float32)
         accumulate = False
     if (dyp.numel() < planes_bytes(d.N * d.Ho * d.Wo, d.Cout) or wTp.numel() < planes_bytes(d.Cin, d.kh * d.kw * d.Cout)
             or dx.numel() != d.N * d.H * d.W * d.Cin):
         raise YoloHipError("conv2d_dgrad_planes: buffers do not match the descriptor")
+    if bnred is not None:
+        b = bnred
+        _chk_f32(b.y, b.scale, b.shift, b.mean, b.invstd, b.partials)
+        if (b.y.numel() != dx.numel() or min(t.numel() for t in (b.scale, b.shift, b.mean, b.invstd)) < d.Cin
+                or b.partials.numel() < b.cap * 2 * d.Cin or b.aux is None or b.aux.numel() < 68):
+            raise YoloHipError("conv2d_dgrad_planes: the fused reduction's buffers do not match the descriptor")
     def run():
-        check(_lib.load().yolo_conv2d_dgrad_planes(byref(d), _p(dyp), _p(wTp), _p(dx), int(bool(accumulate)), _stream()),
-              "yolo_conv2d_dgrad_planes")
+        if bnred is None:
+            check(_lib.load().yolo_conv2d_dgrad_planes(byref(d), _p(dyp), _p(wTp), _p(dx), int(bool(accumulate)), _stream()),
+                  "yolo_conv2d_dgrad_planes")
+            return
+        n = ctypes.c_int(0)
+        check(_lib.load().yolo_conv2d_dgrad_planes_bnred(byref(d), _p(dyp), _p(wTp), _p(dx), int(bool(accumulate)), _p(b.y),
+                                                         _p(b.scale), _p(b.shift), _p(b.mean), _p(b.invstd), int(b.act),
+                                                         _p(b.partials), int(b.cap), _p(b.aux), byref(n), _stream()),
+              "yolo_conv2d_dgrad_planes_bnred")
+        b.nslots = n.value
     if TIMER is not None:
         TIMER.bracket(_planes_variant(d.Cin, _win_key(d, d.Ho, d.Wo, d.Cout), d.kh * d.kw == 1 and d.sh * d.sw == 1), _conv_flops(d), 1, run,
                       _layer_key(d, "dgrad"))
@@ -712,6 +758,10 @@ class ChannelSlice:
     __slots__ = ("base", "ld", "c_off", "C")
 
     def __init__(self, base, ld, c_off, C):
+        _chk_f32(base)     # (contiguous: a reshape in view() would otherwise silently copy, and the row pitch would be wrong)
+        if base.shape[-1] != ld or c_off < 0 or C <= 0 or c_off + C > ld:
+            raise YoloHipError(f"ChannelSlice: channels [{c_off}, {c_off + C}) of a tensor whose last dimension is "
+                               f"{base.shape[-1]} (row pitch given: {ld})")
         self.base, self.ld, self.c_off, self.C = base, ld, c_off, C
 
     def view(self):
@@ -725,10 +775,11 @@ class ChannelSlice:
 
 
 def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dx=None,
-               planes=None, want_dx=True, bound_aux=None):
+               planes=None, want_dx=True, bound_aux=None, fused=None):
     """returns dx (None when want_dx is False and only the planes of dx are produced). planes needs bound_aux:
     int32 CUDA tensor of 68 zeroed words (filled by the reduce step, read by the apply step). dout may be a ChannelSlice
-    (C % 8 == 0): the two passes then read it in place with its row pitch."""
+    (C % 8 == 0): the two passes then read it in place with its row pitch. fused = the BnReduce whose data gradient already
+    made the reduction of THIS dout (conv2d_dgrad_planes(bnred=...)): its slots are folded instead of a pass over x and dout."""
     ld = C
     if isinstance(dout, ChannelSlice):
         if dout.C != C or C % 8 != 0 or dout.c_off % 4 != 0 or dout.ld % 4 != 0:
@@ -744,8 +795,14 @@ def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red
     if dx is None and want_dx:
         dx = torch.empty_like(x)
     lib = _lib.load()
-    check(lib.yolo_bn_act_bwd_reduce_bound_ld(_p(x), _p(dout), ld, P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
-                                              act, _p(red), _p(bound_aux), _stream()), "yolo_bn_act_bwd_reduce")
+    if fused is not None:
+        if fused.nslots <= 0 or fused.aux is None or bound_aux is None or fused.aux.data_ptr() != bound_aux.data_ptr():
+            raise YoloHipError("bn_act_bwd: the fused reduction did not run for this tensor")
+        check(lib.yolo_bn_act_bwd_sum_partials(_p(fused.partials), int(fused.nslots), P, C, _p(scale), _p(red), _p(bound_aux),
+                                               _stream()), "yolo_bn_act_bwd_sum_partials")
+    else:
+        check(lib.yolo_bn_act_bwd_reduce_bound_ld(_p(x), _p(dout), ld, P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
+                                                  act, _p(red), _p(bound_aux), _stream()), "yolo_bn_act_bwd_reduce")
     check(lib.yolo_bn_act_bwd_apply_planes_ld(_p(x), _p(dout), ld, P, C, _p(gamma), _p(scale), _p(shift), _p(save_mean),
                                               _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta),
                                               _p(dx if want_dx else None), _p(planes), _p(bound_aux), _stream()),
@@ -762,9 +819,10 @@ def stem_bn_bwd_supported(d):
             and d.Wo == d.W and d.W >= 16)
 
 
-def stem_bn_bwd_wgrad(d, image, y, dout, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dw):
-    """backward of the stem unit in one pass over (y, dout): yolo_bn_act_bwd_reduce, then the apply step fused with the
-    filter gradient (yolo_stem_bn_bwd_wgrad); dw / dgamma / dbeta are accumulated"""
+def stem_bn_bwd_wgrad(d, image, y, dout, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dw, fused=None):
+    """backward of the stem unit in one pass over (y, dout): yolo_bn_act_bwd_reduce (or, fused = the BnReduce of the data
+    gradient that completed dout, the fold of its slots), then the apply step fused with the filter gradient
+    (yolo_stem_bn_bwd_wgrad); dw / dgamma / dbeta are accumulated"""
     global _STEM_SCRATCH
     _chk_f32(image, y, dout, scale, shift, save_mean, save_invstd, dgamma, dbeta, dw)
     lib = _lib.load()
@@ -773,8 +831,14 @@ def stem_bn_bwd_wgrad(d, image, y, dout, scale, shift, save_mean, save_invstd, a
         raise YoloHipError("stem_bn_bwd_wgrad: tensor sizes do not match the descriptor")
     if _STEM_SCRATCH is None or _STEM_SCRATCH.device != y.device:
         _STEM_SCRATCH = torch.empty(int(lib.yolo_stem_bwd_scratch_bytes()), dtype=torch.uint8, device=y.device)
-    check(lib.yolo_bn_act_bwd_reduce_bound(_p(y), _p(dout), P, 32, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
-                                           act, _p(red), _p(None), _stream()), "yolo_bn_act_bwd_reduce")
+    if fused is not None:
+        if fused.nslots <= 0:
+            raise YoloHipError("stem_bn_bwd_wgrad: the fused reduction did not run for this tensor")
+        check(lib.yolo_bn_act_bwd_sum_partials(_p(fused.partials), int(fused.nslots), P, 32, _p(scale), _p(red), _p(fused.aux),
+                                               _stream()), "yolo_bn_act_bwd_sum_partials")
+    else:
+        check(lib.yolo_bn_act_bwd_reduce_bound(_p(y), _p(dout), P, 32, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
+                                               act, _p(red), _p(None), _stream()), "yolo_bn_act_bwd_reduce")
     def run():
         check(lib.yolo_stem_bn_bwd_wgrad(byref(d), _p(y), _p(dout), _p(image), _p(scale), _p(shift), _p(save_mean),
                                          _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta), _p(dw), _p(_STEM_SCRATCH),
