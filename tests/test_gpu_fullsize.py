@@ -106,10 +106,12 @@ def test_headline_configs_at_their_true_batch_vs_fp64_oracle(config):
     """BASELINE.json's headline configurations at their TRUE per-GPU batch against the float64 oracle:
     C3 = YOLOv3 416x416 bs 32, C4 = YOLOv4 608x608 bs 16 -- training-mode forward (BatchNorm statistics over
     32 x 416 x 416 = 5.5 M pixels per channel through the 64-slot fp64 atomics), the head outputs and the three
-    losses; the oracle runs under torch.no_grad() without retaining activations. Tolerance as the bs-2 end-to-end
-    case (tests/test_gpu_model.py): 1e-4, or 3x the error of the float32 CPU execution of the same oracle."""
+    losses; the oracle runs under torch.no_grad() without retaining activations (in a worker process beside the rest of the
+    suite: conftest.py). Tolerance as the bs-2 end-to-end case (tests/test_gpu_model.py): 1e-4, or 1.5x the error of the
+    float32 CPU execution of the same oracle (measured worst ratio 1.16: profiles/r05_parity_ratios.jsonl)."""
+    import conftest
+    import oracle_jobs
     import test_gpu_model as T
-    from oracle import models as OM
     version, hw, N = (3, 416, 32) if config == "C3" else (4, 608, 16)
     y, model, fwd, loss_o, loss_g, x, ys = T._setup(version, hw=hw, N=N)
     net = model.net
@@ -117,23 +119,30 @@ def test_headline_configs_at_their_true_batch_vs_fp64_oracle(config):
     outs = net.forward(torch.tensor(x).cuda(), training=True)
     dev_losses = [float(lf(torch.tensor(yt).cuda(), o).item()) for lf, o, yt in zip(loss_g, outs, ys)]
     dev = [o.cpu().numpy() for o in outs]
-    OM.KEEP_ACTS = False
-    try:
-        with torch.no_grad():
-            ref, ctx = fwd({k: torch.tensor(v, dtype=torch.float64) for k, v in w.items()},
-                           torch.tensor(x, dtype=torch.float64), True)
-            ref_losses = [float(lf(torch.tensor(yt, dtype=torch.float64), o)) for lf, yt, o in zip(loss_o, ys, ref)]
-            o32, _ = fwd({k: torch.tensor(v) for k, v in w.items()}, torch.tensor(x), True)
-            l32 = [float(lf(torch.tensor(yt), o)) for lf, yt, o in zip(loss_o, ys, o32)]
-    finally:
-        OM.KEEP_ACTS = True
+    # the oracle passes: started in a worker process when the session began (conftest.py), on the same inputs (digest);
+    # run here if this test was selected on its own
+    job = conftest.HEADLINE_JOBS.get(config)
+    if job is not None and job[1] == T.inputs_digest(w, x, ys):
+        res = job[0].result(timeout=1500)
+    else:
+        res = oracle_jobs.headline_job(version, hw // 32, T.A9, w, x, ys, torch.get_num_threads())
+    print(config, "oracle passes (float64, float32) took", res["seconds"], "s on", res["threads"], "threads",
+          "(background worker)" if job is not None else "(in this process)")
+    ref, o32 = [torch.from_numpy(a) for a in res["ref"]], [torch.from_numpy(a) for a in res["o32"]]
+    ref_losses, l32 = res["ref_losses"], res["l32"]
+
+    class _Moving:
+        moving = {k: (torch.from_numpy(a), torch.from_numpy(b)) for k, (a, b) in res["moving"].items()}
+    ctx = _Moving
     floor = max(T._rel(b32.numpy(), b.numpy()) for b, b32 in zip(ref, o32))
     errs = [T._rel(a, b.numpy()) for a, b in zip(dev, ref)]
     print(config, "forward errors", errs, "fp32-CPU floor", floor, "losses", dev_losses, ref_losses)
+    T.log_parity_ratio({"case": f"{config} true batch (bs {N})", "forward_err": max(errs), "fp32_floor": floor,
+                        "forward_ratio": max(errs) / max(floor, 1e-30)})
     for e in errs:
-        assert e < max(1e-4, 3 * floor), (errs, floor)
+        assert e < max(1e-4, 1.5 * floor), (errs, floor)
     for dl, rl, c32 in zip(dev_losses, ref_losses, l32):
-        tol = max(1e-4, 3 * abs(c32 - rl) / max(abs(rl), 1.0))
+        tol = max(1e-4, 1.5 * abs(c32 - rl) / max(abs(rl), 1.0))
         assert abs(dl - rl) < tol * max(abs(rl), 1.0), (dl, rl, c32)
     # moving statistics after the training forward (Keras update, momentum 0.99)
     worst = 0.0

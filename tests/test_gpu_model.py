@@ -1,9 +1,9 @@
 """End-to-end parity of the four model graphs on the GPU against the torch-CPU float64 restatement
 (oracle/models.py + oracle/losses.py): inference forward, training forward (batch statistics,
 moving-stat update), loss, every parameter gradient, and one Adam step.
-Tolerances: forward / loss 1e-4 (north_star; or the floor an fp32 CPU run of the oracle itself reaches on
-these tiny-batch problems). Gradients: per tensor, max(1e-3, 4 x that fp32 floor) relative to the tensor's
-largest entry (measured: v3 4e-4, v2 1e-4, v1.5 2e-4), against the float64 oracle evaluated with the device's LeakyReLU branch pattern (oracle/layers.py
+Tolerances: forward / loss 1e-4 (north_star), or 1.5x the error an fp32 CPU run of the oracle itself has on the same
+instance. Gradients: per tensor, max(2 x the fp32 CPU run's error on that tensor, 4e-4) relative to the tensor's
+largest entry, against the float64 oracle evaluated with the device's LeakyReLU branch pattern (oracle/layers.py
 leaky_masked): two executions of a ReLU network legitimately disagree on the sign of pre-activations
 that are within rounding of zero, and one such flip moves whole gradient tensors by 1e-2; the test
 asserts that the patterns differ only where |z| < 1e-4 and then compares like with like."""
@@ -61,6 +61,37 @@ def _perturb(model, rng):
         st[sl] = (0.1 * rng.standard_normal(s.size)) if name.endswith("moving_mean") else (0.5 + rng.random(s.size))
     net.state.data.copy_(torch.from_numpy(st))
     net.mark_params_changed()
+
+
+def inputs_digest(w, x, ys):
+    """a short digest of an end-to-end case's inputs (weights, images, labels): the background oracle job of the headline
+    tests (conftest.py) must have been given exactly what the test's own _setup produces"""
+    import hashlib
+    h = hashlib.sha1()
+    for k in sorted(w):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(w[k]).tobytes()[:4096])
+        h.update(np.float64(np.asarray(w[k], dtype=np.float64).sum()).tobytes())
+    h.update(np.ascontiguousarray(x).tobytes()[:65536])
+    for a in ys:
+        h.update(np.float64(np.asarray(a, dtype=np.float64).sum()).tobytes())
+    return h.hexdigest()
+
+
+def log_parity_ratio(rec):
+    """one line per end-to-end case: device error over the error of an fp32 CPU execution of the same oracle on the same
+    inputs (forward outputs; worst parameter-gradient tensor) -> gpurun_out/parity_ratios.jsonl (committed per round as
+    profiles/rNN_parity_ratios.jsonl)"""
+    import json
+    import os
+    print("PARITY_RATIO", rec)
+    try:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "parity_ratios.jsonl"), "a") as fh:
+            fh.write(json.dumps(rec) + "\n")
+    except OSError:
+        pass
 
 
 def _weights_dict(model):
@@ -204,6 +235,8 @@ def _kink_census(version, y_true, pred_oracle, pred_dev, class_num):
                                                       (3, True, "tiny416"), (4, True, "608bs1")])
 def test_model_parity(version, unbiased, true_c1):
     from tf2_yolo_amd import optimizers
+    import conftest
+    conftest.foreground_threads()     # explicit CPU threads for this test's oracle passes (half the box while conftest's jobs run)
     if true_c1 == "tiny416":   # tiny-YOLOv3 at its usual resolution: 416x416, grids 13 and 26 (bs 2)
         y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=416, N=2, unbiased=unbiased, tiny=True)
         assert [tuple(o.shape[1:3]) for o in model.output] == [(13, 13), (26, 26)]
@@ -305,7 +338,7 @@ def test_model_parity(version, unbiased, true_c1):
     st_dist = 0.0
     for dp_, o in zip(dev_pred, ref_tr):
         st_dist = max(st_dist, float((dp_ - o.detach()).abs().max()) / max(float(o.detach().abs().max()), 1e-30))
-    assert st_dist < max(1e-4, 3 * fwd_floor), (st_dist, fwd_floor)
+    assert st_dist < max(1e-4, 1.5 * fwd_floor), (st_dist, fwd_floor)
     census["straight_through_max_rel_move"] = st_dist
     near, pairs = 0, 0
     for yt, o, dp_ in zip(ys, ref_tr, dev_pred):
@@ -317,10 +350,12 @@ def test_model_parity(version, unbiased, true_c1):
     sum(lf(torch.tensor(yt), o + (dp_.float() - o).detach(), decide_with=dc)
         for lf, yt, o, dc, dp_ in zip(loss_o, ys, out32, decs, dev_pred)).backward()
 
-    for a, b in zip(outs, ref_tr):
-        assert _rel(a.cpu().numpy(), b.detach().numpy()) < max(1e-4, 3 * fwd_floor)
+    # forward outputs / losses: 1e-4 (north_star), or 1.5x the error of the fp32 CPU execution on this instance (measured
+    # worst device / fp32-CPU ratio over all cases: 1.16 -- profiles/r05_parity_ratios.jsonl; the bar was 3x until round 4)
+    fwd_err = max(_rel(a.cpu().numpy(), b.detach().numpy()) for a, b in zip(outs, ref_tr))
+    assert fwd_err < max(1e-4, 1.5 * fwd_floor), (fwd_err, fwd_floor)
     for dl, rl, l32 in zip(dev_losses, ref_losses, losses32):
-        tol = max(1e-4, 3 * abs(l32.item() - rl.item()) / max(abs(rl.item()), 1.0))
+        tol = max(1e-4, 1.5 * abs(l32.item() - rl.item()) / max(abs(rl.item()), 1.0))
         assert abs(dl - rl.item()) < tol * max(abs(rl.item()), 1.0)
 
     # moving statistics after the training forward
@@ -331,6 +366,7 @@ def test_model_parity(version, unbiased, true_c1):
     # every parameter gradient, per tensor, relative to the tensor's largest entry
     gmax = max(float(t.grad.abs().max()) for t in wt.values() if t.grad is not None)
     worst = ("", 0.0, 0.0)
+    worst_ratio = ("", 0.0, 0.0, 0.0)
     for n in model.layer_names():
         layer_w = model.get_layer(n).get_weights()
         if not layer_w or n.endswith("_anchor"):
@@ -347,12 +383,18 @@ def test_model_parity(version, unbiased, true_c1):
             e = _rel(got, r.numpy())
             e32 = _rel(w32[f"{n}/{i}"].grad.numpy(), r.numpy())
             worst = max(worst, (n, e, e32), key=lambda t: t[1])
-            if true_c1 == "608bs1":
-                # at most twice the fp32-CPU error (floor 3e-4 of the tensor's largest entry: a handful of
-                # head biases sit at 1e-4 where the CPU happens to be at 2e-5)
-                assert e < max(2 * e32, 3e-4), (n, i, e, e32)
-            assert e < max(1e-3, 4 * e32, 3 * fwd_floor), (n, i, e, e32, fwd_floor)
+            worst_ratio = max(worst_ratio, (f"{n}/{i}", e / max(e32, 2e-4), e, e32), key=lambda t: t[1])
+            # EVERY case (round 5; until round 4 only YOLOv4-608 bs 1 had such a bound, the others max(1e-3, 4 e32, 3 floor)): at
+            # most twice the error of the fp32 CPU execution of the oracle on the same tensor, with an absolute floor of 4e-4
+            # of the tensor's largest entry (a handful of head biases sit at 1e-4 where the CPU happens to be at 2e-5; measured
+            # worst: YOLOv4-608 bs 2, out1_box1_prob_conv bias, 3.1e-4 against the CPU's 1.25e-4 -- profiles/r05_parity_ratios.jsonl)
+            assert e < max(2 * e32, 4e-4), (n, i, e, e32)
     print("worst gradient error", worst)
+    log_parity_ratio({"case": f"v{version} unbiased={unbiased} {true_c1}", "fp32_floor": fwd_floor, "forward_err": fwd_err,
+                      "forward_ratio": fwd_err / max(fwd_floor, 1e-30), "worst_gradient_tensor": worst_ratio[0],
+                      "worst_gradient_err": worst_ratio[2], "fp32_cpu_err_same_tensor": worst_ratio[3],
+                      "worst_gradient_ratio_err_over_max_e32_2e-4": worst_ratio[1],
+                      "largest_gradient_err": worst[1], "largest_gradient_err_fp32_cpu": worst[2]})
 
     # ---- unconditioned companion (VERDICT r03 next #2b): the oracle makes ALL its own decisions -- its own LeakyReLU signs,
     # pool winners, responsible anchors and masks, its own predictions -- and the device's gradients are compared with it per
@@ -425,11 +467,14 @@ def test_model_parity(version, unbiased, true_c1):
     ref, _ = fwd(w_inf, xt, False)
     ref32, _ = fwd({k: torch.tensor(v, dtype=torch.float32) for k, v in w_inf.items()}, torch.tensor(x), False)
     inf_floor = max(_rel(b32.numpy(), b.numpy()) for b, b32 in zip(ref, ref32))
+    inf_err = max(_rel(a, b.numpy()) for a, b in zip(pred, ref))
+    log_parity_ratio({"case": f"v{version} unbiased={unbiased} {true_c1} (inference forward)", "fp32_floor": inf_floor,
+                      "forward_err": inf_err, "forward_ratio": inf_err / max(inf_floor, 1e-30)})
     for a, b in zip(pred, ref):
         assert a.shape == tuple(b.shape)
         assert np.isfinite(a).all()
-        # 1e-4, or the error floor of an fp32 CPU execution of the oracle on this small-batch problem
-        assert _rel(a, b.numpy()) < max(1e-4, 4 * inf_floor)
+        # 1e-4, or 1.5x the error of an fp32 CPU execution of the oracle on this small-batch problem
+        assert _rel(a, b.numpy()) < max(1e-4, 1.5 * inf_floor)
 
     # ---- one Adam step ----
     net.forward(xd, training=True)       # restore training state consumed by predict()
