@@ -68,7 +68,9 @@ int yolo_mfma_probe(const void* operands_f16, float* sink, int workgroups, int i
  * LDS ring and takes all nine taps from it (conv_wgrad_win.hip): 0 = the per-tap kernel everywhere; wherever the shape allows: 1 = on
  * v_mfma_f32_32x32x16_f16, 3 = on v_mfma_f32_16x16x32_f16 (holds a higher clock on random data).
  * key -1 resets every option to its default. */
-enum { YOLO_OPT_CONV_WIN = 0, YOLO_OPT_STAMPS = 1, YOLO_OPT_CONV_SK = 2, YOLO_OPT_CONV_PATCH = 5, YOLO_OPT_WGRAD_WIN = 6 };
+enum { YOLO_OPT_CONV_WIN = 0, YOLO_OPT_STAMPS = 1, YOLO_OPT_CONV_SK = 2, YOLO_OPT_CONV_PATCH = 5, YOLO_OPT_WGRAD_WIN = 6,
+       YOLO_OPT_NMS_WALK = 7 /* (env YOLO_NMS_WALK, default 0) hard / DIoU NMS: 1 = the greedy walk kernel for every class instead of the
+                                pair bit matrix + walk over the bits (same rows either way; tests) */ };
 int yolo_set_option(int key, int value);
 /* Scratch for the split-K / stream-K forms of the planes convolutions (key 2 = YOLO_OPT_CONV_SK != 0): the accumulator
  * slabs of tiles computed by several workgroups (+ the stream-K form's tile tickets). The caller owns the memory

@@ -1,6 +1,7 @@
 #!/bin/bash
-O=gpurun_out/r5f; mkdir -p $O
-for V in 1 2 0 1 2 0; do
-  YOLO_BN_TIGHT_BOUND=$V python bench.py --no-cpu-baseline --no-kernel-timer --steps 20 > $O/c.log 2>$O/c.err; echo -n "tight=$V: "; python scripts/bench_line.py $O/c.log
-done
-YOLO_BN_TIGHT_BOUND=0 python -m pytest tests/test_gpu_model.py -x -q -k "not 608 and not 416" > $O/t.log 2>&1; echo "tests(tight=0) rc $?"; tail -3 $O/t.log
+R=$PWD; O=$R/gpurun_out/r5f; mkdir -p $O; export TMPDIR=/tmp
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/scripts/nms_c5_profile.py > $O/nms_c5.log 2>&1 || echo "prof failed"
+cat $O/nms_c5.log | grep -v amdgpu.ids
+cp $O/ks/*/*kernel_stats.csv $O/nms_c5_kernel_stats.csv 2>/dev/null; rm -rf $O/ks
+python3 $R/scripts/kstats_summary.py $O/nms_c5_kernel_stats.csv 40 | grep -i "nms\|decode\|total" 

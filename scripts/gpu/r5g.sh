@@ -1,4 +1,10 @@
 #!/bin/bash
-python bench.py --steps 10 --warmup 3 > gpurun_out/r03_e_bench.json 2> gpurun_out/r03_e_bench.log; python scripts/bench_line.py gpurun_out/r03_e_bench.json
-python scripts/bench_configs.py > gpurun_out/r03_e_configs.jsonl 2>gpurun_out/r03_e_configs.err; cut -c1-200 gpurun_out/r03_e_configs.jsonl | head -5
-for V in 1 0 1 0; do echo -n "tight=$V: "; YOLO_BN_TIGHT_BOUND=$V python scripts/bench_configs.py c4 2>&1 | grep images_per_s | cut -c1-170; done
+R=$PWD; O=$R/gpurun_out/r5g; mkdir -p $O; export TMPDIR=/tmp
+timeout -k 10 600 python -m pytest tests/test_gpu_decode_nms.py tests/test_gpu_measurement.py -x -q > $O/t1.log 2>&1; echo "nms tests rc $?"; tail -15 $O/t1.log
+timeout -k 10 300 python -m pytest tests/test_gpu_fullsize.py -x -q -k "decode_nms" > $O/t2.log 2>&1; echo "fullsize nms rc $?"; tail -3 $O/t2.log
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ks -- python3 $R/scripts/nms_c5_profile.py > $O/nms_c5.log 2>&1 || echo "prof failed"
+grep -v "amdgpu.ids\|rocprofv3\|Opened result\|HSA version" $O/nms_c5.log
+cp $O/ks/*/*kernel_stats.csv $O/nms_c5_kernel_stats.csv 2>/dev/null; rm -rf $O/ks
+python3 $R/scripts/kstats_summary.py $O/nms_c5_kernel_stats.csv 40 | grep -i "nms\|total"
+cd $R; python scripts/nms_profile.py 2>&1 | grep -v amdgpu

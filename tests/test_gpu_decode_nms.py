@@ -80,3 +80,78 @@ def test_decode_capacity_regrow():
     full = T.decode(lv, class_num=80, threshold=0.3, version=3)
     got = tools.decode_device(lv, class_num=80, threshold=0.3, version=3, capacity=100).cpu().numpy()
     assert np.array_equal(got, full)
+
+
+def _crowded_rows(rng, n, class_num, skew=False):
+    """rows whose boxes overlap heavily (centres in a small region, similar sizes): most of them get suppressed, the
+    greedy walk's decisions depend on one another in long chains"""
+    rows = np.zeros((n, 7))
+    rows[:, :2] = 0.3 + 0.4 * rng.random((n, 2))
+    rows[:, 2:4] = 0.05 + 0.1 * rng.random((n, 2))
+    rows[:, 4] = rng.random(n)
+    rows[:, 6] = rng.random(n)
+    if skew:     # a few large classes and many small ones
+        p = np.ones(class_num)
+        p[:3] = class_num * 2.0
+        rows[:, 5] = rng.choice(class_num, size=n, p=p / p.sum())
+    else:
+        rows[:, 5] = rng.integers(0, class_num, n)
+    return rows
+
+
+@pytest.mark.parametrize("case", ["crowded_20_classes", "skewed_80_classes", "one_class_5000", "uniform_noise_131k",
+                                  "class_larger_than_the_bit_matrix"])
+def test_nms_bit_matrix_and_walk_give_the_same_rows(case):
+    """Round 5: hard / DIoU NMS makes every pair test of a class first (bit matrix, whole chip) and then walks the bits
+    (csrc/decode_nms.hip: nms_mask_kernel, nms_scan_kernel); classes of more than 8192 rows keep the greedy walk kernel
+    (nms_walk_kernel), which yolo_set_option(7, 1) selects for every class. Both forms must return bit-identical rows --
+    crowded inputs where most rows are suppressed in long dependency chains, skewed class sizes (tile rows of different
+    lengths, classes of one row), a class that spans 79 tile rows, BASELINE.md's 131 304-row uniform-noise input -- and on the
+    inputs the CPU oracle can do in seconds both must equal the oracle's rows."""
+    import torch
+    from tf2_yolo_amd import ops, tools
+    rng = np.random.default_rng(77)
+    check_oracle = True
+    if case == "crowded_20_classes":
+        rows, C = _crowded_rows(rng, 6000, 20), 20
+    elif case == "skewed_80_classes":
+        rows, C = _crowded_rows(rng, 9000, 80, skew=True), 80
+    elif case == "one_class_5000":
+        rows, C = _crowded_rows(rng, 5000, 1), 1
+    elif case == "class_larger_than_the_bit_matrix":
+        rows, C = _crowded_rows(rng, 9500, 2), 2
+        rows[:9000, 5] = 1            # class 1: 9000 rows (> 8192: walk kernel in the default mode too), class 0: the rest
+        rows[9000:, 5] = 0
+        rows[:, :2] = rng.random((9500, 2))     # spread out: a few thousand survivors
+        check_oracle = False          # (a 9000 x 9000 float64 IoU matrix on the host)
+    else:
+        lv = [torch.from_numpy(np.random.default_rng(1234).random((g, g, 255), dtype=np.float32)).cuda() for g in (13, 26, 52)]
+        rows, C = tools.decode_device(*lv, class_num=80, threshold=0.5, version=3), 80
+        assert rows.shape[0] > 100000
+        check_oracle = False
+    dev = rows if torch.is_tensor(rows) else torch.from_numpy(rows).cuda()
+    for thr in (0.5, 0.2):
+        got = {}
+        try:
+            for walk in (0, 1):
+                ops.set_option(ops.OPT_NMS_WALK, walk)
+                got[walk] = (tools.nms(dev, class_num=C, nms_threshold=thr), tools.nms(dev, class_num=C, nms_threshold=thr, iou_mode=2))
+        finally:
+            ops.reset_options()
+        for a, b in zip(got[0], got[1]):
+            assert torch.equal(a, b)
+        assert got[0][0].shape[0] < dev.shape[0] or case == "uniform_noise_131k"
+        if check_oracle:
+            assert np.array_equal(got[0][0].cpu().numpy(), T.nms(rows, C, thr))
+            assert np.array_equal(got[0][1].cpu().numpy(), T.nms(rows, C, thr, 2))
+    # a threshold of zero or below: no early rejection of non-overlapping pairs (IoU = 0 >= 0 suppresses everything behind
+    # the best row of a class; DIoU is negative for distinct centres)
+    small = dev[:1500].contiguous()
+    for thr in (0.0, -0.5):
+        for mode in (1, 2):
+            ref = T.nms(small.cpu().numpy(), C, thr, mode)
+            assert np.array_equal(tools.nms(small, class_num=C, nms_threshold=thr, iou_mode=mode).cpu().numpy(), ref)
+    # soft-NMS (LDS-tiled since round 5) on the same rows against the oracle
+    if check_oracle:
+        assert np.array_equal(tools.soft_nms(dev, class_num=C, nms_threshold=0.3, conf_threshold=0.3, sigma=0.5).cpu().numpy(),
+                              T.soft_nms(rows, C, 0.3, 0.3, 0.5))

@@ -35,6 +35,10 @@ static void options_from_env() {
   // v_mfma_f32_32x32x16_f16, 2 = that with fragment reads two tap-steps ahead, 3 = on v_mfma_f32_16x16x32_f16 (default 1: 3 is 4 % faster alone, equal in the step)
   e = getenv("YOLO_WGRAD_WIN");
   g_opt[OPT_WGRAD_WIN] = e ? atoi(e) : 1;
+  // hard / DIoU NMS: 0 = pair tests as a bit matrix by the whole chip + per-class walk over the bits (classes of up to 8192
+  // rows; larger ones walk), 1 = the greedy walk kernel for every class (tests: both must give the same rows)
+  e = getenv("YOLO_NMS_WALK");
+  g_opt[OPT_NMS_WALK] = e ? atoi(e) : 0;
 }
 void init_options() {
   static bool done = false;
@@ -75,7 +79,7 @@ extern "C" int yolo_set_debug_buffer(void* p, size_t bytes) {
 
 extern "C" const char* yolo_last_error(void) { return yolo::g_err; }
 
-extern "C" int yolo_abi_version(void) { return 4; }   // 4: round 5 added yolo_conv2d_dgrad_planes_bnred, yolo_bn_act_bwd_sum_partials, yolo_bnred_slots_cap; 3: round 4 added yolo_bn_act_bwd_reduce_bound_ld / _apply_planes_ld (dout with a row pitch), option key 6; 2: round 3 added yolo_cal_iou, yolo_nms_select, yolo_adam_step_dev, yolo_bn_finalize_offset, the wgrad workspace, yolo_mfma_probe
+extern "C" int yolo_abi_version(void) { return 4; }   // 4: round 5 added yolo_conv2d_dgrad_planes_bnred, yolo_bn_act_bwd_sum_partials, yolo_bnred_slots_cap, option key 7; 3: round 4 added yolo_bn_act_bwd_reduce_bound_ld / _apply_planes_ld (dout with a row pitch), option key 6; 2: round 3 added yolo_cal_iou, yolo_nms_select, yolo_adam_step_dev, yolo_bn_finalize_offset, the wgrad workspace, yolo_mfma_probe
 
 extern "C" int yolo_device_available(void) {
   int n = 0;

@@ -162,6 +162,7 @@ OPT_CONV_WIN = 0   # include/yolo_hip.h YOLO_OPT_CONV_WIN
 OPT_CONV_SK = 2
 OPT_CONV_PATCH = 5   # include/yolo_hip.h YOLO_OPT_CONV_PATCH
 OPT_WGRAD_WIN = 6    # 3x3 stride-1 filter gradient with the input window in LDS (conv_wgrad_win.hip): 0 off, 1 on
+OPT_NMS_WALK = 7     # hard / DIoU NMS: 1 = the greedy walk kernel for every class (default 0: pair bit matrix + walk over the bits)
 _CONV_WS = None
 
 
