@@ -344,6 +344,7 @@ class Network:
         # the gradient of a Concatenate reaches the BatchNormalization backward of its sources as a channel SLICE of the
         # concat's gradient (ops.ChannelSlice: read in place with its row pitch) instead of being copied out per source
         self._concat_grad_slices = os.environ.get("YOLO_CONCAT_GRAD_SLICE", "1") != "0"
+        self._dyp_per_layer = os.environ.get("YOLO_DYP_PER_LAYER", "1") != "0"
         # The BatchNormalization-backward reduction of a conv + BN unit P (sums of dz and dz * xhat over dL/d(P.out)) is made
         # by the data gradient that COMPLETES dL/d(P.out) -- the last contribution in backward order, when that is a planes
         # data gradient (include/yolo_hip.h: yolo_conv2d_dgrad_planes_bnred): W.bnred_for = P on that writer W.
@@ -629,6 +630,21 @@ class Network:
         self._dyplanes2 = [torch.empty(dyp, device=dev, dtype=torch.uint8) if dyp else None for _ in range(2)]
         self._dyp_events = [None, None]
         self._dyp_idx = 0
+        # YOLO_DYP_PER_LAYER=1 (default): every layer has its OWN dy planes instead -- 288 GB of HBM make the reuse pointless
+        # (YOLOv3-416 at bs 32: +4.6 GB), and the reuse costs the compute stream a wait on the filter-gradient stream's event
+        # per layer: a barrier packet in its queue even when the event has long fired (2.4 us each, 75 per step, measured
+        # with scripts/hip_probe/event_gap_probe.cpp: profiles/r05_a_event_gap_probe.log) plus the event record on the side
+        # stream. Across steps the buffers are safe: backward joins the filter-gradient stream before it returns.
+        self._dyp_own = {}
+        if self._dyp_per_layer:
+            for u in self.units:
+                if u.kind == "head" and u.cpad:
+                    nb = ops.planes_bytes(N * u.out.h * u.out.w, u.cpad)
+                elif u.kind in ("conv", "head") and (u.planes_dgrad or u.planes_wgrad):
+                    nb = ops.planes_bytes(N * u.out.h * u.out.w, u.cout if u.kind == "conv" else u.out.c)
+                else:
+                    continue
+                self._dyp_own[u.name] = torch.empty(nb, device=dev, dtype=torch.uint8)
         self._xp_valid = set()
 
     def _tb_row(self, tid):
@@ -1058,7 +1074,7 @@ class Network:
                         if self.grad_ready_hook is not None:
                             tape.host_call(lambda u=u: self.grad_ready_hook(u))
                         continue
-                    dyp = self._next_dyp_buffer() if need_pl else None
+                    dyp = self._next_dyp_buffer(u) if need_pl else None
                     dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
                                         sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta),
                                         planes=dyp, want_dx=need_f32,
@@ -1080,7 +1096,7 @@ class Network:
                                       danchors=self._anchor_grad_views.get(u.name) if self.anchors_trainable else None)
                 if u.cpad:
                     rows = N * u.out.h * u.out.w
-                    dtp = ops.split_planes_padded(dt, rows, u.out.c, out=self._next_dyp_buffer())
+                    dtp = ops.split_planes_padded(dt, rows, u.out.c, out=self._next_dyp_buffer(u))
                     with self._beside_backward(dt):
                         ops.zero_bytes(u.dw_pad)
                         ops.conv2d_wgrad_planes(u.desc_pad, self._xplanes[u.src.tid], dtp, u.dw_pad)
@@ -1164,7 +1180,11 @@ class Network:
     # fp32 tensors read on the second stream are marked with record_stream; the main stream joins the second
     # one at the end of backward. A grad_ready_hook (data parallel gradient buckets) must order its work after
     # BOTH streams (dp.GradReducer.extra_streams).
-    def _next_dyp_buffer(self):
+    def _next_dyp_buffer(self, u=None):
+        if u is not None and u.name in self._dyp_own:
+            self._dyp_cur_own = True
+            return self._dyp_own[u.name]
+        self._dyp_cur_own = False
         self._dyp_idx ^= 1
         ev = self._dyp_events[self._dyp_idx]
         if ev is not None:
@@ -1186,8 +1206,10 @@ class Network:
                 t.record_stream(side)
         with torch.cuda.stream(side):
             yield
-            ev = tape.record_event(side)
-        self._dyp_events[self._dyp_idx] = ev
+            # (the event guards the REUSE of a shared dy planes buffer: a layer with planes of its own needs none)
+            ev = None if getattr(self, "_dyp_cur_own", False) else tape.record_event(side)
+        if ev is not None:
+            self._dyp_events[self._dyp_idx] = ev
         self._wgrad_pending = True
 
     def _join_wgrad(self):
@@ -1200,7 +1222,7 @@ class Network:
         if not (u.planes_wgrad or u.planes_dgrad):
             return None
         cout = u.cout if u.kind == "conv" else u.out.c
-        return ops.split_planes(dy, self.batch * u.out.h * u.out.w, cout, out=self._next_dyp_buffer())
+        return ops.split_planes(dy, self.batch * u.out.h * u.out.w, cout, out=self._next_dyp_buffer(u))
 
     def _bnred_of(self, w, cur):
         """the fused reduction this writer's data gradient makes (None: none). cur = the gradient it adds into, if any: a
