@@ -535,7 +535,12 @@ size_t yolo_decode_workspace_bytes(int gh, int gw, int A, int C);
 
 /* NMS over n decoded rows (device float64 [n,7]); keep_out: device uint8[n] (1 = kept).
  * The caller gathers kept rows class by class in ascending class id, original order inside
- * a class (utils/tools.py:730-732). */
+ * a class (utils/tools.py:730-732).
+ * Round 5: hard / DIoU NMS make every pair test of a class first (a bit matrix, one 64-bit word per row and 64 columns, by
+ * the whole chip) and then walk the bits, one workgroup per class; classes of more than 8192 rows walk the boxes directly.
+ * The workspace therefore includes room for the matrices: yolo_nms_workspace_bytes(n, class_num) grows by
+ * n * (min(n, 8192) / 64 + 1) * 8 bytes (156 MB for 151 186 rows; 1 MB for 4 425). Results are bit-identical to the walk
+ * (yolo_set_option(YOLO_OPT_NMS_WALK, 1) selects it for every class). */
 size_t yolo_nms_workspace_bytes(int n, int class_num);
 int yolo_nms(const double* rows, int n, int class_num, int mode, double nms_threshold,
              double conf_threshold, double sigma, unsigned char* keep_out,
