@@ -154,8 +154,9 @@ __device__ __forceinline__ void planes_epilogue(const GatherConvArgs& a, f32x16 
     const int bcol = n0 + wn * WCOLS + (lane % C4) * 4;
     f32x4 b_sc = {0.f, 0.f, 0.f, 0.f}, b_sh = b_sc, b_mu = b_sc, b_iv = b_sc, b_s1 = b_sc, b_s2 = b_sc;
     // ALL the y values (and, for small sub-tiles, the old values of the accumulate form) this lane will need are requested
-    // HERE, before the first staging pass: one memory latency per tile instead of one per batch of row pieces (loaded
-    // batch by batch the fused launches ran 9-14 % longer -- exactly what the standalone reduction had cost)
+    // HERE, before the first staging pass: one memory latency per tile instead of one per batch of row pieces. (Measured,
+    // the window data gradient still pays 13-21 us per launch for its y tile, the bandwidth-bound 1x1
+    // accumulate form 34 us -- about what the standalone reduction costs beside the filter-gradient stream: the option is off.)
     constexpr int NPASS = TM * (32 / RP);
     constexpr bool PRE_OLD = TM * TN <= 2;
     [[maybe_unused]] f32x4 ypre[BNRED ? NPASS : 1][BNRED ? ITER : 1];
