@@ -623,3 +623,35 @@ def test_fused_bn_backward_reduction_option_gives_the_same_gradients(version, mo
         a, b = g0[s.offset:s.offset + s.size], g1[s.offset:s.offset + s.size]
         scale = max(a.abs().max().item(), 1e-30)
         assert (a - b).abs().max().item() / scale < 2e-5, name
+
+
+def test_dy_planes_per_layer_or_shared_give_identical_gradients(monkeypatch):
+    """YOLO_DYP_PER_LAYER=1 (default since round 5: every conv layer owns the planes of its d(conv out), no event wait on the
+    filter-gradient stream per layer) against the two shared, alternately used buffers of rounds 1-4: the same kernels on the
+    same values in the same order -- every parameter gradient bit-identical, over two steps (the second step re-uses the
+    buffers the first one's filter gradients read)."""
+    import numpy as np
+    from tf2_yolo_amd import labels
+    import yolov3
+    hw, cls = 96, 4
+    x_h, ys_h = labels.synthetic_batch(np.random.default_rng(21), 2, (hw, hw), cls)
+    x = torch.from_numpy(x_h).cuda()
+    ys = [torch.from_numpy(y).cuda() for y in ys_h]
+    grads = []
+    for mode in ("0", "1"):
+        monkeypatch.setenv("YOLO_DYP_PER_LAYER", mode)
+        y = yolov3.Yolo((hw, hw, 3), [f"c{i}" for i in range(cls)])
+        y.create_model(pretrained_body=None, seed=9)
+        net, lossf = y.model.net, y.loss()
+        assert bool(net._dyp_per_layer) == (mode == "1")
+        for _ in range(2):
+            outs = net.forward(x, training=True)
+            dpred = [torch.empty_like(o) for o in outs]
+            for i, (o, yt) in enumerate(zip(outs, ys)):
+                lossf[i].fwd_bwd(yt, o, grad_scale=1.0, dpred=dpred[i])
+            net.grads.zero_()
+            net.backward(dpred)
+        torch.cuda.synchronize()
+        assert (len(net._dyp_own) > 50) == (mode == "1")
+        grads.append(net.grads.clone())
+    assert torch.equal(grads[0], grads[1])
