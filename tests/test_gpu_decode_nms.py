@@ -155,3 +155,46 @@ def test_nms_bit_matrix_and_walk_give_the_same_rows(case):
     if check_oracle:
         assert np.array_equal(tools.soft_nms(dev, class_num=C, nms_threshold=0.3, conf_threshold=0.3, sigma=0.5).cpu().numpy(),
                               T.soft_nms(rows, C, 0.3, 0.3, 0.5))
+
+
+def test_nms_edge_cases_walk_and_bit_matrix_agree():
+    """The corners of the round-5 NMS pipeline: more classes than the LDS-resident counters hold (3000 > 2048: the global-atomic
+    paths of the counter kernels and the tile table read from memory), inputs of 1 / 2 / 3 rows, exact score ties inside a
+    class (ordered "higher original index first" in both forms), every row in one class with identical boxes (one survivor)."""
+    import torch
+    from tf2_yolo_amd import ops, tools
+    rng = np.random.default_rng(99)
+
+    def both(rows, C, thr=0.5):
+        dev = torch.from_numpy(rows).cuda()
+        out = {}
+        try:
+            for walk in (0, 1):
+                ops.set_option(ops.OPT_NMS_WALK, walk)
+                out[walk] = [tools.nms(dev, class_num=C, nms_threshold=thr).cpu().numpy(),
+                             tools.nms(dev, class_num=C, nms_threshold=thr, iou_mode=2).cpu().numpy(),
+                             tools.soft_nms(dev, class_num=C, nms_threshold=thr, conf_threshold=0.3, sigma=0.5).cpu().numpy()]
+        finally:
+            ops.reset_options()
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b)
+        return out[0]
+
+    rows = _crowded_rows(rng, 6000, 3000)
+    got = both(rows, 3000)
+    assert np.array_equal(got[0], T.nms(rows, 3000, 0.5)) and np.array_equal(got[1], T.nms(rows, 3000, 0.5, 2))
+    assert np.array_equal(got[2], T.soft_nms(rows, 3000, 0.5, 0.3, 0.5))
+    for n in (1, 2, 3):
+        r = _crowded_rows(rng, n, 2)
+        g = both(r, 2)
+        assert np.array_equal(g[0], T.nms(r, 2, 0.5))
+    # exact ties: groups of equal conf * prob inside one class
+    r = _crowded_rows(rng, 400, 1)
+    r[:, 4] = np.repeat(rng.random(40), 10)
+    r[:, 6] = 0.5
+    g = both(r, 1, thr=0.3)
+    assert 0 < g[0].shape[0] < 400
+    # identical boxes: exactly one survivor (the best-ranked row; ties -> the highest original index)
+    r = np.tile(np.array([[.5, .5, .2, .2, .9, 0., .9]]), (300, 1))
+    g = both(r, 1)
+    assert g[0].shape[0] == 1 and g[1].shape[0] == 1
