@@ -21,7 +21,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -o $@
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $(OBJS) -ldl -o $@
 
 clean:
 	rm -f $(OBJS) $(LIB)

@@ -595,14 +595,17 @@ int yolo_pr_curve(const double* joint, const int* gt_id, const unsigned char* ma
                   double* recall, void* stream);
 
 /* ------------------------------------------------------------------------------------
- * Gradient exchange (data parallelism; no reference counterpart). SURVEY.md section 8b lists a
- * `yolo_allreduce_bucket` wrapper: it is deliberately NOT exported. The exchange is torch.distributed's
- * all_reduce (backend "nccl" = RCCL over xGMI) on contiguous slices of the caller's flat gradient buffer, issued
- * from the host side (tf2_yolo_amd/dp.py) on a communication stream -- RCCL needs its communicator, its own stream
- * ordering and process-group bootstrap, all of which live above this C-ABI; the library only guarantees that the
- * parameter gradients of a unit are complete on the stream(s) it was given when its backward calls have been
- * enqueued. yolo_adam_step applies the 1/world factor (grad_scale).
+ * Gradient exchange (data parallelism; no reference counterpart). `yolo_allreduce_bucket` is the thin RCCL wrapper
+ * SURVEY.md section 8b lists (round 5; rounds 1-4 left it out): in-place sum all-reduce of `count` fp32 values of the
+ * caller's flat gradient buffer on the caller's stream with the CALLER'S communicator (`rccl_comm` = an ncclComm_t). The
+ * library does not link RCCL: ncclAllReduce is resolved in the process at the first call (the RCCL the host already
+ * loaded, else librccl.so from the loader path). It is for hosts that own their communicators; the Python host of this
+ * repository exchanges gradients through torch.distributed (backend "nccl" = RCCL over xGMI; tf2_yolo_amd/dp.py), which
+ * does not hand out its communicator -- same collective, same buffer slices, same stream ordering. The library guarantees
+ * that the parameter gradients of a unit are complete on the stream(s) it was given when its backward calls have been
+ * enqueued; yolo_adam_step applies the 1/world factor (grad_scale).
  * ------------------------------------------------------------------------------------ */
+int yolo_allreduce_bucket(void* rccl_comm, float* grads, long long count, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Label tensors (the step in front of the loss): box -> grid encoder of the reference's data sequences

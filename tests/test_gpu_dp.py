@@ -100,3 +100,45 @@ def test_dp_step_timing_and_bucket_readiness_at_the_benchmark_batch():
     assert len(buckets) >= 4 and abs(sum(mb for mb, _, _ in buckets) - n_train * 4 / 1e6) < 1.0
     assert buckets[0][1] <= 5.0, buckets
     assert all(d >= r for _, r, d in buckets)
+
+
+def test_allreduce_bucket_wrapper_with_a_one_rank_communicator():
+    """yolo_allreduce_bucket (the thin RCCL wrapper of the C-ABI, for hosts that own their
+    communicator): a one-rank RCCL communicator created here through the RCCL torch bundles (ncclGetUniqueId /
+    ncclCommInitRank), two slices of a flat buffer reduced in place on a side stream -- a sum over one rank leaves the values
+    as they are, and the call must have run on the given stream (the wrapper resolves ncclAllReduce in the process at its
+    first call: the same RCCL copy, never a second one)."""
+    import ctypes
+    import glob
+    import torch
+    from tf2_yolo_amd import _lib
+    from tf2_yolo_amd._lib import check
+    paths = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*"))
+    assert paths, "torch ships no librccl.so here"
+    rccl = ctypes.CDLL(paths[0], mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+    uid = UniqueId()
+    rccl.ncclGetUniqueId.argtypes = [ctypes.POINTER(UniqueId)]
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    rccl.ncclCommDestroy.argtypes = [ctypes.c_void_p]
+    torch.cuda.set_device(0)
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    comm = ctypes.c_void_p()
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    try:
+        flat = torch.randn(3_000_000, device="cuda")
+        want = flat.clone()
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        lib = _lib.load()
+        for lo, hi in ((0, 1_000_000), (1_000_000, 3_000_000)):
+            view = flat[lo:hi]
+            check(lib.yolo_allreduce_bucket(comm, ctypes.c_void_p(view.data_ptr()), hi - lo, ctypes.c_void_p(st.cuda_stream)),
+                  "yolo_allreduce_bucket")
+        st.synchronize()
+        assert torch.equal(flat, want)
+        assert lib.yolo_allreduce_bucket(None, ctypes.c_void_p(flat.data_ptr()), 16, ctypes.c_void_p(st.cuda_stream)) != 0
+    finally:
+        rccl.ncclCommDestroy(comm)

@@ -101,6 +101,7 @@ SIGNATURES = {
     "yolo_conv2d_dgrad_planes_bnred": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, _P, c_int, _P,
                                                POINTER(c_int), _P]),
     "yolo_bn_act_bwd_sum_partials": (c_int, [_P, c_int, _LL, c_int, _P, _P, _P, _P]),
+    "yolo_allreduce_bucket": (c_int, [_P, _P, _LL, _P]),
     "yolo_act_fwd": (c_int, [_P, _LL, c_int, _P, _P]),
     "yolo_act_bwd": (c_int, [_P, _P, _LL, c_int, _P, _P]),
     "yolo_copy_channels_in": (c_int, [_P, _LL, c_int, _P, c_int, c_int, _P]),

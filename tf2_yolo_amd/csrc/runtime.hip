@@ -79,7 +79,43 @@ extern "C" int yolo_set_debug_buffer(void* p, size_t bytes) {
 
 extern "C" const char* yolo_last_error(void) { return yolo::g_err; }
 
-extern "C" int yolo_abi_version(void) { return 4; }   // 4: round 5 added yolo_conv2d_dgrad_planes_bnred, yolo_bn_act_bwd_sum_partials, yolo_bnred_slots_cap, option key 7; 3: round 4 added yolo_bn_act_bwd_reduce_bound_ld / _apply_planes_ld (dout with a row pitch), option key 6; 2: round 3 added yolo_cal_iou, yolo_nms_select, yolo_adam_step_dev, yolo_bn_finalize_offset, the wgrad workspace, yolo_mfma_probe
+extern "C" int yolo_abi_version(void) { return 4; }   // 4: round 5 added yolo_conv2d_dgrad_planes_bnred, yolo_bn_act_bwd_sum_partials, yolo_bnred_slots_cap, option key 7, yolo_allreduce_bucket; 3: round 4 added yolo_bn_act_bwd_reduce_bound_ld / _apply_planes_ld (dout with a row pitch), option key 6; 2: round 3 added yolo_cal_iou, yolo_nms_select, yolo_adam_step_dev, yolo_bn_finalize_offset, the wgrad workspace, yolo_mfma_probe
+
+// ---- gradient exchange: the thin RCCL wrapper of SURVEY.md section 8b ----
+// For a host that OWNS an RCCL communicator (a C++ trainer, a binding that creates its communicators itself): in-place
+// sum all-reduce of one contiguous fp32 slice of the flat gradient buffer on the caller's stream. The library does not link
+// RCCL: ncclAllReduce is looked up in the process at the first call (the copy the host already loaded -- torch bundles its
+// own -- or librccl.so from the loader path), so there is never a second RCCL in the process. The Python host of this
+// repository keeps using torch.distributed (tf2_yolo_amd/dp.py): torch does not hand out its ncclComm_t.
+#include <dlfcn.h>
+namespace {
+using nccl_allreduce_fn = int (*)(const void*, void*, size_t, int, int, void*, hipStream_t);
+nccl_allreduce_fn find_nccl_allreduce() {
+  void* f = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+  if (f == nullptr) {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (h == nullptr) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (h != nullptr) f = dlsym(h, "ncclAllReduce");
+  }
+  return reinterpret_cast<nccl_allreduce_fn>(f);
+}
+}  // namespace
+
+extern "C" int yolo_allreduce_bucket(void* rccl_comm, float* grads, long long count, void* stream) {
+  YOLO_REQUIRE(rccl_comm != nullptr && grads != nullptr && count > 0, "allreduce_bucket: bad args");
+  static nccl_allreduce_fn fn = find_nccl_allreduce();
+  if (fn == nullptr) {
+    yolo::set_error("allreduce_bucket: no RCCL in this process (ncclAllReduce not found, librccl.so not loadable)");
+    return YOLO_ERR_LAUNCH;
+  }
+  constexpr int kNcclFloat = 7, kNcclSum = 0;   // rccl.h: ncclFloat32, ncclSum
+  const int rc = fn(grads, grads, (size_t)count, kNcclFloat, kNcclSum, rccl_comm, yolo::as_stream(stream));
+  if (rc != 0) {
+    yolo::set_error("allreduce_bucket: ncclAllReduce returned %d", rc);
+    return YOLO_ERR_LAUNCH;
+  }
+  return YOLO_OK;
+}
 
 extern "C" int yolo_device_available(void) {
   int n = 0;
