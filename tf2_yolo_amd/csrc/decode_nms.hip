@@ -458,6 +458,10 @@ __device__ __forceinline__ bool pair_suppresses(const BoxA& A, const double* b, 
 // One wave per 64 x 64 tile (tr <= tc) of a class's pair matrix; lane = row p = 64 tr + lane of the tile, the tile's 64
 // column boxes sit in the wave's own 2 KB of LDS. Tiles are numbered class after class (NmsWs::tile_off), rows of tiles
 // inside a class; the waves of a fixed grid stride over the list (the host does not know its length).
+// TRANS (soft-NMS): the transposed matrix -- lane = column q of the tile, bits over the tile's rows p < q, word [q][tr] --
+// so that a row of the matrix lists, in rank order, the earlier rows that decay q. IoU is symmetric in its operands bit for
+// bit (min / max / the commutative sum of the two areas), so the roles of the two boxes may be swapped.
+template <bool TRANS>
 __global__ __launch_bounds__(256) void nms_mask_kernel(int class_num, NmsWs ws, double thr, int diou) {
   __shared__ double s_box[4][64 * 4];
   __shared__ int s_toff[NMS_LDS_CLASSES + 1];
@@ -487,21 +491,23 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(int class_num, NmsWs ws, 
     while (tr > 0 && tr * T - tr * (tr - 1) / 2 > u) --tr;
     while (tr + 1 < T && (tr + 1) * T - (tr + 1) * tr / 2 <= u) ++tr;
     const int tc = tr + (u - (tr * T - tr * (tr - 1) / 2));
-    const int q_mine = tc * 64 + lane;
+    const int t_mine = TRANS ? tc : tr, t_other = TRANS ? tr : tc;   // the tile index of the lanes' rows / of the LDS boxes
+    const int o_mine = t_other * 64 + lane;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) sb[lane * 4 + k] = q_mine < nc ? ws.box[(long long)(beg + q_mine) * 4 + k] : 0.;
-    const int p = tr * 64 + lane;
+    for (int k = 0; k < 4; ++k) sb[lane * 4 + k] = o_mine < nc ? ws.box[(long long)(beg + o_mine) * 4 + k] : 0.;
+    const int m = t_mine * 64 + lane;
     unsigned long long bits = 0;
-    if (p < nc) {
-      const double a4[4] = {ws.box[(long long)(beg + p) * 4], ws.box[(long long)(beg + p) * 4 + 1],
-                            ws.box[(long long)(beg + p) * 4 + 2], ws.box[(long long)(beg + p) * 4 + 3]};
+    if (m < nc) {
+      const double a4[4] = {ws.box[(long long)(beg + m) * 4], ws.box[(long long)(beg + m) * 4 + 1],
+                            ws.box[(long long)(beg + m) * 4 + 2], ws.box[(long long)(beg + m) * 4 + 3]};
       const BoxA A = box_a(a4);
-      const int jn = nc - tc * 64 < 64 ? nc - tc * 64 : 64;
+      const int jn = nc - t_other * 64 < 64 ? nc - t_other * 64 : 64;
       for (int j = 0; j < jn; ++j) {
         const double b4[4] = {sb[j * 4], sb[j * 4 + 1], sb[j * 4 + 2], sb[j * 4 + 3]};
-        if (tc * 64 + j > p && pair_suppresses(A, b4, diou != 0, thr, thr_pos)) bits |= 1ull << j;
+        const int o = t_other * 64 + j;
+        if ((TRANS ? o < m : o > m) && pair_suppresses(A, b4, diou != 0, thr, thr_pos)) bits |= 1ull << j;
       }
-      ws.mask[ws.mask_off[c] + (long long)p * T + tc] = bits;
+      ws.mask[ws.mask_off[c] + (long long)m * T + t_other] = bits;
     }
   }
 }
@@ -550,10 +556,41 @@ __global__ __launch_bounds__(64 * NMS_SCAN_WAVES) void nms_scan_kernel(NmsWs ws)
   };
   stage(0, 0, NMS_SCAN_WAVES);
   __syncthreads();
+  // the loader waves (1 .. 7, rows wave - 1 + 7 u) run ONE tile row further ahead in registers: the loads of tile row tr + 2
+  // are issued before the barrier that ends iteration tr and land while wave 0 works on tr + 1 (a stage's latency otherwise
+  // sat between two barriers: 5.6 us per tile row where wave 0 needs 1.7)
+  static_assert((NMS_SCAN_WAVES - 1) * 10 >= 64, "one batch of 10 rows per loader wave covers a tile row");
+  unsigned long long pv0[10], pv1[10];
+  auto fetch = [&](int tr) {
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int r = wave - 1 + u * (NMS_SCAN_WAVES - 1);
+      const int p = tr * 64 + r;
+      const int w0 = tr + lane, w1 = tr + lane + 64;
+      const bool ok = tr < T && r < 64 && p < nc;
+      pv0[u] = (ok && w0 < T) ? M[(long long)p * T + w0] : 0ull;
+      pv1[u] = (ok && w1 < T) ? M[(long long)p * T + w1] : 0ull;
+    }
+  };
+  auto put = [&](int tr) {
+    unsigned long long* dst = buf + (size_t)(tr & 1) * 64 * NMS_MASK_WORDS;
+#pragma unroll
+    for (int u = 0; u < 10; ++u) {
+      const int r = wave - 1 + u * (NMS_SCAN_WAVES - 1);
+      if (r < 64) {
+        dst[r * NMS_MASK_WORDS + lane] = pv0[u];
+        if (tr + lane + 64 < T) dst[r * NMS_MASK_WORDS + lane + 64] = pv1[u];
+      }
+    }
+  };
+  if (wave != 0) fetch(1);
   unsigned long long rem0 = 0, rem1 = 0;
   for (int tr = 0; tr < T; ++tr) {
     if (wave != 0) {
-      if (tr + 1 < T) stage(tr + 1, 1, NMS_SCAN_WAVES - 1);
+      if (tr + 1 < T) {
+        put(tr + 1);
+        fetch(tr + 2);
+      }
     } else {
       const unsigned long long* src = buf + (size_t)(tr & 1) * 64 * NMS_MASK_WORDS;
       const int rows_here = nc - tr * 64 < 64 ? nc - tr * 64 : 64;
@@ -657,6 +694,40 @@ __global__ __launch_bounds__(1024) void nms_walk_kernel(NmsWs ws, double thr, in
 // soft-NMS: row q is deleted iff its score, decayed in rank order by every earlier row of its
 // class with IoU >= thr, falls below conf_threshold after some decay. One thread per row; the earlier rows' boxes in
 // tiles of 256 through LDS (union of the classes that meet in the workgroup, as in nms_rank_kernel).
+// Classes of up to NMS_MASK_MAX rows (round 5): the pairs with IoU >= thr come from the transposed bit matrix
+// (nms_mask_kernel<true>), so a row only recomputes the IoU of the few earlier rows that actually decay it -- in rank order,
+// with the arithmetic of the loop below (the product of the decays is rounded in that order).
+__global__ __launch_bounds__(256) void nms_soft_mask_kernel(int class_num, NmsWs ws, double thr, double conf_thr, double sigma) {
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= ws.class_off[class_num]) return;
+  const int c = ws.cls[ws.sorted_idx[q]];
+  const long long moff = ws.mask_off[c];
+  if (moff < 0) return;     // (nms_soft_kernel below takes the larger classes)
+  const int beg = ws.class_off[c], nc = ws.class_off[c + 1] - beg;
+  const int T = (nc + 63) >> 6;
+  const int ql = q - beg;
+  const double b[4] = {ws.box[(long long)q * 4], ws.box[(long long)q * 4 + 1], ws.box[(long long)q * 4 + 2],
+                       ws.box[(long long)q * 4 + 3]};
+  double conf = ws.sscore[q];
+  bool del = false;
+  const unsigned long long* row = ws.mask + moff + (long long)ql * T;
+  for (int tr = 0; tr <= (ql >> 6); ++tr) {
+    unsigned long long w = row[tr];
+    while (w) {
+      const int j = __builtin_ctzll(w);
+      w &= w - 1;
+      const long long p = beg + tr * 64 + j;
+      const double a[4] = {ws.box[p * 4], ws.box[p * 4 + 1], ws.box[p * 4 + 2], ws.box[p * 4 + 3]};
+      const double iou = pair_score(a, b, false);
+      if (iou >= thr) {     // (what the bit says; kept so that the two kernels are the same text)
+        conf *= exp(-1. * (iou * iou) / sigma);
+        if (conf < conf_thr) del = true;
+      }
+    }
+  }
+  ws.removed[q] = del ? 1 : 0;
+}
+
 __global__ __launch_bounds__(256) void nms_soft_kernel(int n, int class_num, NmsWs ws, double thr, double conf_thr, double sigma) {
   __shared__ double s_box[256 * 4];
   __shared__ int s_lo;
@@ -668,7 +739,9 @@ __global__ __launch_bounds__(256) void nms_soft_kernel(int n, int class_num, Nms
   const int i = live ? ws.sorted_idx[q] : 0;
   const int beg = live ? ws.class_off[ws.cls[i]] : 0;
   if (threadIdx.x == 0) s_lo = beg;
-  __syncthreads();
+  // (rows of classes that have a bit matrix were decided by nms_soft_mask_kernel)
+  const bool mine = live && ws.mask_off[ws.cls[i]] < 0;
+  if (!__syncthreads_or(mine ? 1 : 0)) return;
   const int lo = s_lo;
   const int hi = (q0 + 255 < total ? q0 + 255 : total - 1);   // the last row of the workgroup needs rows < hi
   double b[4] = {0., 0., 0., 0.};
@@ -685,7 +758,7 @@ __global__ __launch_bounds__(256) void nms_soft_kernel(int n, int class_num, Nms
     __syncthreads();
     const int k_lo = beg > p0 ? beg - p0 : 0;
     const int k_hi = q < p0 + 256 ? q - p0 : 256;
-    if (live)
+    if (mine)
       for (int k = k_lo; k < k_hi; ++k) {
         const double a[4] = {s_box[k * 4], s_box[k * 4 + 1], s_box[k * 4 + 2], s_box[k * 4 + 3]};
         // (boxes that do not overlap have IoU +0: below any positive threshold, before the divisions)
@@ -699,7 +772,7 @@ __global__ __launch_bounds__(256) void nms_soft_kernel(int n, int class_num, Nms
         }
       }
   }
-  if (live) ws.removed[q] = del ? 1 : 0;
+  if (mine) ws.removed[q] = del ? 1 : 0;
 }
 
 __global__ void nms_finish_kernel(int n, NmsWs ws, unsigned char* __restrict__ keep) {
@@ -856,10 +929,24 @@ extern "C" int yolo_nms(const double* rows, int n, int class_num, int mode, doub
   }
   const int nb = (n + 255) / 256;
   init_options();
-  const bool hard = mode != YOLO_NMS_SOFT;
-  const int force_walk = g_opt[OPT_NMS_WALK];   // yolo_set_option key 7 (tests): every class through the walk kernel
+  const int force_walk = g_opt[OPT_NMS_WALK];   // yolo_set_option key 7 (tests): no bit matrices -- the walk / tiled kernels for every class
   hipLaunchKernelGGL(nms_prepare_kernel, dim3(nb), dim3(256), 0, st, rows, n, class_num, ws);
-  hipLaunchKernelGGL(nms_class_scan_kernel, dim3(1), dim3(64), 0, st, class_num, ws, (hard && !force_walk) ? 1 : 0);
+  hipLaunchKernelGGL(nms_class_scan_kernel, dim3(1), dim3(64), 0, st, class_num, ws, force_walk ? 0 : 1);
+  // workgroups of the pair-matrix kernel: tiles <= sum over classes of T (T + 1) / 2 <= (n / 64 + class_num) (T_max + 1) / 2
+  long long mask_grid = 1;
+  {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        cus = 256;
+    }
+    const long long t_max = (n < NMS_MASK_MAX ? n : NMS_MASK_MAX) / 64 + 1;
+    const long long tiles_bound = ((long long)n / 64 + class_num) * (t_max + 1) / 2;
+    mask_grid = (tiles_bound + 3) / 4;
+    if (mask_grid > 8LL * cus) mask_grid = 8LL * cus;
+    if (mask_grid < 1) mask_grid = 1;
+  }
   hipLaunchKernelGGL(nms_bucket_kernel, dim3(nb), dim3(256), 0, st, n, class_num, ws);
   {   // order inside the classes: LDS sort (classes of up to NMS_MASK_MAX rows), rank by counting (the larger ones)
     constexpr size_t lds_sort = (size_t)NMS_MASK_MAX * 12;
@@ -872,23 +959,15 @@ extern "C" int yolo_nms(const double* rows, int n, int class_num, int mode, doub
     hipLaunchKernelGGL(nms_rank_kernel, dim3(nb), dim3(256), 0, st, rows, n, class_num, ws);
   }
   if (mode == YOLO_NMS_SOFT) {
+    if (!force_walk) {
+      hipLaunchKernelGGL(nms_mask_kernel<true>, dim3((unsigned)mask_grid), dim3(256), 0, st, class_num, ws, nms_threshold, 0);
+      hipLaunchKernelGGL(nms_soft_mask_kernel, dim3(nb), dim3(256), 0, st, class_num, ws, nms_threshold, conf_threshold, sigma);
+    }
     hipLaunchKernelGGL(nms_soft_kernel, dim3(nb), dim3(256), 0, st, n, class_num, ws, nms_threshold, conf_threshold, sigma);
   } else {
     if (!force_walk) {
       // pair tests of every class by the whole chip, then one workgroup per class walks its bit matrix
-      static int cus = 0;
-      if (cus == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-          cus = 256;
-      }
-      // tiles <= sum over classes of T (T + 1) / 2 <= (n / 64 + class_num) * (T_max + 1) / 2: no more workgroups than that
-      const long long t_max = (n < NMS_MASK_MAX ? n : NMS_MASK_MAX) / 64 + 1;
-      long long tiles_bound = ((long long)n / 64 + class_num) * (t_max + 1) / 2;
-      long long grid = (tiles_bound + 3) / 4;
-      if (grid > 8LL * cus) grid = 8LL * cus;
-      if (grid < 1) grid = 1;
-      hipLaunchKernelGGL(nms_mask_kernel, dim3((unsigned)grid), dim3(256), 0, st, class_num, ws, nms_threshold,
+      hipLaunchKernelGGL(nms_mask_kernel<false>, dim3((unsigned)mask_grid), dim3(256), 0, st, class_num, ws, nms_threshold,
                          mode == YOLO_NMS_DIOU ? 1 : 0);
       constexpr size_t lds = (size_t)2 * 64 * NMS_MASK_WORDS * 8;
       static bool attr_set = false;
