@@ -116,11 +116,11 @@ def pmc_from_profile(kernel):
                                                     "SIMDs over GRBM_GUI_ACTIVE / 8 XCDs)"}
 
 
-def cpu_baseline(threads, n=16):
+def cpu_baseline(threads, n=BATCH, timed=1):
     """Bounded sample of the SAME workload on the host CPU: training steps (forward, loss, autograd backward) of the torch-CPU
-    restatement of the reference graph, fp32, batch 16 (batch 32 takes ~45 s for the three steps below: past the bound of a
-    default bench run). One warm-up step OUTSIDE the timer (oneDNN primitive creation, allocator growth, page faults: the
-    round-4 figure timed exactly that step), then two timed steps; value = batch / median step time."""
+    restatement of the reference graph, fp32, at the benchmark's own batch of 32 (rounds 4-5 ran batch 16). One warm-up step
+    OUTSIDE the timer (oneDNN primitive creation, allocator growth, page faults), then `timed` steps of ~17 s each;
+    value = batch / median step time."""
     from oracle import losses as OL
     from oracle import models as OM
     from tf2_yolo_amd import graphs, labels
@@ -147,14 +147,14 @@ def cpu_baseline(threads, n=16):
         return time.perf_counter() - t0
 
     warm = step()
-    times = sorted(step() for _ in range(2))
-    dt = 0.5 * (times[0] + times[1])       # median of two
+    times = sorted(step() for _ in range(timed))
+    dt = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     return {"value": round(n / dt, 4), "unit": "images/s", "cores": threads, "kind": "port", "batch": n,
             "step_seconds": {"warmup_untimed": round(warm, 2), "timed": [round(t, 2) for t in times]},
-            "sample": f"2 timed training steps after 1 untimed warm-up step (fwd+loss+autograd bwd, no optimizer) of the "
-                      f"torch-CPU/oneDNN fp32 restatement of the reference YOLOv3 graph, batch {n} (NOT the benchmark's 32: "
-                      f"three batch-32 steps exceed the bound of a default run) at 416x416 C=80, median {dt:.1f} s per step on "
-                      f"{threads} threads; NOT tf.keras (TensorFlow is not installable in this pipeline)"}
+            "sample": f"{timed} timed training step(s) after 1 untimed warm-up step (fwd+loss+autograd bwd, no optimizer) of the "
+                      f"torch-CPU/oneDNN fp32 restatement of the reference YOLOv3 graph at the benchmark's batch {n}, 416x416 C=80, "
+                      f"median {dt:.1f} s per step on {threads} threads; NOT tf.keras (TensorFlow is not installable in this "
+                      f"pipeline)"}
 
 
 def decode_nms_block():
@@ -366,6 +366,64 @@ def configs_block():
     return res
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: start N fresh child processes of this file, one rank per
+    GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* and GPU_MAX_HW_QUEUES in their environment), relay rank 0's JSON line and
+    return the exit code (non-zero if any rank failed). The parent never touches the GPU (torch.cuda.device_count() does not
+    initialise HIP on this image) and never re-execs itself. With fewer visible devices than ranks the job degrades to the
+    visible count and says so; returns None when that leaves one rank (the caller then runs the N = 1 job itself).
+    YOLO_BENCH_SINGLE_DEVICE=1 (rehearsal: every rank on device 0, YOLO_DIST_BACKEND=gloo) keeps N."""
+    import socket
+    import subprocess
+    n = args.gpus
+    single_dev = os.environ.get("YOLO_BENCH_SINGLE_DEVICE") == "1"
+    visible = torch.cuda.device_count()
+    if not single_dev and visible < n:
+        print(f"[bench] --gpus {n} asked for, {visible} device(s) visible: running {max(visible, 1)} rank(s)",
+              file=sys.stderr, flush=True)
+        n = max(visible, 1)
+    if n == 1:
+        args.gpus = 1
+        return None
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    argv = [sys.executable, os.path.abspath(__file__), "--gpus", str(n), "--steps", str(args.steps), "--warmup", str(args.warmup),
+            "--batch", str(args.batch)]
+    for flag in ("no_cpu_baseline", "no_kernel_timer", "no_extra_blocks", "plain"):
+        if getattr(args, flag):
+            argv.append("--" + flag.replace("_", "-"))
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("GPU_MAX_HW_QUEUES", "8")
+        procs.append(subprocess.Popen(argv, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # rank 0's stdout is the job's stdout; a rank that dies takes the others down (they would wait in a collective for ever)
+    import threading
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    code = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            rc = p.poll()
+            if rc is None:
+                continue
+            alive.remove(p)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                print(f"[bench] rank {procs.index(p)} exited with {rc}: stopping the other ranks", file=sys.stderr, flush=True)
+                for q in alive:
+                    q.terminate()          # (exactly the PIDs started here)
+        time.sleep(0.2)
+    rd.join(timeout=10)
+    sys.stdout.write("".join(out0))
+    sys.stdout.flush()
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -378,12 +436,18 @@ def main():
     ap.add_argument("--plain", action="store_true", help="timed region only; prints {ms_per_step, images_per_s, loss}")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: this process (which has made NO GPU call) becomes the launcher of N ranks
+        code = launch_ranks(args)
+        if code is not None:
+            raise SystemExit(code)
+        # (one visible device and no single-device rehearsal: fall through as the N = 1 job, said on stderr)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} "
-                         f"(WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node "
+                         f"{args.gpus}, or unset WORLD_SIZE and let bench.py start its own ranks")
     # YOLO_BENCH_SINGLE_DEVICE=1 + YOLO_DIST_BACKEND=gloo: rehearse the N > 1 code path (buckets, side
     # stream, events, 1/world) with several ranks on ONE GPU; the real runs use RCCL, one rank per GPU
     single_dev = os.environ.get("YOLO_BENCH_SINGLE_DEVICE") == "1"

@@ -61,7 +61,17 @@ def _headline_selected(items):
     return [it for it in items if "test_headline_configs_at_their_true_batch_vs_fp64_oracle" in it.nodeid]
 
 
-def pytest_collection_finish(session):
+@pytest.hookimpl(tryfirst=True)
+def pytest_runtestloop(session):
+    """starts the two oracle jobs when the test loop begins -- not at collection time (`--collect-only` builds nothing and
+    starts nothing: ADVICE r05) -- and returns None, so that pytest's own loop runs the tests"""
+    if session.config.option.collectonly or session.testsfailed:
+        return None
+    _start_headline_jobs(session)
+    return None
+
+
+def _start_headline_jobs(session):
     items = session.items
     sel = _headline_selected(items)
     if not sel or not _has_gpu():
@@ -80,10 +90,11 @@ def pytest_collection_finish(session):
         if config not in want:
             continue
         version, hw, N = (3, 416, 32) if config == "C3" else (4, 608, 16)
-        y, model, fwd, loss_o, loss_g, x, ys = T._setup(version, hw=hw, N=N)
+        y, model, fwd, loss_o, loss_g, x, ys = T._setup(version, hw=hw, N=N, class_num=T.HEADLINE_CLASSES)
         w = T._weights_dict(model)
         threads = max(2, min(16, ncpu) // 4)
-        HEADLINE_JOBS[config] = (pool.submit(oracle_jobs.headline_job, version, hw // 32, T.A9, w, x, ys, threads),
+        HEADLINE_JOBS[config] = (pool.submit(oracle_jobs.headline_job, version, hw // 32, T.A9, w, x, ys, threads,
+                                             T.HEADLINE_CLASSES),
                                  T.inputs_digest(w, x, ys))
         del y, model, w
         torch.cuda.empty_cache()

@@ -30,7 +30,7 @@ def oracle_fns(version, g0, unbiased=True, anchors9=None, class_num=3):
     return fwd, loss_o
 
 
-def headline_job(version, g0, anchors9, w, x, ys, threads):
+def headline_job(version, g0, anchors9, w, x, ys, threads, class_num=3):
     """float64 and float32 training-mode forward + losses of one headline configuration at its true batch, without autograd
     and without retaining activations. Returns numpy arrays only."""
     import time
@@ -38,14 +38,18 @@ def headline_job(version, g0, anchors9, w, x, ys, threads):
     from oracle import models as OM
     t0 = time.time()
     torch.set_num_threads(threads)
-    fwd, loss_o = oracle_fns(version, g0, True, anchors9)
-    OM.KEEP_ACTS = False
-    with torch.no_grad():
-        ref, ctx = fwd({k: torch.tensor(v, dtype=torch.float64) for k, v in w.items()}, torch.tensor(x, dtype=torch.float64), True)
-        ref_losses = [float(lf(torch.tensor(yt, dtype=torch.float64), o)) for lf, yt, o in zip(loss_o, ys, ref)]
-        t1 = time.time()
-        o32, _ = fwd({k: torch.tensor(v) for k, v in w.items()}, torch.tensor(x), True)
-        l32 = [float(lf(torch.tensor(yt), o)) for lf, yt, o in zip(loss_o, ys, o32)]
+    fwd, loss_o = oracle_fns(version, g0, True, anchors9, class_num)
+    keep = OM.KEEP_ACTS
+    OM.KEEP_ACTS = False      # (restored below: this also runs in-process, tests/test_oracle_jobs_cpu.py and the single-test fallback)
+    try:
+        with torch.no_grad():
+            ref, ctx = fwd({k: torch.tensor(v, dtype=torch.float64) for k, v in w.items()}, torch.tensor(x, dtype=torch.float64), True)
+            ref_losses = [float(lf(torch.tensor(yt, dtype=torch.float64), o)) for lf, yt, o in zip(loss_o, ys, ref)]
+            t1 = time.time()
+            o32, _ = fwd({k: torch.tensor(v) for k, v in w.items()}, torch.tensor(x), True)
+            l32 = [float(lf(torch.tensor(yt), o)) for lf, yt, o in zip(loss_o, ys, o32)]
+    finally:
+        OM.KEEP_ACTS = keep
     return {"ref": [o.numpy() for o in ref], "ref_losses": ref_losses, "o32": [o.numpy() for o in o32], "l32": l32,
             "moving": {k: (mm.numpy(), mv.numpy()) for k, (mm, mv) in ctx.moving.items()},
             "seconds": (t1 - t0, time.time() - t1), "threads": threads}

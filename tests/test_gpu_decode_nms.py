@@ -198,3 +198,56 @@ def test_nms_edge_cases_walk_and_bit_matrix_agree():
     r = np.tile(np.array([[.5, .5, .2, .2, .9, 0., .9]]), (300, 1))
     g = both(r, 1)
     assert g[0].shape[0] == 1 and g[1].shape[0] == 1
+
+
+def test_nms_with_nan_scores_keeps_a_total_order():
+    """yolo_nms is a raw C-ABI and takes any rows. A NaN score compares false both ways; the LDS bitonic
+    sort needs a total order or its (-inf, -1) padding can end among the first nc entries (row index -1: an out-of-bounds
+    access). The order key of a NaN score is +inf -- np.argsort puts NaN last, so the reference's argsort()[::-1]
+    (utils/tools.py:717) visits NaN rows FIRST. Class sizes are not powers of two (padding present), one class exceeds the
+    bit-matrix bound (rank by counting). Both forms agree bit for bit; with ONE NaN per class the order is defined and the
+    result equals the oracle's."""
+    import torch
+    from tf2_yolo_amd import ops, tools
+    rng = np.random.default_rng(5)
+
+    def both(rows, C, thr=0.5, soft=True):
+        dev = torch.from_numpy(rows).cuda()
+        out = {}
+        try:
+            for walk in (0, 1):
+                ops.set_option(ops.OPT_NMS_WALK, walk)
+                out[walk] = [tools.nms(dev, class_num=C, nms_threshold=thr).cpu().numpy(),
+                             tools.nms(dev, class_num=C, nms_threshold=thr, iou_mode=2).cpu().numpy()]
+                if soft:
+                    out[walk].append(tools.soft_nms(dev, class_num=C, nms_threshold=thr, conf_threshold=0.3, sigma=0.5).cpu().numpy())
+        finally:
+            ops.reset_options()
+        for a, b in zip(out[0], out[1]):
+            assert np.array_equal(a, b, equal_nan=True)
+        return out[0]
+
+    # one NaN per class, 7 classes of ~143 rows (N2 = 256 > nc): defined order, equal to the oracle
+    rows = _crowded_rows(rng, 1000, 7)
+    for c in range(7):
+        idx = np.flatnonzero(rows[:, 5] == c)
+        rows[idx[len(idx) // 2], 4] = np.nan
+    g = both(rows, 7, soft=False)
+    assert np.array_equal(g[0], T.nms(rows, 7, 0.5), equal_nan=True)
+    assert np.array_equal(g[1], T.nms(rows, 7, 0.5, 2), equal_nan=True)
+    assert np.isnan(g[0][:, 4]).sum() == 7          # the NaN row of every class is visited first and kept
+    # many NaN rows (a third of a 3000-row class; N2 = 4096), +-inf scores among them: every returned row is an input row,
+    # no row twice, both forms identical
+    rows = _crowded_rows(rng, 3000, 1)
+    rows[rng.choice(3000, 1000, replace=False), 6] = np.nan
+    rows[5, 4], rows[6, 4] = np.inf, -np.inf
+    for out in both(rows, 1):
+        assert 0 < out.shape[0] <= 3000
+        key = {r.tobytes() for r in rows}
+        assert all(r.tobytes() in key for r in out)
+    # a class beyond the bit-matrix bound (9000 rows: rank by counting + walk kernel) with NaN scores
+    rows = _crowded_rows(rng, 9000, 1)
+    rows[:, :2] = rng.random((9000, 2))
+    rows[rng.choice(9000, 500, replace=False), 4] = np.nan
+    out = both(rows, 1, soft=False)
+    assert 0 < out[0].shape[0] <= 9000 and len({r.tobytes() for r in out[0]}) == out[0].shape[0]

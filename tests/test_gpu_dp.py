@@ -68,6 +68,26 @@ def test_two_ranks_on_one_gpu_stay_in_sync_over_gloo(mode):
         assert all(d - r >= 1.0 for mb, r, d in buckets if mb >= 10.0), buckets
 
 
+def test_bench_starts_its_own_ranks_without_a_torchrun_environment():
+    """`python3 bench.py --gpus 2` as the driver's N = 1 line is called, no torchrun, no RANK / WORLD_SIZE: the parent (which
+    makes no GPU call) starts two fresh rank processes, relays rank 0's JSON line and exits with the ranks' status. Here the two
+    ranks share the one GPU of the test box over gloo (YOLO_BENCH_SINGLE_DEVICE=1); on an N-GPU node the same launcher puts one
+    rank on each device over RCCL. A failing rank makes the launcher exit non-zero."""
+    env = _env(YOLO_BENCH_SINGLE_DEVICE="1", YOLO_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2"] + ARGS, cwd=ROOT, env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _json_line(r.stdout)
+    assert j["n_gpus"] == 2 and j["config"]["global_batch"] == 8 and j["scaling"] == "weak"
+    assert j["config"]["replicas_in_sync"] is True
+    assert "GPU_MAX_HW_QUEUES=8 does not apply" not in r.stderr
+    bad = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--batch", "-1"] + ARGS[:4], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0
+
+
 def test_dp_step_timing_and_bucket_readiness_at_the_benchmark_batch():
     """The benchmark configuration (bs 32, launch tape) plain and with RCCL in a forced world of one rank -- side-stream
     all-reduces of every bucket, the waits on both gradient streams, the tape's host calls; one run of each, with a bound
@@ -78,22 +98,21 @@ def test_dp_step_timing_and_bucket_readiness_at_the_benchmark_batch():
     The first gradient bucket must be ready within 5 ms of the start of backward (measured ~2 ms), and the buckets cover
     every trainable parameter of the model."""
     args = ["--steps", "8", "--warmup", "3", "--no-cpu-baseline", "--no-kernel-timer", "--no-extra-blocks"]
-    ms = {"plain": [], "forced": []}
     last = {}
-    for rep in range(1):
-        for kind, env in (("plain", _env()),
-                          ("forced", _env(YOLO_DP_FORCE="1", MASTER_PORT=str(29547 + rep), RANK="0", WORLD_SIZE="1",
-                                          LOCAL_RANK="0"))):
-            r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, cwd=ROOT, env=env, capture_output=True,
-                               text=True, timeout=600)
-            assert r.returncode == 0, r.stderr[-3000:]
-            last[kind] = _json_line(r.stdout)
-            ms[kind].append(last[kind]["ms_per_step"])
+    for kind, env in (("plain", _env()),
+                      ("forced", _env(YOLO_DP_FORCE="1", MASTER_PORT="29547", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))):
+        r = subprocess.run([sys.executable, "bench.py", "--gpus", "1"] + args, cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        last[kind] = _json_line(r.stdout)
     a, b = last["plain"], last["forced"]
-    print("plain", ms["plain"], "ms; forced RCCL world 1", ms["forced"], "ms;", b["dp_trace"]["buckets"])
+    print("plain", a["ms_per_step"], "ms; forced RCCL world 1", b["ms_per_step"], "ms;", b["dp_trace"]["buckets"])
     assert b["config"]["step_launch_mode"].startswith("launch tape")
     assert b["config"]["replicas_in_sync"] is True and b["n_gpus"] == 1
-    assert min(ms["forced"]) <= 1.10 * min(ms["plain"]), ms
+    # the data-parallel tape step computes the SAME step as the plain one at the benchmark batch (same seeds, same 11 steps)
+    assert abs(a["config"]["loss"] - b["config"]["loss"]) <= 1e-3 * abs(a["config"]["loss"]), (a["config"], b["config"])
+    # ONE pair of runs on one box: 10 % covers the run-to-run drift (measured cost +1 %; the fault this guards against: +13 %)
+    assert b["ms_per_step"] <= 1.10 * a["ms_per_step"], (a["ms_per_step"], b["ms_per_step"])
     buckets = b["dp_trace"]["buckets"]
     from tf2_yolo_amd import engine, graphs
     n_train, _ = engine.count_params(graphs.build_yolov3((416, 416, 3), 80))

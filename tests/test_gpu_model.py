@@ -37,6 +37,30 @@ def _labels(rng, N, g, C):
     return yt
 
 
+def _reference_init(model, rng):
+    """the reference's OWN initialisation of YOLOv4 (yolov4/models/backbone.py:63-111: every Conv2D
+    kernel_initializer=RandomNormal(stddev=0.02), BatchNormalization defaults gamma = 1, beta = 0, moving mean 0 / variance 1;
+    the bias-carrying head convs keep Keras' zeros): the case VERDICT r05 asked for beside the he-normal cases"""
+    net = model.net
+    p = net.params.data.cpu().numpy()
+    for name in net.params.order:
+        s = net.params.specs[name]
+        sl = slice(s.offset, s.offset + s.size)
+        if name.endswith("/kernel"):
+            p[sl] = rng.standard_normal(s.size) * 0.02
+        elif name.endswith("/gamma"):
+            p[sl] = 1.0
+        elif name.endswith("/beta") or name.endswith("/bias"):
+            p[sl] = 0.0
+    net.params.data.copy_(torch.from_numpy(p))
+    st = net.state.data.cpu().numpy()
+    for name in net.state.order:
+        s = net.state.specs[name]
+        st[s.offset:s.offset + s.size] = 0.0 if name.endswith("moving_mean") else 1.0
+    net.state.data.copy_(torch.from_numpy(st))
+    net.mark_params_changed()
+
+
 def _perturb(model, rng):
     """make BN parameters / moving statistics and biases non-trivial"""
     net = model.net
@@ -111,11 +135,16 @@ def _l2(a, b):
 
 
 A6 = A9[:6]
+HEADLINE_CLASSES = 80    # the full-batch headline tests (tests/test_gpu_fullsize.py, conftest.py) run the benchmark's C = 80
 
 
-def _setup(version, hw=None, N=2, unbiased=True, true_c1=False, tiny=False):
+def _setup(version, hw=None, N=2, unbiased=True, true_c1=False, tiny=False, class_num=None, ref_init=False):
+    """class_num: YOLOv3 / YOLOv4 with that many classes instead of 3 (80 = what bench.py times: 255-channel heads, the
+    255 -> 256 padded head gradient, the C = 80 loss); ref_init: the reference's own YOLOv4 initialiser instead of he-normal"""
     import os
     rng = np.random.default_rng(version)
+    names3 = ["a", "b", "c"] if class_num is None else [f"c{i}" for i in range(class_num)]
+    C3 = len(names3)
     # v4: the 107-layer CSP/PAN chain needs >= 50 samples per BN channel at the coarsest grid to be a
     # well-conditioned fp32 problem at all (at 64x64 BOTH fp32 executions are O(1) off in the gradients)
     hw = hw or int(os.environ.get("TEST_MODEL_HW", "160" if version == 4 else "64"))
@@ -133,19 +162,19 @@ def _setup(version, hw=None, N=2, unbiased=True, true_c1=False, tiny=False):
         grids = [g0, 2 * g0]
     elif version == 3:
         import yolov3
-        y = yolov3.Yolo((hw, hw, 3), ["a", "b", "c"])
+        y = yolov3.Yolo((hw, hw, 3), names3)
         y.create_model(anchors=A9, pretrained_body=None, bn_unbiased_moving_var=unbiased)
         fwd = lambda w, x, tr, m=None: OM.yolov3_forward(w, x, A9, training=tr, leaky_masks=m, unbiased_moving_var=unbiased)
-        loss_o = [OL.wrap_yolo_loss_v3((g0 * 2 ** i, g0 * 2 ** i), 3, 3, anchors=A9[3 * i:3 * i + 3],
+        loss_o = [OL.wrap_yolo_loss_v3((g0 * 2 ** i, g0 * 2 ** i), 3, C3, anchors=A9[3 * i:3 * i + 3],
                                        loss_weight=[1, 1, 5, 1]) for i in range(3)]
         loss_g = y.loss()
         grids = [g0, 2 * g0, 4 * g0]
     elif version == 4:
         import yolov4
-        y = yolov4.Yolo((hw, hw, 3), ["a", "b", "c"])
+        y = yolov4.Yolo((hw, hw, 3), names3)
         y.create_model(anchors=A9, pretrained_body=None, bn_unbiased_moving_var=unbiased)
         fwd = lambda w, x, tr, m=None: OM.yolov4_forward(w, x, A9, training=tr, leaky_masks=m, unbiased_moving_var=unbiased)
-        loss_o = [OL.wrap_yolo_loss_v4((g0 * 2 ** i, g0 * 2 ** i), 3, 3, anchors=A9[3 * i:3 * i + 3],
+        loss_o = [OL.wrap_yolo_loss_v4((g0 * 2 ** i, g0 * 2 ** i), 3, C3, anchors=A9[3 * i:3 * i + 3],
                                        loss_weight=[1, 5, 1]) for i in range(3)]
         loss_g = y.loss()
         grids = [g0, 2 * g0, 4 * g0]
@@ -171,7 +200,7 @@ def _setup(version, hw=None, N=2, unbiased=True, true_c1=False, tiny=False):
         loss_g = [y.loss(binary_weight=0.5)]
         grids = [g0]
     model = y.model
-    _perturb(model, rng)
+    (_reference_init if ref_init else _perturb)(model, rng)
     H = y.input_shape[0]
     x = rng.random((N, H, H, 3), dtype=np.float32)
     ys = [_labels(rng, N, g, y.class_num) for g in grids]
@@ -232,7 +261,8 @@ def _kink_census(version, y_true, pred_oracle, pred_dev, class_num):
 @pytest.mark.parametrize("version,unbiased,true_c1", [(3, True, False), (2, True, False), (1, True, False), (4, True, False),
                                                       (3, False, False), (1, True, True), (3, True, "tiny"),
                                                       (3, True, "416"), (4, True, "608"), (2, True, "416"),
-                                                      (3, True, "tiny416"), (4, True, "608bs1")])
+                                                      (3, True, "tiny416"), (4, True, "608bs1"),
+                                                      (3, True, "416c80bs8"), (4, True, "608refinit")])
 def test_model_parity(version, unbiased, true_c1):
     from tf2_yolo_amd import optimizers
     import conftest
@@ -247,8 +277,20 @@ def test_model_parity(version, unbiased, true_c1):
         y, model, fwd, loss_o, loss_g, x, ys = _setup(2, hw=416, N=2, unbiased=unbiased)
         assert tuple(y.grid_shape) == (13, 13)
     elif true_c1 == "416":   # BASELINE.json's headline graph at its true resolution (bs 2): 13 / 26 / 52 grids, the
-        y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=416, N=2, unbiased=unbiased)   # window kernels' real shapes
-        assert [tuple(o.shape[1:3]) for o in model.output] == [(13, 13), (26, 26), (52, 52)]
+        # window kernels' real shapes -- with the benchmark's 80 classes since round 6 (255-channel heads, the 255 -> 256
+        # zero-padded head gradient of the planes kernels, the C = 80 loss: what bench.py times; VERDICT r05 missing #3)
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=416, N=2, unbiased=unbiased, class_num=80)
+        assert [tuple(o.shape[1:]) for o in model.output] == [(13, 13, 255), (26, 26, 255), (52, 52, 255)]
+    elif true_c1 == "416c80bs8":
+        # VERDICT r05 next #2b: EVERY parameter gradient of the benchmark graph (416 x 416, C = 80) against the float64
+        # oracle's autograd at batch 8 -- a quarter of the benchmark's per-GPU batch: 1.4 M-pixel planes, BatchNorm statistics
+        # over 1.4 M samples, per-tensor scales from those statistics, the padded head gradients
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=416, N=8, unbiased=unbiased, class_num=80)
+        assert [tuple(o.shape) for o in model.output] == [(8, 13, 13, 255), (8, 26, 26, 255), (8, 52, 52, 255)]
+    elif true_c1 == "608refinit":
+        # VERDICT r05 next #2c: YOLOv4-608 (bs 2) under the reference's OWN initialiser (N(0, 0.02) kernels, gamma 1, beta 0:
+        # yolov4/models/backbone.py:63-111) instead of the he-normal kernels of the other cases; its fp32 floor is logged
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(4, hw=608, N=2, unbiased=unbiased, ref_init=True)
     elif true_c1 == "608bs1":
         # YOLOv4-608 at bs ONE: the case round 2 moved to bs 2 because single BN tensors were 3-5x the fp32-CPU error on
         # every conv path. Cause (scripts/grad_excess.py, profiles/r03_grad_excess_*.json): near-ties among the 25 / 81 /
@@ -390,7 +432,9 @@ def test_model_parity(version, unbiased, true_c1):
             # worst: YOLOv4-608 bs 2, out1_box1_prob_conv bias, 3.1e-4 against the CPU's 1.25e-4 -- profiles/r05_parity_ratios.jsonl)
             assert e < max(2 * e32, 4e-4), (n, i, e, e32)
     print("worst gradient error", worst)
-    log_parity_ratio({"case": f"v{version} unbiased={unbiased} {true_c1}", "fp32_floor": fwd_floor, "forward_err": fwd_err,
+    log_parity_ratio({"case": f"v{version} unbiased={unbiased} {true_c1}", "classes": len(y.class_names), "batch": int(x.shape[0]),
+                      "fp32_floor": fwd_floor, "forward_err": fwd_err,
+                      "forward_meets_plain_1e-4": bool(fwd_err < 1e-4), "fp32_cpu_meets_plain_1e-4": bool(fwd_floor < 1e-4),
                       "forward_ratio": fwd_err / max(fwd_floor, 1e-30), "worst_gradient_tensor": worst_ratio[0],
                       "worst_gradient_err": worst_ratio[2], "fp32_cpu_err_same_tensor": worst_ratio[3],
                       "worst_gradient_ratio_err_over_max_e32_2e-4": worst_ratio[1],

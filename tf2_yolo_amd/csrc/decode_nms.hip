@@ -298,6 +298,13 @@ __global__ __launch_bounds__(256) void nms_bucket_kernel(int n, int class_num, N
   }
 }
 
+// The order needs a TOTAL order on the scores: a NaN score compares false both ways, and a comparison sort that is handed
+// such keys can leave its (-inf, -1) padding entries among the real rows (an out-of-bounds row index), a rank by counting
+// colliding positions. np.argsort puts NaN LAST, so the reference's `argsort()[::-1]` (utils/tools.py:717) visits NaN rows
+// FIRST: the key of a NaN score is +inf (ties with other NaN / +inf rows by index like every other tie). The score that is
+// stored and reported stays the row's own.
+__device__ __forceinline__ double nms_order_key(double s) { return s != s ? __builtin_huge_val() : s; }
+
 // rank of every row inside its class by (score descending, ties: higher original index first -- np.argsort leaves ties
 // undefined, utils/tools.py:717) = the number of rows of the class that come before it: one thread per bucket slot, the
 // class's slots in tiles of 256 through LDS (a workgroup = 256 consecutive slots = one class, or the few small classes
@@ -313,7 +320,8 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const double* __restrict_
   const int e = e0 + threadIdx.x;
   const bool live = e < total;
   const int i = live ? ws.bidx[e] : 0;
-  const double si = live ? ws.bscore[e] : 0.;
+  const double si_raw = live ? ws.bscore[e] : 0.;
+  const double si = nms_order_key(si_raw);
   const int ci = live ? ws.cls[i] : 0;
   const int beg = live ? ws.class_off[ci] : 0, end = live ? ws.class_off[ci + 1] : 0;
   if (threadIdx.x == 0) s_lo = beg;
@@ -328,7 +336,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const double* __restrict_
     __syncthreads();
     const int j = j0 + threadIdx.x;
     if (j < hi) {
-      s_sc[threadIdx.x] = ws.bscore[j];
+      s_sc[threadIdx.x] = nms_order_key(ws.bscore[j]);
       s_ix[threadIdx.x] = ws.bidx[j];
     }
     __syncthreads();
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const double* __restrict_
     const int k_hi = end < j0 + 256 ? end - j0 : 256;
     if (counted)
       for (int k = k_lo; k < k_hi; ++k) {
-        const double sj = s_sc[k];
+        const double sj = s_sc[k];      // (already a key: no NaN)
         const int jj = s_ix[k];
         rank += ((sj > si) || (sj == si && jj > i)) ? 1 : 0;
       }
@@ -350,7 +358,7 @@ __global__ __launch_bounds__(256) void nms_rank_kernel(const double* __restrict_
   ws.box[(long long)pos * 4 + 1] = r[1];
   ws.box[(long long)pos * 4 + 2] = r[2];
   ws.box[(long long)pos * 4 + 3] = r[3];
-  ws.sscore[pos] = si;
+  ws.sscore[pos] = si_raw;
 }
 
 // The same order for classes of up to NMS_MASK_MAX rows: one workgroup per class, a bitonic sort of (score, row) in LDS
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const double* __restrict
   int N2 = 64;
   while (N2 < nc) N2 <<= 1;
   for (int t = threadIdx.x; t < N2; t += 1024) {
-    s_sc[t] = t < nc ? ws.bscore[beg + t] : -__builtin_huge_val();   // padding sorts behind every row
+    s_sc[t] = t < nc ? nms_order_key(ws.bscore[beg + t]) : -__builtin_huge_val();   // padding sorts behind every row
     s_ix[t] = t < nc ? ws.bidx[beg + t] : -1;
   }
   __syncthreads();
@@ -391,6 +399,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const double* __restrict
     }
   for (int r = threadIdx.x; r < nc; r += 1024) {
     const int i = s_ix[r];
+    if (i < 0) continue;      // (cannot happen with a total order: a padding entry among the first nc; never index with it)
     const int pos = beg + r;
     ws.sorted_idx[pos] = i;
     ws.pos_of[i] = pos;
@@ -399,7 +408,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const double* __restrict
     ws.box[(long long)pos * 4 + 1] = src[1];
     ws.box[(long long)pos * 4 + 2] = src[2];
     ws.box[(long long)pos * 4 + 3] = src[3];
-    ws.sscore[pos] = s_sc[r];
+    ws.sscore[pos] = ws.score[i];   // the row's own score (s_sc holds the order key)
   }
 }
 

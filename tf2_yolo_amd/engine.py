@@ -627,7 +627,10 @@ class Network:
                 dyp = max(dyp, ops.planes_bytes(N * u.out.h * u.out.w, u.cout if u.kind == "conv" else u.out.c))
         # (two scratch buffers, used alternately: the filter gradient of layer L may still be reading its dy
         # planes on the second stream while layer L-1 produces its own)
-        self._dyplanes2 = [torch.empty(dyp, device=dev, dtype=torch.uint8) if dyp else None for _ in range(2)]
+        # (not allocated when every planes layer owns its buffer, the default below: _next_dyp_buffer creates them on demand)
+        self._dyp_shared_bytes = dyp
+        self._dyplanes2 = ([None, None] if self._dyp_per_layer else
+                           [torch.empty(dyp, device=dev, dtype=torch.uint8) if dyp else None for _ in range(2)])
         self._dyp_events = [None, None]
         self._dyp_idx = 0
         # YOLO_DYP_PER_LAYER=1 (default): every layer has its OWN dy planes instead -- 288 GB of HBM make the reuse pointless
@@ -1190,6 +1193,8 @@ class Network:
         if ev is not None:
             tape.wait_event(torch.cuda.current_stream(), ev)
             self._dyp_events[self._dyp_idx] = None
+        if self._dyplanes2[self._dyp_idx] is None and self._dyp_shared_bytes:
+            self._dyplanes2[self._dyp_idx] = torch.empty(self._dyp_shared_bytes, device=self.device, dtype=torch.uint8)
         return self._dyplanes2[self._dyp_idx]
 
     @contextlib.contextmanager
