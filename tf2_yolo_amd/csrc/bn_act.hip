@@ -761,6 +761,7 @@ extern "C" int yolo_bn_finalize_offset(double* stats, long long P, int C, const 
                "bn_finalize: bad args");
   YOLO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must come in pairs");
   static_assert(YOLO_BN_STAT_SLOTS == 64, "bn_finalize_kernel: one lane per replica slot");
+  if (!(g_opt[OPT_EXP] & 2))
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, as_stream(stream), stats, P, C, gamma,
                      beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var, scale, shift, save_mean,
                      save_invstd, absmax, bound, mean_offset);
@@ -870,6 +871,7 @@ extern "C" int yolo_bn_act_bwd_reduce_bound_ld(const float* x, const float* dout
   dim3 grid(gx, (C / 4 + g.cw - 1) / g.cw);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, dout, ldd, P, C, g.cw, g.rpp, scale,
                      shift, save_mean, save_invstd, act, red, bound_aux);
+  if (!(g_opt[OPT_EXP] & 1))
   hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), C, red, gx, P, scale,
                      bound_aux);
   return check_launch("bn_bwd_reduce_kernel");
