@@ -369,6 +369,18 @@ int yolo_bn_act_bwd_apply_planes(const float* x, const float* dout, long long P,
 int yolo_bn_act_bwd_reduce_bound_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
                                     const float* scale, const float* shift, const float* save_mean,
                                     const float* save_invstd, int act, double* red, unsigned* bound_aux, void* stream);
+/* yolo_bn_act_bwd_reduce_bound_ld in ONE launch (round 6): the workgroups that arrive last fold the per-workgroup slots
+ * themselves, in slot order (bit-reproducible; two levels of ticket words, agent-scope relaxed atomics instead of cache-wide
+ * fences: csrc/bn_act.hip), instead of a second launch doing it -- 72 launches fewer in a YOLOv3 backward pass
+ * (yolov3/models/backbone.py:27-55: one BatchNormalization per DarknetConv2D_BN_Leaky). Measured neutral on the step
+ * (DESIGN.md section 3.4): the executor keeps the two-launch form unless YOLO_BN_FOLD=1. tickets:
+ * YOLO_BN_FOLD_TICKET_WORDS uint32, zeroed by the caller before the FIRST use (the kernel leaves them zero); NULL, or more
+ * than 1024 channels: the two-launch form. */
+#define YOLO_BN_FOLD_TICKET_WORDS 36
+int yolo_bn_act_bwd_reduce_fold_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
+                                   const float* scale, const float* shift, const float* save_mean,
+                                   const float* save_invstd, int act, double* red, unsigned* bound_aux,
+                                   unsigned* tickets, void* stream);
 int yolo_bn_act_bwd_apply_planes_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
                                     const float* gamma, const float* scale, const float* shift, const float* save_mean,
                                     const float* save_invstd, int act, double* red, float* dgamma, float* dbeta,

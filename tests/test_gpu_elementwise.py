@@ -402,3 +402,59 @@ def test_split_planes_concat(chans):
     pl2 = torch.zeros_like(pl)
     ops.split_planes_concat(srcs, list(chans), bounds, rows, pl2)
     assert torch.equal(pl, pl2)
+
+
+@pytest.mark.parametrize("P,C,act", [(32 * 52 * 52, 256, 1), (32 * 13 * 13, 1024, 1), (4 * 19 * 19, 512, 2), (2 * 7 * 5, 32, 1),
+                                     (16 * 26 * 26 + 3, 48, 1), (32 * 104 * 104, 64, 1)])
+def test_bn_backward_reduction_finished_by_its_own_launch(P, C, act):
+    """yolo_bn_act_bwd_reduce_fold_ld (round 6): the BatchNormalization-backward reduction in ONE launch -- the workgroups that
+    arrive last fold the per-workgroup slots, two levels of ticket words -- against the two-launch form
+    (bn_bwd_reduce + bn_bwd_sum): the final fp64 sums agree to 1e-13 of their magnitude (another fixed summation order), the
+    bound words agree, dx / its planes are equal to float rounding, the ticket words are back at zero, and two runs are
+    BIT-identical (who arrives last changes nothing in the arithmetic). Sizes: the benchmark's 52x52x256 and 13x13x1024
+    layers at bs 32 (512 workgroups: 32 full groups), a 208x208-sized tensor, and small / ragged ones (one group, a partial
+    last group, fewer workgroups than a group holds)."""
+    from tf2_yolo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(P % 1000 + C + act)
+    dev = "cuda"
+    x = torch.randn(P, C, device=dev, generator=g) * 2 + 0.3
+    dout = torch.randn(P, C, device=dev, generator=g) * 1e-3
+    gd = torch.rand(C, device=dev, generator=g) + 0.5
+    bd = torch.randn(C, device=dev, generator=g)
+    stats = torch.zeros(64 * 2 * C, device=dev, dtype=torch.float64)
+    f = lambda: torch.empty(C, device=dev)
+    scale, shift, smean, sinv = f(), f(), f(), f()
+    ops.bn_stats(x, C, stats)
+    ops.bn_finalize(stats, P, C, gd, bd, None, None, scale, shift, smean, sinv)
+
+    def run(fold):
+        red = torch.full(((ops.BN_RED_SLOTS + 1) * 2 * C,), float("nan"), device=dev, dtype=torch.float64)   # no slot is read unwritten
+        aux = torch.zeros(68 + ops.BN_FOLD_TICKET_WORDS, device=dev, dtype=torch.int32)
+        pl = torch.zeros(ops.planes_bytes(P, C), device=dev, dtype=torch.uint8) if C % 16 == 0 else None
+        dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+        dx = ops.bn_act_bwd(x, dout, C, gd, scale, shift, smean, sinv, act, red, dg, db, planes=pl, bound_aux=aux[:68],
+                            tickets=aux[68:] if fold else None)
+        torch.cuda.synchronize()
+        return red[ops.BN_RED_SLOTS * 2 * C:].clone(), aux.clone(), dx, pl, dg, db
+
+    two = run(False)
+    one = run(True)
+    again = run(True)
+    assert torch.isfinite(one[0]).all()
+    mag = two[0].abs().max().item()
+    assert (one[0] - two[0]).abs().max().item() <= 1e-13 * max(mag, 1e-300)
+    assert int(one[1][68:].abs().max()) == 0                       # tickets back at zero
+    a1, a2 = one[1][:3].view(torch.float32), two[1][:3].view(torch.float32)
+    assert a1[0] == a2[0] and torch.allclose(a1[1:], a2[1:], rtol=1e-6, atol=0)
+    assert torch.allclose(one[2], two[2], rtol=1e-5, atol=1e-9) and torch.allclose(one[4], two[4], rtol=1e-6, atol=1e-9)
+    for a, b in zip(one, again):                                   # run-to-run bit identity
+        if a is not None:
+            assert torch.equal(a, b)
+    # against a float64 evaluation of the two sums
+    xd, dd = x.double(), dout.double()
+    z = xd * scale.double() + shift.double()
+    if act == 1:
+        dz = dd * torch.where(z > 0, 1.0, 0.1)
+        ref0, ref1 = dz.sum(0), (dz * ((xd - smean.double()) * sinv.double())).sum(0)
+        assert (one[0][:C] - ref0).abs().max().item() <= 1e-5 * ref0.abs().max().item()
+        assert (one[0][C:] - ref1).abs().max().item() <= 1e-5 * ref1.abs().max().item()

@@ -706,3 +706,44 @@ def test_dy_planes_per_layer_or_shared_give_identical_gradients(monkeypatch):
         assert (len(net._dyp_own) > 50) == (mode == "1")
         grads.append(net.grads.clone())
     assert torch.equal(grads[0], grads[1])
+
+
+@pytest.mark.parametrize("version", [3, 4])
+def test_bn_fold_option_gives_the_same_gradients(version, monkeypatch):
+    """YOLO_BN_FOLD=1 (the BatchNormalization-backward reduction finished by its own launch: include/yolo_hip.h,
+    yolo_bn_act_bwd_reduce_fold_ld) against the default two-launch form: same weights, same batch, one forward + loss +
+    backward, twice. Every parameter gradient within 1e-6 of the largest gradient of its tensor (the two forms add the same
+    fp64 partial sums in different fixed orders), and the folded form is bit-identical from run to run."""
+    import numpy as np
+    from tf2_yolo_amd import graphs, labels
+    import yolov3, yolov4
+    hw, cls = 96, 5
+    x_h, ys_h = labels.synthetic_batch(np.random.default_rng(12), 3, (hw, hw), cls)
+    x = torch.from_numpy(x_h).cuda()
+    ys = [torch.from_numpy(y).cuda() for y in ys_h]
+    res = []
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("YOLO_BN_FOLD", mode)
+        if version == 3:
+            y = yolov3.Yolo((hw, hw, 3), [f"c{i}" for i in range(cls)])
+            y.create_model(pretrained_body=None, seed=5)
+        else:
+            y = yolov4.Yolo((hw, hw, 3), [f"c{i}" for i in range(cls)])
+            y.create_model(anchors=graphs.V4_DEFAULT_ANCHORS, pretrained_body=None, seed=5)
+        net, lossf = y.model.net, y.loss()
+        assert bool(net._bn_fold) == (mode == "1")
+        for _ in range(2):      # the second pass re-uses the ticket words the first one left at zero
+            outs = net.forward(x, training=True)
+            dpred = [torch.empty_like(o) for o in outs]
+            for i, (o, yt) in enumerate(zip(outs, ys)):
+                lossf[i].fwd_bwd(yt, o, grad_scale=1.0, dpred=dpred[i])
+            net.grads.zero_()
+            net.backward(dpred)
+        torch.cuda.synchronize()
+        res.append((net.grads.clone(), net))
+    (g0, net0), (g1, _), (g2, _) = res
+    assert torch.equal(g1, g2)
+    for name in net0.params.order:
+        s = net0.params.specs[name]
+        a, b = g0[s.offset:s.offset + s.size], g1[s.offset:s.offset + s.size]
+        assert (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30) < 1e-6, name

@@ -95,6 +95,7 @@ SIGNATURES = {
                                         _P, _P, _P]),
     "yolo_bn_act_bwd_reduce_bound": (c_int, [_P, _P, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
     "yolo_bn_act_bwd_reduce_bound_ld": (c_int, [_P, _P, _LL, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P, _P]),
+    "yolo_bn_act_bwd_reduce_fold_ld": (c_int, [_P, _P, _LL, _LL, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, _P]),
     "yolo_bn_act_bwd_apply_planes_ld": (c_int, [_P, _P, _LL, _LL, c_int, _P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P,
                                                 _P]),
     "yolo_bnred_slots_cap": (c_int, [POINTER(ConvDesc)]),

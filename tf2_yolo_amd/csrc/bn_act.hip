@@ -61,7 +61,10 @@ __device__ __forceinline__ void block_col_reduce(double (&v)[NQ][4], int cw, int
         double s = 0.0;
         for (int r = 0; r < rpp; ++r) s += smem[(q * 4 + e) * 256 + r * cw + col];
         if (EXCLUSIVE)   // slot blockIdx.x belongs to this workgroup alone (gridDim.x <= YOLO_BN_RED_SLOTS)
-          out[(long long)blockIdx.x * NQ * C + (long long)q * C + c4 * 4 + e] = s;
+          // (agent-scope store = written through to the memory side: the in-launch fold of bn_bwd_reduce_kernel<true> reads
+          // the slots from workgroups on other XCDs without any cache-wide fence)
+          __hip_atomic_store(&out[(long long)blockIdx.x * NQ * C + (long long)q * C + c4 * 4 + e], s, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
         else
           atomicAdd(&out[(long long)(blockIdx.x & (YOLO_BN_STAT_SLOTS - 1)) * NQ * C + (long long)q * C + c4 * 4 + e], s);
       }
@@ -190,13 +193,25 @@ __global__ __launch_bounds__(256) void bn_act_fwd_kernel(const float* __restrict
   }
 }
 
+// FOLD (round 6): the kernel also FINISHES the reduction -- what bn_bwd_sum_kernel did in a launch of its own (7.7 us + its
+// place in the compute queue, 72 times per step on the critical chain of backward). Two levels of "last workgroup to arrive":
+// the workgroups of a launch form groups of 16 consecutive blockIdx.x; the last of a group to arrive (ticket word of the
+// group) adds the group's 16 slots IN SLOT ORDER into the group's first slot; the last GROUP to finish (ticket word of the
+// column chunk) adds the group sums in group order into the final sums, makes the bound words and sets the tickets back to
+// zero. Who arrives last changes nothing in the arithmetic: bit-reproducible like the two-launch form (whose summation
+// order -- 16 strided partial sums -- it does not reproduce: the fp64 sums differ in their last bits). The slots cross
+// XCDs: release fence before a ticket, acquire fence behind it (as bn_bwd_sum_part_kernel / the stream-K window kernel).
+// tickets: 33 words per column chunk (blockIdx.y): [0] groups done, [1 + g] workgroups of group g done.
+constexpr int BN_FOLD_GROUP = 16;
+constexpr int BN_FOLD_TICKETS = 1 + YOLO_BN_RED_SLOTS / BN_FOLD_GROUP;   // per column chunk
+template <bool FOLD>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ dout, long long ldd, long long P, int C,
                                                             int cw, int rpp, const float* __restrict__ scale,
                                                             const float* __restrict__ shift,
                                                             const float* __restrict__ smean,
                                                             const float* __restrict__ sinv, int act,
-                                                            double* __restrict__ red, unsigned* __restrict__ aux) {
+                                                            double* red, unsigned* aux, unsigned* tickets) {
   __shared__ double smem[8 * 256];
   float mdz = 0.f;
   const int tid = threadIdx.x;
@@ -277,6 +292,108 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
       const float m = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
       if (m > 0.f) atomicMax(&aux[4 + ((blockIdx.x + blockIdx.y) & 63)], __builtin_bit_cast(unsigned, m));
     }
+  }
+  if constexpr (FOLD) {
+    // No cache-wide fences here: a release / acquire fence at agent scope writes back / invalidates the whole L2 of the XCD,
+    // and in the two-stream step that L2 is full of the OTHER stream's filter-gradient operands and slabs -- the first version
+    // of this fold (fence + ticket per workgroup) cost 6 ms per step. Instead every value that crosses workgroups is moved
+    // with agent-scope RELAXED atomics (sc1 loads / stores: through to the memory side, past the XCD's L2) and ordered by
+    // hand: my stores are complete (vmcnt(0)) before my workgroup's barrier, the barrier comes before the ticket.
+    __shared__ unsigned s_tk;
+    auto ld = [](const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto st = [](double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const int gx = (int)gridDim.x;
+    const int grp = (int)blockIdx.x / BN_FOLD_GROUP, ngrp = (gx + BN_FOLD_GROUP - 1) / BN_FOLD_GROUP;
+    const int gsz = (gx - grp * BN_FOLD_GROUP < BN_FOLD_GROUP) ? gx - grp * BN_FOLD_GROUP : BN_FOLD_GROUP;
+    unsigned* tk = tickets + (size_t)blockIdx.y * BN_FOLD_TICKETS;
+    const int c_lo = (int)blockIdx.y * cw * 4;
+    const int c_n = (C - c_lo < cw * 4) ? C - c_lo : cw * 4;      // this column chunk's channels
+    // ---- level 1: my slot (and my max|dz| atomic) is out; am I the last of my group? ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_tk = __hip_atomic_fetch_add(&tk[1 + grp], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_tk != (unsigned)(gsz - 1)) return;
+    {
+      const long long s0 = (long long)grp * BN_FOLD_GROUP;
+      for (int cc = tid; cc < c_n; cc += 256) {
+        const int c = c_lo + cc;
+        double v0[BN_FOLD_GROUP], v1[BN_FOLD_GROUP];
+#pragma unroll
+        for (int r = 0; r < BN_FOLD_GROUP; ++r) {   // all loads in flight together; slots past the group read slot s0 again
+          const long long sl = s0 + (r < gsz ? r : 0);
+          v0[r] = ld(&red[sl * 2 * C + c]);
+          v1[r] = ld(&red[sl * 2 * C + C + c]);
+        }
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < BN_FOLD_GROUP; ++r) {   // slot order
+          a0 += r < gsz ? v0[r] : 0.0;
+          a1 += r < gsz ? v1[r] : 0.0;
+        }
+        st(&red[s0 * 2 * C + c], a0);               // (the group's own first slot: nobody else reads the group's slots)
+        st(&red[s0 * 2 * C + C + c], a1);
+      }
+    }
+    if (tid == 0) __hip_atomic_store(&tk[1 + grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+    // ---- level 2: the group's sum is out; is mine the last group? ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_tk = __hip_atomic_fetch_add(&tk[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_tk != (unsigned)(ngrp - 1)) return;
+    for (int cc = tid; cc < ((c_n + 63) & ~63); cc += 256) {
+      float u1 = 0.f, u2 = 0.f;
+      if (cc < c_n) {
+        const int c = c_lo + cc;
+        double a0 = 0.0, a1 = 0.0;
+        int g = 0;
+        for (; g + 8 <= ngrp; g += 8) {             // eight groups (sixteen loads) in flight, added in group order
+          double v0[8], v1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            v0[u] = ld(&red[(long long)(g + u) * BN_FOLD_GROUP * 2 * C + c]);
+            v1[u] = ld(&red[(long long)(g + u) * BN_FOLD_GROUP * 2 * C + C + c]);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            a0 += v0[u];
+            a1 += v1[u];
+          }
+        }
+        for (; g < ngrp; ++g) {
+          a0 += ld(&red[(long long)g * BN_FOLD_GROUP * 2 * C + c]);
+          a1 += ld(&red[(long long)g * BN_FOLD_GROUP * 2 * C + C + c]);
+        }
+        red[(long long)YOLO_BN_RED_SLOTS * 2 * C + c] = a0;      // (read by the next launch: plain stores)
+        red[(long long)YOLO_BN_RED_SLOTS * 2 * C + C + c] = a1;
+        const double asc = fabs((double)scale[c]);
+        u1 = (float)asc;
+        u2 = (float)(asc * (fabs(a1 / (double)P) * sqrt((double)P) + fabs(a0 / (double)P)) * 1.001);
+      }
+      if (aux != nullptr) {   // per-channel parts of the bound of dx (bn_bwd_apply8_kernel)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          u1 = fmaxf(u1, __shfl_xor(u1, o, 64));
+          u2 = fmaxf(u2, __shfl_xor(u2, o, 64));
+        }
+        if ((tid & 63) == 0) {
+          atomicMax(&aux[1], __builtin_bit_cast(unsigned, u1));
+          atomicMax(&aux[2], __builtin_bit_cast(unsigned, u2));
+        }
+      }
+    }
+    if (aux != nullptr && tid < 64) {   // the 64 replica words of max|dz| (with several column chunks every chunk's last
+      // workgroup folds what is there: the maximum over all of them is the tensor's)
+      unsigned m = __hip_atomic_load(&aux[4 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned v = __shfl_xor(m, o, 64);
+        m = v > m ? v : m;
+      }
+      if (tid == 0 && m != 0u) atomicMax(&aux[0], m);
+    }
+    if (tid == 0) __hip_atomic_store(&tk[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -855,10 +972,10 @@ extern "C" int yolo_bn_act_fwd(const float* x, long long P, int C, const float* 
   return yolo_bn_act_fwd_planes(x, P, C, scale, shift, act, residual, out, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-extern "C" int yolo_bn_act_bwd_reduce_bound_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
-                                               const float* scale, const float* shift, const float* save_mean,
-                                               const float* save_invstd, int act, double* red, unsigned* bound_aux,
-                                               void* stream) {
+extern "C" int yolo_bn_act_bwd_reduce_fold_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
+                                              const float* scale, const float* shift, const float* save_mean,
+                                              const float* save_invstd, int act, double* red, unsigned* bound_aux,
+                                              unsigned* tickets, void* stream) {
   YOLO_REQUIRE(x && dout && scale && shift && save_mean && save_invstd && red && P > 0 && C > 0,
                "bn_act_bwd_reduce: bad args");
   YOLO_REQUIRE(C % 4 == 0, "bn_act_bwd_reduce: C=%d must be a multiple of 4", C);
@@ -869,12 +986,26 @@ extern "C" int yolo_bn_act_bwd_reduce_bound_ld(const float* x, const float* dout
   int gx = reduce_grid_x(P, g.rpp);
   if (gx > YOLO_BN_RED_SLOTS) gx = YOLO_BN_RED_SLOTS;   // every workgroup owns one slot of `red`
   dim3 grid(gx, (C / 4 + g.cw - 1) / g.cw);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, as_stream(stream), x, dout, ldd, P, C, g.cw, g.rpp, scale,
-                     shift, save_mean, save_invstd, act, red, bound_aux);
+  if (tickets != nullptr && (int)grid.y * BN_FOLD_TICKETS <= YOLO_BN_FOLD_TICKET_WORDS) {
+    // one launch: the last workgroups to arrive fold the slots (see the kernel)
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<true>, grid, dim3(256), 0, as_stream(stream), x, dout, ldd, P, C, g.cw, g.rpp,
+                       scale, shift, save_mean, save_invstd, act, red, bound_aux, tickets);
+    return check_launch("bn_bwd_reduce_kernel<fold>");
+  }
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, as_stream(stream), x, dout, ldd, P, C, g.cw, g.rpp,
+                     scale, shift, save_mean, save_invstd, act, red, bound_aux, (unsigned*)nullptr);
   if (!(g_opt[OPT_EXP] & 1))
   hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), C, red, gx, P, scale,
                      bound_aux);
   return check_launch("bn_bwd_reduce_kernel");
+}
+
+extern "C" int yolo_bn_act_bwd_reduce_bound_ld(const float* x, const float* dout, long long ld_dout, long long P, int C,
+                                               const float* scale, const float* shift, const float* save_mean,
+                                               const float* save_invstd, int act, double* red, unsigned* bound_aux,
+                                               void* stream) {
+  return yolo_bn_act_bwd_reduce_fold_ld(x, dout, ld_dout, P, C, scale, shift, save_mean, save_invstd, act, red, bound_aux,
+                                        nullptr, stream);
 }
 
 extern "C" int yolo_bn_act_bwd_sum_partials(const float* partials, int nslots, long long P, int C, const float* scale,

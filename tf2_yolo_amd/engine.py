@@ -28,6 +28,10 @@ from . import ops
 from . import tape
 from ._lib import ACT_LEAKY, ACT_LINEAR, ACT_MISH, YoloHipError
 
+# words of the bounds / tickets block of a conv unit in Network._aux (zeroed at the start of every forward pass): [0] bound of the
+# BatchNorm output, [1..68] the 68 words of yolo_bn_act_bwd_reduce_bound, [69..104] ticket words of its in-launch fold
+AUX_WORDS = 112
+
 ACT_NAMES = {ACT_LINEAR: "linear", ACT_LEAKY: "leaky", ACT_MISH: "mish"}
 
 
@@ -345,6 +349,12 @@ class Network:
         # concat's gradient (ops.ChannelSlice: read in place with its row pitch) instead of being copied out per source
         self._concat_grad_slices = os.environ.get("YOLO_CONCAT_GRAD_SLICE", "1") != "0"
         self._dyp_per_layer = os.environ.get("YOLO_DYP_PER_LAYER", "1") != "0"
+        # round 6: YOLO_BN_FOLD=1 finishes the BatchNormalization-backward reduction inside its own launch
+        # (yolo_bn_act_bwd_reduce_fold_ld: the last workgroups to arrive fold the slots) instead of a bn_bwd_sum launch per
+        # layer: 72 launches fewer. Default 0: measured neutral on YOLOv3-416 (28.99 / 28.99 ms) and 1 % SLOWER on YOLOv4-608
+        # (37.20 -> 37.56: profiles/r06_a_bn_fold_ab_*.log) -- the two dependent memory-side round trips of the fold's tail
+        # cost what the 8 us launch cost behind a queue that dispatches back to back
+        self._bn_fold = os.environ.get("YOLO_BN_FOLD", "0") == "1"
         # The BatchNormalization-backward reduction of a conv + BN unit P (sums of dz and dz * xhat over dL/d(P.out)) is made
         # by the data gradient that COMPLETES dL/d(P.out) -- the last contribution in backward order, when that is a planes
         # data gradient (include/yolo_hip.h: yolo_conv2d_dgrad_planes_bnred): W.bnred_for = P on that writer W.
@@ -432,8 +442,8 @@ class Network:
         # tensor = bound of that activation
         off = 0
         for u in self.units:
-            u.aux_off = off       # [0] forward bound, [1..68] = the 68 words of yolo_bn_act_bwd_reduce_bound,
-            off += 72             # [72 .. 72+C) = per-channel max|conv out| from the conv epilogue
+            u.aux_off = off       # [0] forward bound, [1..68] = the 68 words of yolo_bn_act_bwd_reduce_bound, [69..104] = the
+            off += AUX_WORDS      # ticket words of its in-launch fold, [AUX_WORDS .. +C) = per-channel max|conv out| (conv epilogue)
             if u.kind == "conv" and u.bn:
                 off += (u.cout + 7) // 8 * 8
         # (the per-tensor bounds live behind the units' words: zeroed with them at the start of every forward pass, which the
@@ -712,7 +722,7 @@ class Network:
         self._wTp_valid = True
 
     def _conv_fwd(self, u, xin, w, bias, out, stats=None):
-        amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout] if (stats is not None and self._tight_bound(u)) else None
+        amax = self._aux[u.aux_off + AUX_WORDS:u.aux_off + AUX_WORDS + u.cout] if (stats is not None and self._tight_bound(u)) else None
         if u.planes_fwd:
             return ops.conv2d_fwd_planes(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias,
                                          out=out, stats=stats, absmax=amax)
@@ -841,14 +851,14 @@ class Network:
                                         self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
                                         scale, shift, smean, sinv, unbiased=self.unbiased_moving_var,
                                         bound=self._aux[u.aux_off:u.aux_off + 1],
-                                        absmax=(self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout]
+                                        absmax=(self._aux[u.aux_off + AUX_WORDS:u.aux_off + AUX_WORDS + u.cout]
                                                 if self._tight_bound(u) else None), mean_offset=bias)
                     elif self._fuse_infer and self._fused_infer_unit(u, bias, gamma, beta, scale, shift):
                         continue
                     elif self._fuse_infer and self._infer_onepass and self._stem_infer_unit(u, xin, w, bias, gamma, beta, scale, shift):
                         continue
                     else:
-                        amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout]
+                        amax = self._aux[u.aux_off + AUX_WORDS:u.aux_off + AUX_WORDS + u.cout]
                         if u.planes_fwd:
                             ops.conv2d_fwd_planes(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes],
                                                   bias, out=u.y, absmax=amax)
@@ -958,7 +968,7 @@ class Network:
         if not self._infer_scale_valid:
             ops.bn_fold_inference(u.cout, gamma, beta, self.state.view(u.s_mean.name), self.state.view(u.s_var.name),
                                   scale, shift)
-        amax = self._aux[u.aux_off + 72:u.aux_off + 72 + u.cout]
+        amax = self._aux[u.aux_off + AUX_WORDS:u.aux_off + AUX_WORDS + u.cout]
         res = self.act[u.residual.tid] if u.residual is not None else None
         epi = {ACT_LEAKY: ops.EPI_AFFINE_LEAKY, ACT_MISH: ops.EPI_AFFINE_MISH}.get(u.act, ops.EPI_AFFINE)
         tb = self._tbound
@@ -1081,7 +1091,9 @@ class Network:
                     dy = ops.bn_act_bwd(u.y, dout, u.cout, self.params.view(u.p_gamma.name), scale, shift, smean,
                                         sinv, u.act, red, self._gview(u.p_gamma), self._gview(u.p_beta),
                                         planes=dyp, want_dx=need_f32,
-                                        bound_aux=self._aux[u.aux_off + 1:u.aux_off + 69], fused=self._take_fused(u, dout))
+                                        bound_aux=self._aux[u.aux_off + 1:u.aux_off + 69], fused=self._take_fused(u, dout),
+                                        tickets=(self._aux[u.aux_off + 69:u.aux_off + 69 + ops.BN_FOLD_TICKET_WORDS]
+                                                 if self._bn_fold else None))
                 else:
                     dy = ops.act_bwd(u.y, dout, u.act) if u.act != ACT_LINEAR else dout
                     dyp = self._dyp(u, dy)

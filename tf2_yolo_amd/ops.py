@@ -775,10 +775,15 @@ class ChannelSlice:
         return out
 
 
+BN_FOLD_TICKET_WORDS = 36   # include/yolo_hip.h YOLO_BN_FOLD_TICKET_WORDS
+
+
 def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red, dgamma, dbeta, dx=None,
-               planes=None, want_dx=True, bound_aux=None, fused=None):
+               planes=None, want_dx=True, bound_aux=None, fused=None, tickets=None):
     """returns dx (None when want_dx is False and only the planes of dx are produced). planes needs bound_aux:
-    int32 CUDA tensor of 68 zeroed words (filled by the reduce step, read by the apply step). dout may be a ChannelSlice
+    int32 CUDA tensor of 68 zeroed words (filled by the reduce step, read by the apply step). tickets: BN_FOLD_TICKET_WORDS
+    int32 words, zero before their first use: the reduction then finishes inside its own launch (yolo_bn_act_bwd_reduce_fold_ld)
+    instead of a second one. dout may be a ChannelSlice
     (C % 8 == 0): the two passes then read it in place with its row pitch. fused = the BnReduce whose data gradient already
     made the reduction of THIS dout (conv2d_dgrad_planes(bnred=...)): its slots are folded instead of a pass over x and dout."""
     ld = C
@@ -802,8 +807,10 @@ def bn_act_bwd(x, dout, C, gamma, scale, shift, save_mean, save_invstd, act, red
         check(lib.yolo_bn_act_bwd_sum_partials(_p(fused.partials), int(fused.nslots), P, C, _p(scale), _p(red), _p(bound_aux),
                                                _stream()), "yolo_bn_act_bwd_sum_partials")
     else:
-        check(lib.yolo_bn_act_bwd_reduce_bound_ld(_p(x), _p(dout), ld, P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
-                                                  act, _p(red), _p(bound_aux), _stream()), "yolo_bn_act_bwd_reduce")
+        if tickets is not None and tickets.numel() < BN_FOLD_TICKET_WORDS:
+            raise YoloHipError(f"bn_act_bwd: tickets needs {BN_FOLD_TICKET_WORDS} int32 words")
+        check(lib.yolo_bn_act_bwd_reduce_fold_ld(_p(x), _p(dout), ld, P, C, _p(scale), _p(shift), _p(save_mean), _p(save_invstd),
+                                                 act, _p(red), _p(bound_aux), _p(tickets), _stream()), "yolo_bn_act_bwd_reduce")
     check(lib.yolo_bn_act_bwd_apply_planes_ld(_p(x), _p(dout), ld, P, C, _p(gamma), _p(scale), _p(shift), _p(save_mean),
                                               _p(save_invstd), act, _p(red), _p(dgamma), _p(dbeta),
                                               _p(dx if want_dx else None), _p(planes), _p(bound_aux), _stream()),
