@@ -16,15 +16,22 @@ for ver, N, hw, grids, anchors in ((3, 32, 416, (13, 26, 52), graphs.V3_DEFAULT_
         yp = torch.rand(N, g, g, 255, device="cuda") * 0.98 + 0.01
         dp = torch.empty_like(yp)
         out = torch.zeros(8, device="cuda", dtype=torch.float64)
-        for _ in range(3):
-            ops.loss_fwd_bwd(cfg, yt, yp, loss_out=out, dpred=dp)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            ops.loss_fwd_bwd(cfg, yt, yp, loss_out=out, dpred=dp)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
-        mb = (yt.numel() + 2 * yp.numel()) * 4 / 1e6
-        print(f"v{ver} N={N} grid {g:3d}: {us:7.1f} us per call (incl. the 64-byte memset), {mb:6.1f} MB compulsory, {mb / us / 1e3 * 1e3:5.2f} GB/ms = {mb / us:5.2f} TB/s, loss {float(out[0]):.6f}")
+        res = {}
+        for name, opt in (("chunk-ahead loader (round 4)", 8), ("cell-ahead loader (round 6)", 0)):
+            ops.set_option(8, opt)    # OPT_EXP bit 8: the old loader
+            for _ in range(3):
+                ops.loss_fwd_bwd(cfg, yt, yp, loss_out=out, dpred=dp)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                ops.loss_fwd_bwd(cfg, yt, yp, loss_out=out, dpred=dp)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 20 * 1e3
+            mb = (yt.numel() + 2 * yp.numel()) * 4 / 1e6
+            res[opt] = (dp.clone(), float(out[0]))
+            print(f"v{ver} N={N} grid {g:3d} {name}: {us:7.1f} us per call (incl. the 64-byte memset), {mb:6.1f} MB compulsory, "
+                  f"{mb / us:5.2f} TB/s, loss {float(out[0]):.6f}")
+        ops.reset_options()
+        print("    same gradient bit for bit:", bool(torch.equal(res[0][0], res[8][0])), " loss rel diff", abs(res[0][1] - res[8][1]) / abs(res[8][1]))

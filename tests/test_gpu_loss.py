@@ -205,3 +205,39 @@ def test_metrics(version):
     assert out[5] == cells
     for a, b in zip(got, ref):
         assert abs(a - b) < 1e-5, (got, ref)
+
+
+@pytest.mark.parametrize("version,A,C,g,N", [(3, 3, 80, 13, 4), (3, 3, 80, 52, 2), (3, 3, 3, 8, 3), (4, 3, 80, 19, 2), (2, 5, 20, 13, 3),
+                                             (3, 3, 1, 5, 1), (3, 3, 91, 6, 2)])
+def test_loss_cell_ahead_loader_equals_chunk_ahead_loader(version, A, C, g, N):
+    """Round 6: the loss kernel requests a whole cell (its <= 256 prediction channels, class targets, true box, the anchors'
+    predicted boxes) one cell ahead; yolo_set_option(8, 8) keeps the round-4 loader (one 64-channel chunk ahead). Same
+    arithmetic on the same values in the same per-lane order: the gradient (v2 / v3) and the exported decisions must be
+    BIT-identical, the loss parts equal up to the order of the per-workgroup fp64 atomics. (C = 91: 288 channels per cell, more than the
+    cell-ahead loader holds -- the launcher keeps the old loader; one cell per wave and fewer cells than waves are covered by
+    the small grids.)"""
+    from tf2_yolo_amd import ops
+    anchors = ANCH9[:A] if A <= 9 else None
+    if A == 5:
+        anchors = [[0.75, 0.70], [0.60, 0.27], [0.25, 0.42], [0.14, 0.15], [0.04, 0.05]]
+    yt, yp = make_case(N, g, A, C, anchors, seed=version * 100 + C)
+    kw = dict(loss_weight=(1, 1, 5, 1)) if version != 4 else dict(loss_weight=(1, 5, 1), truth_thresh=0.7)
+    cfg = ops.make_loss_cfg(version, N, g, g, A, C, anchors=anchors, **kw)
+    ytd, ypd = torch.tensor(yt).cuda(), torch.tensor(yp).cuda()
+    res = {}
+    try:
+        for opt in (8, 0):
+            ops.set_option(8, opt)
+            dec = torch.full((N * g * g, 2), -7, dtype=torch.int32, device="cuda")
+            out, dp = ops.loss_fwd_bwd(cfg, ytd, ypd, decisions=dec)
+            torch.cuda.synchronize()
+            res[opt] = (out.cpu().numpy().copy(), dp.clone(), dec.clone())
+    finally:
+        ops.reset_options()
+    if version == 4:   # (the CIoU chain is contracted into fused multiply-adds differently in the two instantiations: last bits)
+        scale = res[8][1].abs().max().item()
+        assert (res[0][1] - res[8][1]).abs().max().item() <= 1e-6 * scale
+    else:
+        assert torch.equal(res[0][1], res[8][1])
+    assert torch.equal(res[0][2], res[8][2]) and int(res[0][2].min()) >= 0
+    assert np.allclose(res[0][0], res[8][0], rtol=1e-7 if version == 4 else 1e-12, atol=0)

@@ -565,6 +565,7 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
   const bool active = col < a.Cout && mrow < a.M;
   float mx = 0.f, mxf = 0.f;              // max|.| before the residual (absmax) / of the values written
   float vout[4] = {0.f, 0.f, 0.f, 0.f};   // this thread's four rows of its column (0 where the row does not exist)
+  float st1 = 0.f, st2 = 0.f;             // BatchNorm statistics of the thread's (existing) rows: sum, sum of squares
   if (active) {
   // everything this thread needs besides the slabs is fetched first (this kernel is a chain of memory latencies: the
   // per-column parameters and the residual values fly beside the parts instead of behind them)
@@ -623,6 +624,8 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
       float v = fmaf(t[e], unscale, bv);
       if (fused) v = act_fwd(fmaf(esc, v, esh), a.epi_act);
       const float vstat = v;     // max|.| before the residual, as planes_epilogue
+      st1 += vstat;
+      st2 = fmaf(vstat, vstat, st2);
       v += rv[e];                // (residual and / or the accumulate form's old value; 0 otherwise)
       a.dst[offs[e] + col] = v;
       vout[e] = v;
@@ -630,6 +633,27 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
       mxf = fmaxf(mxf, fabsf(v));
     }
   }
+  }
+  if (a.stats != nullptr) {
+    // BatchNorm statistics of the training-mode forward (round 6: split launches may carry them -- until then every
+    // forward launch with statistics ran one workgroup per tile however few tiles it had: 120 us per 3x3 layer of YOLOv1.5
+    // at bs 4, 16 tiles of 576 stages). The workgroup's 32 x 32 block: eight threads share a column (fixed order), one
+    // fp64 atomic pair per column into the replica slot of the block's row block, as planes_epilogue does per tile.
+    __shared__ float ss1[256], ss2[256];
+    ss1[threadIdx.x] = st1;
+    ss2[threadIdx.x] = st2;
+    __syncthreads();
+    if (threadIdx.x < 32 && col < a.Cout) {
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        a1 += ss1[threadIdx.x + 32 * u];
+        a2 += ss2[threadIdx.x + 32 * u];
+      }
+      double* slot = a.stats + (long long)((tile_m * (BM / 32) + wm * TM + i) & (YOLO_BN_STAT_SLOTS - 1)) * 2 * a.Cout;
+      atomicAdd(&slot[col], (double)a1);
+      atomicAdd(&slot[a.Cout + col], (double)a2);
+    }
   }
   if (a.absmax != nullptr && a.out_planes == nullptr) {   // (with planes going out nobody reads the per-channel maxima)
     // one atomic per column and workgroup (256 same-address atomics from eight XCDs per column made this kernel 21 us)
@@ -694,15 +718,16 @@ __global__ __launch_bounds__(256) void conv_split_reduce_kernel(const GatherConv
   }
 }
 
-// Parts per tile for a launch of nb tiles of bm x 128 (1 = do not split). Only launches without BatchNorm statistics
-// whose tiles would fill less than 1/idle_div of the chip's workgroup slots (window kernel: half -- the 13x13 data
+// Parts per tile for a launch of nb tiles of bm x 128 (1 = do not split). Only launches (since round 6 also those with
+// BatchNorm statistics: conv_split_reduce_kernel makes them) whose tiles would fill less than 1/idle_div of the chip's workgroup slots (window kernel: half -- the 13x13 data
 // gradients at bs 32, 172 tiles of 576 stages: 181 -> 169 us with two parts; per-tap kernel: a quarter -- the 13x13 1x1
 // layers at bs 32 have 64 stages per tile and lose 8 % with two parts), each part at least min_cb channel blocks long, as many parts as
 // it takes to give every CU two workgroups, at most 32; needs the workspace of yolo_set_conv_workspace.
 int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb, int idle_div) {
   init_options();
   // (a.bwd_y: the fused BatchNorm-backward reduction lives in planes_epilogue only, not in conv_split_reduce_kernel)
-  if (g_opt[OPT_CONV_SK] != 1 || a.stats != nullptr || a.bwd_y != nullptr || g_sk_ws == nullptr) return 1;
+  if (g_opt[OPT_CONV_SK] != 1 || a.bwd_y != nullptr || g_sk_ws == nullptr) return 1;
+  if (a.stats != nullptr && (g_opt[OPT_EXP] & 16)) return 1;   // (A/B: forward launches with statistics unsplit, as until round 5)
   static int cus = 0;
   if (cus == 0) {
     int dev = 0;

@@ -14,7 +14,9 @@
 // coalesced loads/stores, accumulate the loss parts in fp64 and write the gradient row.
 // HBM-bound: reads y_true + y_pred once, writes the gradient once.
 #include "common.hpp"
+#include "conv_args.hpp"
 #include <cfloat>
+#include <cstdlib>
 
 namespace yolo {
 
@@ -113,8 +115,179 @@ struct LossParams {
   int* dec;     // optional [cells][2]: the discrete decisions of every cell (see yolo_loss_fwd_bwd in yolo_hip.h)
 };
 
-// parts: [0] total (weighted), then per-version diagnostics (see yolo_hip.h)
+// One prediction channel of one cell: the loss parts it adds and dL/dp (before the 1/N factor). b = anchor, k = channel inside
+// the anchor (k >= 5: class k - 5), p = the prediction, tk = the class target of a class channel, Tb = the cell's true box,
+// t4 = its object flag; iou_b / d0..d3 = the IoU of anchor b (and, v1.5 / v4, its partials), an = the anchor extent of a w / h
+// channel, cb = anchor b's confidence (v1.5), r_b = 1 for the responsible anchor. Shared by the two loaders of loss_kernel.
 template <int VER>
+__device__ __forceinline__ float loss_channel(const yolo_loss_cfg& c, const int b, const int k, const float p, const float tk_cur,
+                                              const float t4, const float (&Tb)[4], const float iou_b, const float d0,
+                                              const float d1, const float d2, const float d3, const float an, const float cb,
+                                              const float r_b, double (&part)[7]) {
+  (void)b;
+  const float tbk = (k == 0) ? Tb[0] : (k == 1) ? Tb[1] : (k == 2) ? Tb[2] : Tb[3];
+  float obj, noobj;
+  if (VER == 1) {
+    obj = t4 * r_b;
+    noobj = 1.f - obj;
+  } else {
+    obj = t4 * r_b;
+    if (VER == 4 && c.truth_thresh < 1.f) obj = obj + ((iou_b > c.truth_thresh) ? 1.f : 0.f) * (1.f - obj);
+    noobj = (1.f - obj) * ((iou_b < c.ignore_thresh) ? 1.f : 0.f);
+  }
+  float g = 0.f;  // dL/dp before the 1/N factor
+
+  if (k < 4) {
+    const float dIk = (k == 0) ? d0 : (k == 1) ? d1 : (k == 2) ? d2 : d3;
+    if (VER == 2 || VER == 3) {
+      const float s = (VER == 2 || c.use_scale) ? (2.f - Tb[2] * Tb[3]) : 1.f;
+      if (k < 2) {
+        const float diff = tbk - p;
+        const float l = obj * s * (diff * diff);
+        part[1] += (double)l;
+        part[0] += (double)c.loss_weight[0] * (double)l;
+        g = -2.f * c.loss_weight[0] * obj * s * diff;
+      } else {
+        const float tl = logf(fmaxf(tbk / an, LEPS));
+        const float pl = logf(p / an);
+        const float diff = tl - pl;
+        const float l = obj * s * (diff * diff);
+        const float reg = pl * pl;
+        part[2] += (double)l;
+        part[6] += (double)reg;
+        part[0] += (double)c.loss_weight[1] * (double)l + 0.01 * (double)reg;
+        g = (-2.f * c.loss_weight[1] * obj * s * diff + 0.02f * pl) / p;
+      }
+    } else if (VER == 4) {
+      // box loss gradient through CIoU; wh regulariser on the log-ratio
+      g = -c.loss_weight[0] * obj * dIk;
+      if (k >= 2) {
+        const float pl = logf(p / an);
+        const float reg = pl * pl;
+        part[6] += (double)reg;
+        part[0] += (double)c.wh_reg_weight * (double)reg;
+        g += 2.f * c.wh_reg_weight * pl / p;
+      }
+    } else {  // VER == 1
+      // confidence target is the IoU itself and is differentiated through
+      g = 2.f * c.loss_weight[2] * obj * (iou_b - cb) * dIk;
+      if (k < 2) {
+        const float diff = tbk - p;
+        const float l = obj * (diff * diff);
+        part[1] += (double)l;
+        part[0] += (double)c.loss_weight[0] * (double)l;
+        g += -2.f * c.loss_weight[0] * obj * diff;
+      } else {
+        const float tq = sqrtf(fmaxf(tbk, LEPS));
+        const float pq = sqrtf(fmaxf(p, LEPS));
+        const float diff = tq - pq;
+        const float l = obj * (diff * diff);
+        part[2] += (double)l;
+        part[0] += (double)c.loss_weight[1] * (double)l;
+        if (p >= LEPS) g += -2.f * c.loss_weight[1] * obj * diff * (0.5f / pq);
+      }
+    }
+  } else if (k == 4) {
+    if (VER == 1) {
+      const float e = iou_b - p;
+      const float lo = obj * (e * e);
+      const float ln = noobj * (p * p);
+      part[3] += (double)lo;
+      part[4] += (double)ln;
+      part[0] += (double)c.loss_weight[2] * ((double)lo + (double)c.binary_weight * (double)ln);
+      g = c.loss_weight[2] * (-2.f * obj * e + 2.f * c.binary_weight * noobj * p);
+    } else if (VER == 2 || (VER == 3 && !c.use_focal_loss)) {
+      const float lo = obj * ((1.f - p) * (1.f - p));
+      const float ln = noobj * (p * p);
+      part[3] += (double)lo;
+      part[4] += (double)ln;
+      part[0] += (double)c.loss_weight[2] * ((double)lo + (double)c.binary_weight * (double)ln);
+      g = c.loss_weight[2] * (-2.f * obj * (1.f - p) + 2.f * c.binary_weight * noobj * p);
+    } else if (VER == 3) {  // focal
+      const float cc = fminf(fmaxf(p, LEPS), ONE_M_EPS);
+      const float pass = (p >= LEPS && p <= ONE_M_EPS) ? 1.f : 0.f;
+      const float gm = c.focal_gamma;
+      // (gamma = 2, the reference's default: x^2 and x^1 without libm's powf -- the ONE confidence lane of a 64-channel
+      // chunk ran it four times while 63 lanes waited)
+      const bool g2 = gm == 2.f;
+      const float a1 = g2 ? (1.f - cc) * (1.f - cc) : powf(1.f - cc, gm), l1 = logf(cc);
+      const float a0 = g2 ? cc * cc : powf(cc, gm), l0 = logf(1.f - cc);
+      const float lo = -obj * a1 * l1;
+      const float ln = -noobj * a0 * l0;
+      part[3] += (double)lo;
+      part[4] += (double)ln;
+      part[0] += (double)c.loss_weight[2] * ((double)lo + (double)c.binary_weight * (double)ln);
+      const float d1 = -obj * (-gm * (g2 ? (1.f - cc) : powf(1.f - cc, gm - 1.f)) * l1 + a1 / cc);
+      const float d0 = -noobj * (gm * (g2 ? cc : powf(cc, gm - 1.f)) * l0 - a0 / (1.f - cc));
+      g = c.loss_weight[2] * (d1 + c.binary_weight * d0) * pass;
+    } else {  // VER == 4
+      const float cc = fminf(fmaxf(p, LEPS), ONE_M_EPS);
+      const float pass = (p >= LEPS && p <= ONE_M_EPS) ? 1.f : 0.f;
+      const float gm = c.focal_gamma;
+      float eo, en, deo, den;  // errors and d(error)/dc
+      if (c.label_smooth > 0.f) {
+        const float uo = 1.f - c.label_smooth - cc;
+        const float un = c.label_smooth - cc;
+        eo = fabsf(uo);
+        en = fabsf(un);
+        deo = (uo > 0.f) ? -1.f : (uo < 0.f ? 1.f : 0.f);
+        den = (un > 0.f) ? -1.f : (un < 0.f ? 1.f : 0.f);
+      } else {
+        eo = 1.f - cc;
+        en = cc;
+        deo = -1.f;
+        den = 1.f;
+      }
+      const bool g2 = gm == 2.f;   // (see the focal branch above)
+      const float ao = g2 ? eo * eo : powf(eo, gm), lo_ = logf(1.f - eo);
+      const float an_ = g2 ? en * en : powf(en, gm), ln_ = logf(1.f - en);
+      const float lo = -obj * ao * lo_;
+      const float ln = -noobj * an_ * ln_;
+      part[3] += (double)lo;
+      part[4] += (double)ln;
+      part[0] += (double)c.loss_weight[1] * ((double)lo + (double)c.binary_weight * (double)ln);
+      const float dfo = gm * (g2 ? eo : powf(eo, gm - 1.f)) * lo_ - ao / (1.f - eo);  // d/de [e^g log(1-e)]
+      const float dfn = gm * (g2 ? en : powf(en, gm - 1.f)) * ln_ - an_ / (1.f - en);
+      g = c.loss_weight[1] * (-obj * dfo * deo - c.binary_weight * noobj * dfn * den) * pass;
+    }
+  } else {  // class channel
+    const float tk = tk_cur;
+    const float pc = fminf(fmaxf(p, LEPS), ONE_M_EPS);
+    const float pass = (p >= LEPS && p <= ONE_M_EPS) ? 1.f : 0.f;
+    const float wcls = (VER == 4) ? c.loss_weight[2] : c.loss_weight[3];
+    if (VER != 1 && obj == 0.f) {
+      // every class term carries the factor obj: loss part and gradient are (signed) zeros -- 99.7 % of the slots of a
+      // 52x52 level -- so the two logarithms and two divisions per element are skipped; adding -0.0 to the sums and
+      // storing -0.0 instead of +0.0 would change nothing either
+      g = 0.f;
+    } else if (VER == 3 || VER == 4) {
+      const float l = -obj * (tk * logf(pc) + (1.f - tk) * logf(1.f - pc));
+      part[5] += (double)l;
+      part[0] += (double)wcls * (double)l;
+      g = -wcls * obj * (tk / pc - (1.f - tk) / (1.f - pc)) * pass;
+    } else if (VER == 2) {
+      const float l = -obj * (tk * logf(pc));
+      part[5] += (double)l;
+      part[0] += (double)wcls * (double)l;
+      g = -wcls * obj * (tk / pc) * pass;
+    } else {  // VER == 1: per cell, mask is the cell's objectness only
+      const float l = -t4 * tk * logf(pc);
+      part[5] += (double)l;
+      part[0] += (double)wcls * (double)l;
+      g = -wcls * t4 * (tk / pc) * pass;
+    }
+  }
+  return g;
+}
+
+// parts: [0] total (weighted), then per-version diagnostics (see yolo_hip.h)
+// PREF (round 6; v2 / v3 / v4 with at most 256 prediction channels per cell): EVERYTHING a cell needs -- its four 64-channel
+// chunks of predictions, the class targets beside them, the true box and the anchors' predicted boxes, 13 loads per lane --
+// is requested ONE CELL AHEAD, while the current cell is worked on. One wave per cell with the next chunk's two loads in
+// flight (round 4) kept ~0.5 KB per wave in the air: 8 waves per SIMD x 1024 SIMDs x 0.5 KB over a ~2 us round trip is the
+// 1.1-1.5 TB/s the kernel sat at, whatever its arithmetic did. A cell ahead it is 1.4 KB per wave and no load is waited for
+// at the head of a cell (the box loads that start a cell's dependency chain come out of registers).
+template <int VER, bool PREF>
 __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const float* __restrict__ y_true,
                                                    const float* __restrict__ y_pred, float* __restrict__ dpred,
                                                    double* __restrict__ out) {
@@ -136,19 +309,27 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
   for (int j = 0; j < 32; ++j)
     if (lane == j) my_anchor = c.use_anchors ? c.anchors[j] : 1.f;
 
-  for (long long cell = wave0; cell < lp.cells; cell += nwaves) {
-    const float* T = y_true + cell * TD;
-    const float* Pc = y_pred + cell * PD;
-    float* G = dpred ? dpred + cell * PD : nullptr;
-
-    // ---- per-anchor IoU on lanes 0..A-1 ----
-    float iou = -1.f, ciou = 0.f;
-    float dI[4] = {0.f, 0.f, 0.f, 0.f};  // partials of the differentiated score (iou for v1, ciou for v4)
-    const float t4 = T[4];
+  auto chan_of = [&](int idx, int& b, int& k) {   // anchor, channel within anchor (k >= 5: class k-5)
+    if (VER == 1) {
+      if (idx < 5 * A) {
+        b = idx / 5;
+        k = idx - b * 5;
+      } else {
+        b = 0;
+        k = 5 + (idx - 5 * A);
+      }
+    } else {
+      b = idx / TD;
+      k = idx - b * TD;
+    }
+  };
+  // the per-anchor IoU on lanes 0..A-1, the responsible anchor, the decisions, the v4 box term: shared by both loaders
+  auto cell_head = [&](long long cell, const float (&Tb)[4], const float t4, const float (&Pb)[4], float& iou, float (&dI)[4],
+                       int& resp) {
+    iou = -1.f;
+    float ciou = 0.f;
+    dI[0] = dI[1] = dI[2] = dI[3] = 0.f;   // partials of the differentiated score (iou for v1, ciou for v4)
     if (lane < A) {
-      const float* P = Pc + ((VER == 1) ? lane * 5 : lane * (5 + C));
-      const float Tb[4] = {T[0], T[1], T[2], T[3]};
-      const float Pb[4] = {P[0], P[1], P[2], P[3]};
       const IouOut o = iou_dual<VER == 4>(Tb, Pb, gw, gh);
       iou = o.iou.v;
       ciou = o.ciou.v;
@@ -156,7 +337,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
       for (int i = 0; i < 4; ++i) dI[i] = src.d[i];
     }
     // responsible anchor: first maximal IoU (tf.argmax)
-    int resp = 0;
+    resp = 0;
     float best = __shfl(iou, 0, 64);
     for (int b = 1; b < A; ++b) {
       const float ib = __shfl(iou, b, 64);
@@ -165,7 +346,6 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
         resp = b;
       }
     }
-
     if (lp.dec != nullptr) {
       // the decisions a second execution can only reproduce by being told: [0] responsible anchor, [1] bit b = "anchor b is
       // below ignore_thresh", bit 16 + b = "anchor b is above truth_thresh" (tests force the oracle's decisions to these)
@@ -176,7 +356,6 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
         lp.dec[cell * 2 + 1] = (int)((unsigned)(ign & 0xffffu) | ((unsigned)(tru & 0xffffu) << 16));
       }
     }
-
     // v4 box term lives on the anchor lanes
     if (VER == 4 && lane < A) {
       float obj = t4 * (lane == resp ? 1.f : 0.f);
@@ -185,24 +364,89 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
       part[1] += box;
       part[0] += (double)c.loss_weight[0] * box;
     }
+  };
+
+  if constexpr (PREF) {
+    constexpr int NCK = 4;   // 64-channel chunks of a cell (PD <= 256, checked by the launcher)
+    float pn[NCK], tkn[NCK], tbn, pbn[4];        // the NEXT cell: predictions, class targets, T[0..4] on lanes 0..4, my anchor's box
+    auto prefetch = [&](long long cell) {
+      const float* T = y_true + cell * TD;
+      const float* Pc = y_pred + cell * PD;
+#pragma unroll
+      for (int q = 0; q < NCK; ++q) {
+        int idx = q * 64 + lane;
+        idx = idx < PD ? idx : PD - 1;
+        int b, k;
+        chan_of(idx, b, k);
+        pn[q] = Pc[idx];
+        tkn[q] = T[k >= 5 ? k : 4];
+      }
+      tbn = T[lane < 5 ? lane : 4];
+      const float* P = Pc + (lane < A ? lane : 0) * TD;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pbn[j] = P[j];
+    };
+    long long cell = wave0;
+    if (cell < lp.cells) prefetch(cell);
+    for (; cell < lp.cells; cell += nwaves) {
+      float pc[NCK], tkc[NCK], Pb[4];
+#pragma unroll
+      for (int q = 0; q < NCK; ++q) {
+        pc[q] = pn[q];
+        tkc[q] = tkn[q];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) Pb[j] = pbn[j];
+      const float tbc = tbn;
+      if (cell + nwaves < lp.cells) prefetch(cell + nwaves);
+      float* G = dpred ? dpred + cell * PD : nullptr;
+      const float Tb[4] = {__shfl(tbc, 0, 64), __shfl(tbc, 1, 64), __shfl(tbc, 2, 64), __shfl(tbc, 3, 64)};
+      const float t4 = __shfl(tbc, 4, 64);
+      float iou, dI[4];
+      int resp;
+      cell_head(cell, Tb, t4, Pb, iou, dI, resp);
+#pragma unroll
+      for (int q = 0; q < NCK; ++q) {
+        const int base = q * 64;
+        if (base < PD) {   // (wave-uniform)
+          const bool active = (base + lane) < PD;
+          const int idx = active ? (base + lane) : (PD - 1);
+          int b, k;
+          chan_of(idx, b, k);
+          // all cross-lane traffic happens here, with every lane participating
+          const float iou_b = __shfl(iou, b, 64);
+          const float d0 = __shfl(dI[0], b, 64), d1 = __shfl(dI[1], b, 64);
+          const float d2 = __shfl(dI[2], b, 64), d3 = __shfl(dI[3], b, 64);
+          const float an = __shfl(my_anchor, (b * 2 + ((k == 3) ? 1 : 0)) & 31, 64);
+          const float r_b = (b == resp) ? 1.f : 0.f;
+          if (active) {
+            const float g = loss_channel<VER>(c, b, k, pc[q], tkc[q], t4, Tb, iou_b, d0, d1, d2, d3, an, 0.f, r_b, part);
+            if (G) G[idx] = g * lp.inv_n;
+          }
+        }
+      }
+    }
+  } else {
+  for (long long cell = wave0; cell < lp.cells; cell += nwaves) {
+    const float* T = y_true + cell * TD;
+    const float* Pc = y_pred + cell * PD;
+    float* G = dpred ? dpred + cell * PD : nullptr;
+
+    // ---- per-anchor IoU on lanes 0..A-1 ----
+    const float t4 = T[4];
+    const float Tb[4] = {T[0], T[1], T[2], T[3]};
+    float Pb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (lane < A) {
+      const float* P = Pc + ((VER == 1) ? lane * 5 : lane * (5 + C));
+      for (int j = 0; j < 4; ++j) Pb[j] = P[j];
+    }
+    float iou, dI[4];
+    int resp;
+    cell_head(cell, Tb, t4, Pb, iou, dI, resp);
 
     // ---- sweep the prediction channels ----
     // (the loads of chunk i + 1 -- the prediction and, for a class channel, its target -- are issued before chunk i is worked on:
     // one wave per cell had ONE load in flight per 64 channels; 52x52 level 227 -> 179 us for 206 MB)
-    auto chan_of = [&](int idx, int& b, int& k) {   // anchor, channel within anchor (k >= 5: class k-5)
-      if (VER == 1) {
-        if (idx < 5 * A) {
-          b = idx / 5;
-          k = idx - b * 5;
-        } else {
-          b = 0;
-          k = 5 + (idx - 5 * A);
-        }
-      } else {
-        b = idx / TD;
-        k = idx - b * TD;
-      }
-    };
     float p_nxt, tk_nxt;
     {
       const int idx0 = lane < PD ? lane : (PD - 1);
@@ -232,159 +476,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const LossParams lp, const fl
       const float cb = (VER == 1) ? Pc[b * 5 + 4] : 0.f;
       const float r_b = (b == resp) ? 1.f : 0.f;
       if (!active) continue;  // no cross-lane operations below this line
-      float obj, noobj;
-      if (VER == 1) {
-        obj = t4 * r_b;
-        noobj = 1.f - obj;
-      } else {
-        obj = t4 * r_b;
-        if (VER == 4 && c.truth_thresh < 1.f) obj = obj + ((iou_b > c.truth_thresh) ? 1.f : 0.f) * (1.f - obj);
-        noobj = (1.f - obj) * ((iou_b < c.ignore_thresh) ? 1.f : 0.f);
-      }
-      float g = 0.f;  // dL/dp before the 1/N factor
-
-      if (k < 4) {
-        const float dIk = (k == 0) ? d0 : (k == 1) ? d1 : (k == 2) ? d2 : d3;
-        if (VER == 2 || VER == 3) {
-          const float s = (VER == 2 || c.use_scale) ? (2.f - T[2] * T[3]) : 1.f;
-          if (k < 2) {
-            const float diff = T[k] - p;
-            const float l = obj * s * (diff * diff);
-            part[1] += (double)l;
-            part[0] += (double)c.loss_weight[0] * (double)l;
-            g = -2.f * c.loss_weight[0] * obj * s * diff;
-          } else {
-            const float tl = logf(fmaxf(T[k] / an, LEPS));
-            const float pl = logf(p / an);
-            const float diff = tl - pl;
-            const float l = obj * s * (diff * diff);
-            const float reg = pl * pl;
-            part[2] += (double)l;
-            part[6] += (double)reg;
-            part[0] += (double)c.loss_weight[1] * (double)l + 0.01 * (double)reg;
-            g = (-2.f * c.loss_weight[1] * obj * s * diff + 0.02f * pl) / p;
-          }
-        } else if (VER == 4) {
-          // box loss gradient through CIoU; wh regulariser on the log-ratio
-          g = -c.loss_weight[0] * obj * dIk;
-          if (k >= 2) {
-            const float pl = logf(p / an);
-            const float reg = pl * pl;
-            part[6] += (double)reg;
-            part[0] += (double)c.wh_reg_weight * (double)reg;
-            g += 2.f * c.wh_reg_weight * pl / p;
-          }
-        } else {  // VER == 1
-          // confidence target is the IoU itself and is differentiated through
-          g = 2.f * c.loss_weight[2] * obj * (iou_b - cb) * dIk;
-          if (k < 2) {
-            const float diff = T[k] - p;
-            const float l = obj * (diff * diff);
-            part[1] += (double)l;
-            part[0] += (double)c.loss_weight[0] * (double)l;
-            g += -2.f * c.loss_weight[0] * obj * diff;
-          } else {
-            const float tq = sqrtf(fmaxf(T[k], LEPS));
-            const float pq = sqrtf(fmaxf(p, LEPS));
-            const float diff = tq - pq;
-            const float l = obj * (diff * diff);
-            part[2] += (double)l;
-            part[0] += (double)c.loss_weight[1] * (double)l;
-            if (p >= LEPS) g += -2.f * c.loss_weight[1] * obj * diff * (0.5f / pq);
-          }
-        }
-      } else if (k == 4) {
-        if (VER == 1) {
-          const float e = iou_b - p;
-          const float lo = obj * (e * e);
-          const float ln = noobj * (p * p);
-          part[3] += (double)lo;
-          part[4] += (double)ln;
-          part[0] += (double)c.loss_weight[2] * ((double)lo + (double)c.binary_weight * (double)ln);
-          g = c.loss_weight[2] * (-2.f * obj * e + 2.f * c.binary_weight * noobj * p);
-        } else if (VER == 2 || (VER == 3 && !c.use_focal_loss)) {
-          const float lo = obj * ((1.f - p) * (1.f - p));
-          const float ln = noobj * (p * p);
-          part[3] += (double)lo;
-          part[4] += (double)ln;
-          part[0] += (double)c.loss_weight[2] * ((double)lo + (double)c.binary_weight * (double)ln);
-          g = c.loss_weight[2] * (-2.f * obj * (1.f - p) + 2.f * c.binary_weight * noobj * p);
-        } else if (VER == 3) {  // focal
-          const float cc = fminf(fmaxf(p, LEPS), ONE_M_EPS);
-          const float pass = (p >= LEPS && p <= ONE_M_EPS) ? 1.f : 0.f;
-          const float gm = c.focal_gamma;
-          // (gamma = 2, the reference's default: x^2 and x^1 without libm's powf -- the ONE confidence lane of a 64-channel
-          // chunk ran it four times while 63 lanes waited)
-          const bool g2 = gm == 2.f;
-          const float a1 = g2 ? (1.f - cc) * (1.f - cc) : powf(1.f - cc, gm), l1 = logf(cc);
-          const float a0 = g2 ? cc * cc : powf(cc, gm), l0 = logf(1.f - cc);
-          const float lo = -obj * a1 * l1;
-          const float ln = -noobj * a0 * l0;
-          part[3] += (double)lo;
-          part[4] += (double)ln;
-          part[0] += (double)c.loss_weight[2] * ((double)lo + (double)c.binary_weight * (double)ln);
-          const float d1 = -obj * (-gm * (g2 ? (1.f - cc) : powf(1.f - cc, gm - 1.f)) * l1 + a1 / cc);
-          const float d0 = -noobj * (gm * (g2 ? cc : powf(cc, gm - 1.f)) * l0 - a0 / (1.f - cc));
-          g = c.loss_weight[2] * (d1 + c.binary_weight * d0) * pass;
-        } else {  // VER == 4
-          const float cc = fminf(fmaxf(p, LEPS), ONE_M_EPS);
-          const float pass = (p >= LEPS && p <= ONE_M_EPS) ? 1.f : 0.f;
-          const float gm = c.focal_gamma;
-          float eo, en, deo, den;  // errors and d(error)/dc
-          if (c.label_smooth > 0.f) {
-            const float uo = 1.f - c.label_smooth - cc;
-            const float un = c.label_smooth - cc;
-            eo = fabsf(uo);
-            en = fabsf(un);
-            deo = (uo > 0.f) ? -1.f : (uo < 0.f ? 1.f : 0.f);
-            den = (un > 0.f) ? -1.f : (un < 0.f ? 1.f : 0.f);
-          } else {
-            eo = 1.f - cc;
-            en = cc;
-            deo = -1.f;
-            den = 1.f;
-          }
-          const bool g2 = gm == 2.f;   // (see the focal branch above)
-          const float ao = g2 ? eo * eo : powf(eo, gm), lo_ = logf(1.f - eo);
-          const float an_ = g2 ? en * en : powf(en, gm), ln_ = logf(1.f - en);
-          const float lo = -obj * ao * lo_;
-          const float ln = -noobj * an_ * ln_;
-          part[3] += (double)lo;
-          part[4] += (double)ln;
-          part[0] += (double)c.loss_weight[1] * ((double)lo + (double)c.binary_weight * (double)ln);
-          const float dfo = gm * (g2 ? eo : powf(eo, gm - 1.f)) * lo_ - ao / (1.f - eo);  // d/de [e^g log(1-e)]
-          const float dfn = gm * (g2 ? en : powf(en, gm - 1.f)) * ln_ - an_ / (1.f - en);
-          g = c.loss_weight[1] * (-obj * dfo * deo - c.binary_weight * noobj * dfn * den) * pass;
-        }
-      } else {  // class channel
-        const float tk = tk_cur;
-        const float pc = fminf(fmaxf(p, LEPS), ONE_M_EPS);
-        const float pass = (p >= LEPS && p <= ONE_M_EPS) ? 1.f : 0.f;
-        const float wcls = (VER == 4) ? c.loss_weight[2] : c.loss_weight[3];
-        if (VER != 1 && obj == 0.f) {
-          // every class term carries the factor obj: loss part and gradient are (signed) zeros -- 99.7 % of the slots of a
-          // 52x52 level -- so the two logarithms and two divisions per element are skipped; adding -0.0 to the sums and
-          // storing -0.0 instead of +0.0 would change nothing either
-          g = 0.f;
-        } else if (VER == 3 || VER == 4) {
-          const float l = -obj * (tk * logf(pc) + (1.f - tk) * logf(1.f - pc));
-          part[5] += (double)l;
-          part[0] += (double)wcls * (double)l;
-          g = -wcls * obj * (tk / pc - (1.f - tk) / (1.f - pc)) * pass;
-        } else if (VER == 2) {
-          const float l = -obj * (tk * logf(pc));
-          part[5] += (double)l;
-          part[0] += (double)wcls * (double)l;
-          g = -wcls * obj * (tk / pc) * pass;
-        } else {  // VER == 1: per cell, mask is the cell's objectness only
-          const float l = -t4 * tk * logf(pc);
-          part[5] += (double)l;
-          part[0] += (double)wcls * (double)l;
-          g = -wcls * t4 * (tk / pc) * pass;
-        }
-      }
+      const float g = loss_channel<VER>(c, b, k, p, tk_cur, t4, Tb, iou_b, d0, d1, d2, d3, an, cb, r_b, part);
       if (G) G[idx] = g * lp.inv_n;
     }
+  }
   }
 
   // block reduction of the 7 parts, one fp64 atomic per part per block
@@ -523,11 +618,24 @@ extern "C" int yolo_loss_fwd_bwd(const yolo_loss_cfg* cfg, const float* y_true, 
   long long blocks = (lp.cells + 3) / 4;
   if (blocks > 2048) blocks = 2048;
   dim3 grid((unsigned)blocks), block(256);
+  // the loader that requests a whole cell one cell ahead (loss_kernel<VER, true>): v2 / v3 / v4, at most 256 prediction
+  // channels per cell; YOLO_LOSS_PREFETCH=0 keeps the chunk-ahead loader (A/B, tests: the two must agree bit for bit)
+  static const bool pref_env = [] { const char* e = getenv("YOLO_LOSS_PREFETCH"); return !(e && atoi(e) == 0); }();
+  const bool pref = pref_env && !(g_opt[OPT_EXP] & 8) && cfg->version != 1 && cfg->A * (5 + cfg->C) <= 256;
   switch (cfg->version) {
-    case 1: hipLaunchKernelGGL(loss_kernel<1>, grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out); break;
-    case 2: hipLaunchKernelGGL(loss_kernel<2>, grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out); break;
-    case 3: hipLaunchKernelGGL(loss_kernel<3>, grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out); break;
-    default: hipLaunchKernelGGL(loss_kernel<4>, grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out); break;
+    case 1: hipLaunchKernelGGL((loss_kernel<1, false>), grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out); break;
+    case 2:
+      if (pref) hipLaunchKernelGGL((loss_kernel<2, true>), grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out);
+      else hipLaunchKernelGGL((loss_kernel<2, false>), grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out);
+      break;
+    case 3:
+      if (pref) hipLaunchKernelGGL((loss_kernel<3, true>), grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out);
+      else hipLaunchKernelGGL((loss_kernel<3, false>), grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out);
+      break;
+    default:
+      if (pref) hipLaunchKernelGGL((loss_kernel<4, true>), grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out);
+      else hipLaunchKernelGGL((loss_kernel<4, false>), grid, block, 0, st, lp, y_true, y_pred, dpred, loss_out);
+      break;
   }
   return check_launch("loss_kernel");
 }

@@ -39,6 +39,8 @@ static void options_from_env() {
   // rows; larger ones walk), 1 = the greedy walk kernel for every class (tests: both must give the same rows)
   e = getenv("YOLO_NMS_WALK");
   g_opt[OPT_NMS_WALK] = e ? atoi(e) : 0;
+  e = getenv("YOLO_EXP");   // experiment / A-B bits (conv_args.hpp: OPT_EXP)
+  g_opt[OPT_EXP] = e ? atoi(e) : 0;
 }
 void init_options() {
   static bool done = false;
