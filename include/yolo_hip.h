@@ -445,6 +445,12 @@ int yolo_maxpool_bwd(const float* dy, int N, int Ho, int Wo, int C, int Cy, int 
  * result depends on the order of its atomicAdds). Shapes the gather kernel does not cover fall back to yolo_maxpool_bwd. */
 int yolo_maxpool_bwd_same(const float* dy, int N, int H, int W, int C, int Cy, int c_off, const int* argmax, int k,
                           int pad_t, int pad_l, float* dx, void* stream);
+/* Backward of a 2x2 / stride-2 pool whose windows tile the input exactly (input [N, 2 Ho, 2 Wo, C], C % 4 == 0; the five
+ * MaxPooling2D of Darknet-19, yolov2/models/backbone.py:42-60, and of tiny-YOLOv3, yolov3/models/darknet.py:107-135): every
+ * input position is written (accumulate = 0: dx needs no zero fill) or added to (accumulate = 1) exactly once -- dy where the
+ * saved winner of its window is, 0 elsewhere. No atomics, 16 bytes per lane. */
+int yolo_maxpool2x2_bwd(const float* dy, int N, int Ho, int Wo, int C, const int* argmax, float* dx, int accumulate,
+                        void* stream);
 /* tf.nn.space_to_depth(x, 2): y[n,h,w,(dy*2+dx)*C+c] = x[n,2h+dy,2w+dx,c], into slice of Cy at c_off */
 int yolo_space_to_depth2_fwd(const float* x, int N, int H, int W, int C, float* y, int Cy, int c_off,
                              void* stream);

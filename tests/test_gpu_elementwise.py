@@ -458,3 +458,42 @@ def test_bn_backward_reduction_finished_by_its_own_launch(P, C, act):
         ref0, ref1 = dz.sum(0), (dz * ((xd - smean.double()) * sinv.double())).sum(0)
         assert (one[0][:C] - ref0).abs().max().item() <= 1e-5 * ref0.abs().max().item()
         assert (one[0][C:] - ref1).abs().max().item() <= 1e-5 * ref1.abs().max().item()
+
+
+@pytest.mark.parametrize("N,hh,ww,c", [(2, 8, 6, 8), (3, 26, 26, 64), (1, 2, 2, 4), (2, 104, 104, 32)])
+def test_maxpool_2x2_stride2_tiling_kernels(N, hh, ww, c):
+    """2x2 / stride-2 pools whose windows tile the input (C % 4 == 0) run on the 16-byte-per-lane kernels (round 6;
+    csrc/elementwise.hip: maxpool2x2_fwd_kernel / maxpool2x2_bwd_kernel): values, recorded winners (first maximum in row-major
+    window order, ties included) and the gradient against the oracle and against the general scatter kernel; the backward in
+    its assign form overwrites a poisoned tensor completely (no zero fill needed), in its accumulate form it adds."""
+    from oracle import layers as L
+    from tf2_yolo_amd import ops
+    g = torch.Generator().manual_seed(N * 1000 + hh + c)
+    m = torch.randn(N, hh, ww, c, generator=g, dtype=torch.float64)
+    m[:, ::2, ::2, : c // 2] = m[:, 1::2, 1::2, : c // 2]      # exact ties between the first and the last element of a window
+    m = m.float().double().requires_grad_(True)
+    ref = L.maxpool(m, 2, 2, "same")
+    dref = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dref)
+    Ho, Wo = hh // 2, ww // 2
+    md = m.detach().float().cuda()
+    out = torch.empty(N, Ho, Wo, c, device="cuda")
+    arg = torch.empty(N, Ho, Wo, c, device="cuda", dtype=torch.int32)
+    ops.maxpool_fwd(md, 2, 2, 0, 0, Ho, Wo, out, c, 0, arg)
+    assert torch.equal(out.double().cpu(), ref.detach().float().double())
+    # the general kernel (selected here by an output channel slice: Cy > C) records the same winners
+    wide = torch.empty(N, Ho, Wo, c + 4, device="cuda")
+    arg2 = torch.empty_like(arg)
+    ops.maxpool_fwd(md, 2, 2, 0, 0, Ho, Wo, wide, c + 4, 4, arg2)
+    assert torch.equal(arg, arg2) and torch.equal(wide[..., 4:], out)
+    dyd = dref.float().cuda()
+    dm = torch.full((N, hh, ww, c), float("nan"), device="cuda")
+    ops.maxpool2x2_bwd(dyd, N, Ho, Wo, c, arg, dm, False)
+    scat = torch.zeros(N, hh, ww, c, device="cuda")
+    ops.maxpool_bwd(dyd, N, Ho, Wo, c, c, 0, arg, scat)
+    assert torch.equal(dm, scat)
+    assert _rel(dm, m.grad) < 1e-6
+    base = torch.randn(N, hh, ww, c, device="cuda")
+    acc = base.clone()
+    ops.maxpool2x2_bwd(dyd, N, Ho, Wo, c, arg, acc, True)
+    assert torch.equal(acc, base + scat)

@@ -161,7 +161,6 @@ bool conv_win_supported(const GatherConvArgs& a);
 enum { OPT_CONV_WIN = 0, OPT_STAMPS = 1, OPT_CONV_SK = 2, OPT_DBG = 3, OPT_TILE_ORDER = 4, OPT_CONV_PATCH = 5, OPT_WGRAD_WIN = 6, OPT_NMS_WALK = 7, OPT_EXP = 8, OPT_COUNT = 16 };
 // OPT_EXP: TIMING EXPERIMENTS ONLY (wrong results): bit 1 = no bn_bwd_sum launch, 2 = no bn_finalize launch, 4 = no filter-gradient
 // reduce launches -- the upper bound of what folding those launches into their neighbours can give (scripts/step_opt_ab.py);
-// bit 32 (correct results) = filter gradients of ONE split still go through a slab and the reduce launch (as until round 5);
 // bit 16 (correct results) = forward launches with BatchNorm statistics never split (as until round 5);
 // bit 8 (correct results) = the chunk-ahead loader of the loss kernel instead of the cell-ahead one (loss.hip; scripts/loss_bench.py)
 int set_conv_workspace(void* p, size_t bytes, hipStream_t st);   // conv_win.hip

@@ -294,11 +294,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, (NB * (BM / 32 + BN / 32) * PL_PLAN
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (cok && co < a.Cout) {
-          // (one split: the tile's only owner -- plain read-modify-write, reproducible, no slab / reduce launch)
-          if (a.splits == 1) a.dw[(long long)co * a.ldw + cj] += acc[i][j][r] * unscale;
-          else atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[i][j][r] * unscale);
-        }
+        if (cok && co < a.Cout) atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[i][j][r] * unscale);
       }
     }
   }
@@ -403,7 +399,6 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   splits = (a.M + chunk - 1) / chunk;
   a.chunk = chunk;
   a.splits = (int)splits;
-  if (a.splits == 1 && !(g_opt[OPT_EXP] & 32)) a.slabs = nullptr;   // one owner per tile: it adds to dw itself (see the kernel)
   if (tiles * splits > 0x7fffffffLL || splits > 65535) {
     set_error("wgrad(planes): bad grid %lld x %lld", tiles, splits);
     return YOLO_ERR_INVALID_ARG;

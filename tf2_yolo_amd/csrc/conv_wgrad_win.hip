@@ -261,10 +261,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win_kernel(const WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      // (one split: this workgroup is the only one that adds to its tile of dw -- a plain read-modify-write, 128 contiguous
-      // bytes per half-wave, reproducible; no slabs and no reduce launch: launch_ww)
-      if (a.splits == 1) a.dw[(long long)co * a.ldw + cj] += acc[t][r] * unscale;
-      else atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[t][r] * unscale);
+      atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[t][r] * unscale);
     }
   }
 }
@@ -538,8 +535,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_win16_kernel(const WgradArgs a) 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int co = co0 + wave * 32 + 16 * m + 4 * (lane >> 4) + e;
-          if (a.splits == 1) a.dw[(long long)co * a.ldw + cj] += acc[t][hf][m][e] * unscale;
-          else atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[t][hf][m][e] * unscale);
+          atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[t][hf][m][e] * unscale);
         }
     }
 }
@@ -636,9 +632,9 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
   a.chunk = chunk;
   a.splits = (int)splits;
   a.nblocks = (int)(tiles * splits);
-  // ONE split (the small layers of a small batch: YOLOv1.5 at bs 4 has 196 pixels in its 7x7 layers): every tile has one
-  // owner, which adds its result to dw itself -- no 147 KB slab per workgroup, no reduce launch (17 us each, 10 per step there)
-  if (a.splits == 1 && !(g_opt[OPT_EXP] & 32)) a.slabs = nullptr;
+  // (one split -- the small layers of a small batch -- still goes through its slab: measured round 6, a tile's owner adding
+  // to dw itself with scalar read-modify-writes costs the kernel what the slab + reduce launch cost: 44 vs 25 + 17 us, and
+  // the 128 x 256 per-tap tile 103 vs 22 + 27 us)
   if constexpr (M16) hipLaunchKernelGGL((wgrad_win16_kernel<RING, KO>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((wgrad_win_kernel<RING, KO, PF>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
   if (int rc = check_launch("wgrad_win_kernel")) return rc;

@@ -1166,6 +1166,17 @@ class Network:
             elif u.kind == "maxpool":
                 if self._needs_grad[u.src.tid]:
                     cur = grads.get(u.src.tid)
+                    if (u.k == 2 and u.stride == 2 and u.pad_t == 0 and u.pad_l == 0 and u.src.h == 2 * u.out.h
+                            and u.src.w == 2 * u.out.w and u.out.c % 4 == 0 and torch.is_tensor(dout) and dout.is_contiguous()
+                            and (cur is None or torch.is_tensor(cur))):
+                        # the windows tile the input: every input position is written / added to once, no zero fill, no atomics
+                        if cur is None:
+                            cur = torch.empty((N, u.src.h, u.src.w, u.src.c), device=self.device, dtype=torch.float32)
+                            grads[u.src.tid] = cur
+                            ops.maxpool2x2_bwd(dout, N, u.out.h, u.out.w, u.out.c, u.argmax, cur, False)
+                        else:
+                            ops.maxpool2x2_bwd(dout, N, u.out.h, u.out.w, u.out.c, u.argmax, cur, True)
+                        continue
                     if cur is None:
                         cur = torch.empty((N, u.src.h, u.src.w, u.src.c), device=self.device, dtype=torch.float32)
                         ops.zero_bytes(cur)

@@ -935,6 +935,15 @@ def maxpool_bwd(dy, N, Ho, Wo, C, Cy, c_off, argmax, dx):
           "yolo_maxpool_bwd")
 
 
+def maxpool2x2_bwd(dy, N, Ho, Wo, C, argmax, dx, accumulate):
+    """backward of a 2x2 / stride-2 pool whose windows tile its [N, 2 Ho, 2 Wo, C] input: writes (accumulate False: no zero
+    fill needed) or adds to every input position exactly once, without atomics"""
+    if dx.numel() != N * 4 * Ho * Wo * C or dy.numel() != N * Ho * Wo * C or argmax.numel() != dy.numel():
+        raise YoloHipError("maxpool2x2_bwd: sizes do not match a pool that tiles its input")
+    check(_lib.load().yolo_maxpool2x2_bwd(_p(dy), N, Ho, Wo, C, _p(argmax), _p(dx), 1 if accumulate else 0, _stream()),
+          "yolo_maxpool2x2_bwd")
+
+
 def maxpool_bwd_same(dy, N, H, W, C, Cy, c_off, argmax, k, pad_t, pad_l, dx):
     """backward of a stride-1 'same' pool without atomics (yolo_maxpool_bwd_same): dx += gathered dy"""
     check(_lib.load().yolo_maxpool_bwd_same(_p(dy), N, H, W, C, Cy, c_off, _p(argmax), int(k), int(pad_t), int(pad_l), _p(dx),
