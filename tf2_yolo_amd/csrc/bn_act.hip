@@ -288,6 +288,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
             const float dz = dv[u][e] * act_grad(z, A);   // dv = 0 for out-of-range rows
             mdz = fmaxf(mdz, fabsf(dz));
             const float xh = (xv[u][e] - mu[e]) * iv[e];
+            // (round 6: adding the four rows of a batch in fp32 and only the batch sums in fp64 -- a quarter of the fp64
+            // operations -- measured +-0 on YOLOv4-608 and YOLOv3-416: the Mish pass is not bound by them)
             v[0][e] += (double)dz;
             v[1][e] += (double)dz * (double)xh;
           }
