@@ -70,7 +70,10 @@ int yolo_mfma_probe(const void* operands_f16, float* sink, int workgroups, int i
  * key -1 resets every option to its default. */
 enum { YOLO_OPT_CONV_WIN = 0, YOLO_OPT_STAMPS = 1, YOLO_OPT_CONV_SK = 2, YOLO_OPT_CONV_PATCH = 5, YOLO_OPT_WGRAD_WIN = 6,
        YOLO_OPT_NMS_WALK = 7 /* (env YOLO_NMS_WALK, default 0) hard / DIoU NMS: 1 = the greedy walk kernel for every class instead of the
-                                pair bit matrix + walk over the bits (same rows either way; tests) */ };
+                                pair bit matrix + walk over the bits (same rows either way; tests) */,
+       YOLO_OPT_AB = 8 /* (env YOLO_EXP, default 0) A/B bits of round 6, results identical either way: 8 = the loss kernel loads one
+                          64-channel chunk ahead instead of one cell ahead, 16 = forward convolutions with BatchNorm statistics are
+                          never split over several workgroups (as until round 5) */ };
 int yolo_set_option(int key, int value);
 /* Scratch for the split-K / stream-K forms of the planes convolutions (key 2 = YOLO_OPT_CONV_SK != 0): the accumulator
  * slabs of tiles computed by several workgroups (+ the stream-K form's tile tickets). The caller owns the memory

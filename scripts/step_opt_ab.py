@@ -1,8 +1,9 @@
 """Same process, same box, ONE model: blocks of K training steps alternating between settings of a library option
 (yolo_set_option, read at launch time, so the replayed tape follows it), wall time per step of each block.
 usage: step_opt_ab.py [--config c3|c4] [--k K] [--rounds R] --opt KEY  V0 V1 ...
-e.g. the timing knock-outs of OPT_EXP (8): 0 = the real step, 1 = no bn_bwd_sum launches, 2 = no bn_finalize launches,
-4 = no filter-gradient reduce launches (WRONG results in 1/2/4: upper bounds of what folding those launches away can give)."""
+e.g. the A/B bits of OPT_EXP (key 8): 0 = defaults, 8 = the loss kernel's chunk-ahead loader, 16 = forward launches with
+BatchNorm statistics unsplit. (Only options whose results stay correct: a knock-out that leaves NaN in the network measures a
+different power state, not the step.)"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")

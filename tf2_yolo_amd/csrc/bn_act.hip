@@ -903,7 +903,6 @@ extern "C" int yolo_bn_finalize_offset(double* stats, long long P, int C, const 
                "bn_finalize: bad args");
   YOLO_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), "bn_finalize: moving stats must come in pairs");
   static_assert(YOLO_BN_STAT_SLOTS == 64, "bn_finalize_kernel: one lane per replica slot");
-  if (!(g_opt[OPT_EXP] & 2))
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 15) / 16), dim3(1024), 0, as_stream(stream), stats, P, C, gamma,
                      beta, eps, momentum, unbiased_moving_var, moving_mean, moving_var, scale, shift, save_mean,
                      save_invstd, absmax, bound, mean_offset);
@@ -1019,7 +1018,6 @@ extern "C" int yolo_bn_act_bwd_reduce_fold_ld(const float* x, const float* dout,
   }
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<false>, grid, dim3(256), 0, as_stream(stream), x, dout, ldd, P, C, g.cw, g.rpp,
                      scale, shift, save_mean, save_invstd, act, red, bound_aux, (unsigned*)nullptr);
-  if (!(g_opt[OPT_EXP] & 1))
   hipLaunchKernelGGL(bn_bwd_sum_kernel, dim3((C + 15) / 16), dim3(256), 0, as_stream(stream), C, red, gx, P, scale,
                      bound_aux);
   return check_launch("bn_bwd_reduce_kernel");

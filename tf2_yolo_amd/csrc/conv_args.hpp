@@ -159,10 +159,11 @@ int launch_conv_win(GatherConvArgs& a, int variant, hipStream_t st);
 bool conv_win_supported(const GatherConvArgs& a);
 // run-time options (yolo_set_option; defaults from the environment): see runtime.hip
 enum { OPT_CONV_WIN = 0, OPT_STAMPS = 1, OPT_CONV_SK = 2, OPT_DBG = 3, OPT_TILE_ORDER = 4, OPT_CONV_PATCH = 5, OPT_WGRAD_WIN = 6, OPT_NMS_WALK = 7, OPT_EXP = 8, OPT_COUNT = 16 };
-// OPT_EXP: TIMING EXPERIMENTS ONLY (wrong results): bit 1 = no bn_bwd_sum launch, 2 = no bn_finalize launch, 4 = no filter-gradient
-// reduce launches -- the upper bound of what folding those launches into their neighbours can give (scripts/step_opt_ab.py);
-// bit 16 (correct results) = forward launches with BatchNorm statistics never split (as until round 5);
-// bit 8 (correct results) = the chunk-ahead loader of the loss kernel instead of the cell-ahead one (loss.hip; scripts/loss_bench.py)
+// OPT_EXP (YOLO_EXP): A/B switches of round 6, all with CORRECT results -- bit 8 = the chunk-ahead loader of the loss kernel
+// instead of the cell-ahead one (loss.hip; scripts/loss_bench.py), bit 16 = forward launches with BatchNorm statistics never
+// split (as until round 5; conv_win.hip: conv_split_parts). (Bits 1 / 2 / 4 were timing knock-outs of the small launches:
+// without bn_bwd_sum the gradients become NaN within a step, and a NaN-filled network runs 12 % FASTER than a real one --
+// the matrix pipes draw less power on constant operands -- so those timings measured nothing and the bits are gone.)
 int set_conv_workspace(void* p, size_t bytes, hipStream_t st);   // conv_win.hip
 extern void* g_dbg_buf;        // yolo_set_debug_buffer
 extern size_t g_dbg_bytes;

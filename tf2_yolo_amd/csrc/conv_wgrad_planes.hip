@@ -416,7 +416,6 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   if (int rc = check_launch("wgrad_planes_kernel")) return rc;
   if (a.slabs != nullptr) {
     const long long pieces = tiles * (BM * BN / 4);
-    if (!(g_opt[OPT_EXP] & 4))
     hipLaunchKernelGGL((wgrad_reduce_kernel<BM, BN, WGM, WGN>), dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, a);
     return check_launch("wgrad_reduce_kernel");
   }

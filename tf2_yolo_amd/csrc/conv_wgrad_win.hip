@@ -638,7 +638,7 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
   if constexpr (M16) hipLaunchKernelGGL((wgrad_win16_kernel<RING, KO>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((wgrad_win_kernel<RING, KO, PF>), dim3((unsigned)a.nblocks), dim3(256), lds, st, a);
   if (int rc = check_launch("wgrad_win_kernel")) return rc;
-  if (a.slabs != nullptr && !(g_opt[OPT_EXP] & 4)) {
+  if (a.slabs != nullptr) {
     const long long pieces = tiles * (WW_TILE_FLOATS / 4);
     if constexpr (M16) hipLaunchKernelGGL(wgrad_win16_reduce_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(wgrad_win_reduce_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, a);
