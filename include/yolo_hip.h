@@ -342,6 +342,16 @@ int yolo_bn_act_fwd_planes(const float* x, long long P, int C, const float* scal
                            int act, const float* residual, float* out, void* planes,
                            const unsigned* bn_bound, const float* residual_bound, float* out_bound,
                            void* stream);
+/* BatchNormalization + activation + MaxPooling2D(2, 2) in ONE pass over the conv output y [N, 2 Ho, 2 Wo, C] (round 6; the
+ * conv + BN + LeakyReLU + pool units of Darknet-19, yolov2/models/backbone.py:42-60, and of tiny-YOLOv3,
+ * yolov3/models/darknet.py:107-135): out [N, Ho, Wo, C] fp32 (may be NULL when only the planes are wanted) and / or the
+ * planes of the pooled tensor (C % 16 == 0; scaled from *bn_bound, the bound yolo_bn_finalize_bound left for the UNPOOLED
+ * activation -- a maximum of four values cannot exceed it), argmax [N, Ho, Wo, C] = the winner's flat offset into the
+ * activation tensor [N, 2 Ho, 2 Wo, C] (first maximum in row-major window order, as yolo_maxpool_fwd), which is never
+ * written: BatchNormalization's backward reads y, yolo_maxpool2x2_bwd only argmax. C % 8 == 0. */
+int yolo_bn_act_maxpool2x2_fwd(const float* y, int N, int Ho, int Wo, int C, const float* scale, const float* shift,
+                               int act, float* out, int* argmax, void* planes, const unsigned* bn_bound,
+                               float* out_bound, void* stream);
 /* yolo_bn_act_fwd_planes with the residual given AS PLANES (the operand format its producer wrote for the convolutions:
  * h + l = the value to 22-23 bits, the bound in the planes header): the fp32 copy of a residual block's input then need
  * not exist. C % 16 == 0. */

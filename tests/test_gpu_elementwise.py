@@ -497,3 +497,47 @@ def test_maxpool_2x2_stride2_tiling_kernels(N, hh, ww, c):
     acc = base.clone()
     ops.maxpool2x2_bwd(dyd, N, Ho, Wo, c, arg, acc, True)
     assert torch.equal(acc, base + scat)
+
+
+@pytest.mark.parametrize("N,hh,ww,C,act", [(2, 8, 6, 16, 1), (3, 26, 26, 64, 1), (1, 4, 4, 32, 2), (2, 52, 52, 32, 1), (1, 6, 10, 8, 1)])
+def test_bn_act_maxpool2x2_in_one_pass(N, hh, ww, C, act):
+    """yolo_bn_act_maxpool2x2_fwd (round 6): BatchNorm apply + activation + MaxPooling2D(2, 2) + the planes of the pooled
+    tensor in one launch against the three-launch path (bn_act_fwd -> maxpool_fwd -> split_planes): the pooled values and the
+    recorded winners are bit-identical, the planes decode to the pooled tensor within the format's accuracy under the bound of
+    the UNPOOLED activation, their tail rows and zero block are zero; C = 8 (no planes) gives the fp32 tensor alone."""
+    from planes_util import planes_to_dense
+    from tf2_yolo_amd import ops
+    g = torch.Generator().manual_seed(N + hh + C + act)
+    dev = "cuda"
+    y = (torch.randn(N, hh, ww, C, generator=g) * 2 + 0.3).to(dev)
+    y[:, ::2, ::2] = y[:, 1::2, 1::2]                      # exact ties inside every window (first element wins)
+    P = N * hh * ww
+    gd = (torch.rand(C, generator=g) + 0.5).to(dev)
+    bd = torch.randn(C, generator=g).to(dev)
+    stats = torch.zeros(64 * 2 * C, device=dev, dtype=torch.float64)
+    f = lambda: torch.empty(C, device=dev)
+    scale, shift, smean, sinv = f(), f(), f(), f()
+    aux = torch.zeros(4, device=dev, dtype=torch.int32)
+    ops.bn_stats(y, C, stats)
+    ops.bn_finalize(stats, P, C, gd, bd, None, None, scale, shift, smean, sinv, bound=aux[0:1])
+    a = ops.bn_act_fwd(y, C, scale, shift, act)
+    Ho, Wo = hh // 2, ww // 2
+    ref = torch.empty(N, Ho, Wo, C, device=dev)
+    arg_ref = torch.empty(N, Ho, Wo, C, device=dev, dtype=torch.int32)
+    ops.maxpool_fwd(a, 2, 2, 0, 0, Ho, Wo, ref, C, 0, arg_ref)
+    out = torch.full((N, Ho, Wo, C), float("nan"), device=dev)
+    arg = torch.full((N, Ho, Wo, C), -5, device=dev, dtype=torch.int32)
+    pl = torch.full((ops.planes_bytes(N * Ho * Wo, C),), 0x55, device=dev, dtype=torch.uint8) if C % 16 == 0 else None
+    ob = torch.zeros(1, device=dev)
+    ops.bn_act_maxpool2x2_fwd(y, C, scale, shift, act, arg, out=out, planes=pl, bn_bound=aux[0:1], out_bound=ob)
+    assert torch.equal(out, ref) and torch.equal(arg, arg_ref)
+    if pl is not None:
+        dense, bound, s, tail0 = planes_to_dense(pl.cpu(), N * Ho * Wo, C)
+        assert tail0 and bound == float(aux[0:1].view(torch.float32)) == float(ob) and bound >= float(a.abs().max())
+        r = ref.double().cpu().reshape(-1, C)
+        assert ((dense - r).abs() <= torch.maximum(2.0 ** -22 * r.abs(), torch.tensor(2.0 ** -25 / s, dtype=torch.float64))).all()
+        only = torch.full_like(pl, 0x33)
+        arg2 = torch.empty_like(arg)
+        ops.bn_act_maxpool2x2_fwd(y, C, scale, shift, act, arg2, out=None, planes=only, bn_bound=aux[0:1])
+        used = pl.numel() - 256 + 12          # body + the three header words (the rest of the 256-byte header is never written)
+        assert torch.equal(only[:used], pl[:used]) and torch.equal(arg2, arg)

@@ -114,6 +114,7 @@ SIGNATURES = {
                                  _P, c_int, c_int, _P, _P]),
     "yolo_maxpool_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P]),
     "yolo_maxpool2x2_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P]),
+    "yolo_bn_act_maxpool2x2_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P, _P, _P]),
     "yolo_maxpool_bwd_same": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P, _P]),
     "yolo_space_to_depth2_fwd": (c_int, [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P]),
     "yolo_space_to_depth2_bwd": (c_int, [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int, _P]),

@@ -991,6 +991,91 @@ static int bn_act_fwd_impl(const float* x, long long P, int C, const float* scal
   return check_launch("bn_act_fwd_kernel");
 }
 
+// ---- BatchNormalization + activation + MaxPooling2D(2, 2) in one pass (round 6) ----
+// Darknet-19 / tiny-YOLOv3 put a 2x2 / stride-2 pool behind five of their conv + BN + LeakyReLU units
+// (yolov2/models/backbone.py:42-60, yolov3/models/darknet.py:107-135). As three launches -- BN apply writing the fp32
+// activation (the pool reads fp32), the pool, then an absmax + split pass that makes the planes of the pooled tensor for the
+// next convolution -- the big pre-pool activation is written and read once each (709 MB for the first pool of YOLOv2-416 at
+// bs 16) although nothing ever reads it again: BatchNorm's backward needs y, the pool's backward only the recorded winner.
+// Here a thread owns 8 channels of one POOLED pixel: it normalises and activates the four window positions from y, takes the
+// maximum (first maximum in row-major window order, v > best, as yolo_maxpool_fwd), records the winner as the flat offset
+// into the (never written) activation tensor, and writes the pooled value as fp32 (optional) and as planes, scaled from the
+// BatchNorm output's bound (a maximum of four values cannot exceed it). Rows [P, rows_total) of the planes are zero-filled.
+__global__ __launch_bounds__(256) void bn_act_pool2_fwd_kernel(const float* __restrict__ y, long long P, long long rows_total,
+                                                               int Ho, int Wo, int C, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, int act,
+                                                               float* __restrict__ out, int* __restrict__ argmax,
+                                                               unsigned char* __restrict__ planes,
+                                                               const unsigned* __restrict__ bn_bound,
+                                                               float* __restrict__ out_bound) {
+  float psc = 1.f;
+  const float b = bn_bound ? __builtin_bit_cast(float, bn_bound[0]) : 0.f;
+  if (out_bound != nullptr && blockIdx.x == 0 && threadIdx.x == 0) out_bound[0] = b;
+  if (planes != nullptr) psc = planes_begin(planes, P, C, b);
+  const int C8 = C >> 3, W = 2 * Wo;
+  const long long n = rows_total * C8;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    // (16 consecutive threads = the 16 rows of one planes sub-block: whole 256-byte pieces per store; fp32 rows are read /
+    // written 32 bytes per thread)
+    const long long blk = i / (16 * C8);
+    const int r16 = (int)(i & 15);
+    const int g8 = (int)((i >> 4) % C8);
+    const long long p = blk * 16 + r16;          // pooled pixel (b, ho, wo), row-major
+    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+    if (p < P) {
+      const f32x4 sc0 = reinterpret_cast<const f32x4*>(scale)[2 * g8], sc1 = reinterpret_cast<const f32x4*>(scale)[2 * g8 + 1];
+      const f32x4 sh0 = reinterpret_cast<const f32x4*>(shift)[2 * g8], sh1 = reinterpret_cast<const f32x4*>(shift)[2 * g8 + 1];
+      const int wo = (int)(p % Wo);
+      const long long bh = p / Wo;               // b * Ho + ho: the window's input rows are 2 bh and 2 bh + 1
+      const long long o00 = ((2 * bh) * W + 2 * wo) * C + g8 * 8;
+      i32x4 a0, a1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const long long o = o00 + ((long long)(t >> 1) * W + (t & 1)) * C;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(y + o), x1 = *reinterpret_cast<const f32x4*>(y + o + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float v0 = act_fwd(fmaf(sc0[k], x0[k], sh0[k]), act);
+          const float v1 = act_fwd(fmaf(sc1[k], x1[k], sh1[k]), act);
+          if (t == 0 || v0 > o0[k]) {
+            o0[k] = v0;
+            a0[k] = (int)o + k;
+          }
+          if (t == 0 || v1 > o1[k]) {
+            o1[k] = v1;
+            a1[k] = (int)o + 4 + k;
+          }
+        }
+      }
+      const long long e = p * C + g8 * 8;
+      if (out != nullptr) {
+        *reinterpret_cast<f32x4*>(out + e) = o0;
+        *reinterpret_cast<f32x4*>(out + e + 4) = o1;
+      }
+      *reinterpret_cast<i32x4*>(argmax + e) = a0;
+      *reinterpret_cast<i32x4*>(argmax + e + 4) = a1;
+    }
+    if (planes != nullptr) store_planes8(planes, p, g8, C, o0, o1, psc);
+  }
+}
+
+extern "C" int yolo_bn_act_maxpool2x2_fwd(const float* y, int N, int Ho, int Wo, int C, const float* scale, const float* shift,
+                                          int act, float* out, int* argmax, void* planes, const unsigned* bn_bound,
+                                          float* out_bound, void* stream) {
+  YOLO_REQUIRE(y && scale && shift && argmax && (out || planes) && N > 0 && Ho > 0 && Wo > 0, "bn_act_maxpool2x2_fwd: bad args");
+  YOLO_REQUIRE(C > 0 && C % 8 == 0 && (planes == nullptr || C % 16 == 0),
+               "bn_act_maxpool2x2_fwd: C=%d must be a multiple of 8 (16 with planes)", C);
+  YOLO_REQUIRE(act >= 0 && act <= 2, "bn_act_maxpool2x2_fwd: bad activation %d", act);
+  YOLO_REQUIRE(planes == nullptr || bn_bound != nullptr, "bn_act_maxpool2x2_fwd: planes output needs the bound from bn_finalize");
+  YOLO_REQUIRE((long long)N * 4 * Ho * Wo * C < (1LL << 31), "bn_act_maxpool2x2_fwd: tensor too large for int32 argmax");
+  const long long P = (long long)N * Ho * Wo;
+  const long long rows = planes ? ((P + 15) / 16 + 1) * 16 : (P + 15) / 16 * 16;
+  const long long n = rows * (C / 8);
+  hipLaunchKernelGGL(bn_act_pool2_fwd_kernel, dim3(stream_grid(n, 256)), dim3(256), 0, as_stream(stream), y, P, rows, Ho, Wo, C,
+                     scale, shift, act, out, argmax, reinterpret_cast<unsigned char*>(planes), bn_bound, out_bound);
+  return check_launch("bn_act_pool2_fwd_kernel");
+}
+
 extern "C" int yolo_bn_act_fwd(const float* x, long long P, int C, const float* scale, const float* shift, int act,
                                const float* residual, float* out, void* stream) {
   return yolo_bn_act_fwd_planes(x, P, C, scale, shift, act, residual, out, nullptr, nullptr, nullptr, nullptr, stream);

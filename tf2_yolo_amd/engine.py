@@ -421,6 +421,27 @@ class Network:
                 has_planes_src = any(c.kind in ("conv", "head") and c.src.tid == u.out.tid and c.planes_fwd for c in cs)
                 u.a_needed = ((not cs) or (u.out.tid in out_tids) or u.cout % 16 != 0 or not has_planes_src
                               or any(not reads_planes_only(c) for c in cs))
+        # conv + BN + activation units whose ONLY consumer is a 2x2 / stride-2 pool that tiles their output (Darknet-19,
+        # tiny-YOLOv3): in training the BatchNorm apply, the pool and the planes of the pooled tensor are ONE launch
+        # (yolo_bn_act_maxpool2x2_fwd) and the unpooled activation is never written (YOLO_POOL_FUSE=0: three launches)
+        self._pool_fuse = os.environ.get("YOLO_POOL_FUSE", "1") != "0"
+        for u in self.units:
+            u.pool_fuse = None
+        if self._pool_fuse:
+            for u in self.units:
+                if u.kind != "conv" or not u.bn or u.residual is not None or u.out.tid in out_tids:
+                    continue
+                cs = consumers.get(u.out.tid, [])
+                if len(cs) != 1 or cs[0].kind != "maxpool":
+                    continue
+                p = cs[0]
+                if (p.k == 2 and p.stride == 2 and u.out.h % 2 == 0 and u.out.w % 2 == 0 and p.out.h * 2 == u.out.h
+                        and p.out.w * 2 == u.out.w and u.cout % 8 == 0 and p.padding in ("same", "valid")):
+                    pcs = consumers.get(p.out.tid, [])
+                    p.f32_needed = (p.out.tid in out_tids) or (not pcs) or p.out.c % 16 != 0 or any(
+                        not (c.kind in ("conv", "head") and c.src.tid == p.out.tid and c.planes_fwd and c.planes_wgrad
+                             and getattr(c, "residual", None) is not p.out) for c in pcs)
+                    u.pool_fuse = p
         # concat units write the planes of their result directly from the fp32 sources (yolo_split_planes_concat): the fp32
         # concatenation is produced only if somebody other than a planes convolution reads it; a source's bound is the one
         # its producer recorded -- BatchNorm's output bound, or, through pools / upsampling / space-to-depth (which cannot
@@ -868,6 +889,21 @@ class Network:
                             ops.bn_fold_inference(u.cout, gamma, beta, self.state.view(u.s_mean.name),
                                                   self.state.view(u.s_var.name), scale, shift)
                         ops.bn_infer_bound(u.cout, scale, shift, amax, self._aux[u.aux_off:u.aux_off + 1])
+                    if training and u.pool_fuse is not None:
+                        # BatchNorm apply + activation + the 2x2 pool behind it + the pooled tensor's planes in one launch; the
+                        # unpooled activation is not written (its only reader would have been the pool)
+                        pu = u.pool_fuse
+                        ppl = self._xplanes.get(pu.out.tid) if pu.out.c % 16 == 0 else None
+                        tb = self._tbound
+                        ops.bn_act_maxpool2x2_fwd(u.y, u.cout, scale, shift, u.act, pu.argmax,
+                                                  out=pu.buf if (pu.f32_needed or ppl is None) else None, planes=ppl,
+                                                  bn_bound=self._aux[u.aux_off:u.aux_off + 1],
+                                                  out_bound=tb[pu.out.tid:pu.out.tid + 1])
+                        self._tbound_set.add(pu.out.tid)
+                        if ppl is not None:
+                            self._xp_valid.add(pu.out.tid)
+                        pu.fused_this_pass = True
+                        continue
                     res = self.act[u.residual.tid] if u.residual is not None else None
                     res_pl = None
                     if (res is not None and training and self._res_from_planes and u.cout % 16 == 0
@@ -919,6 +955,9 @@ class Network:
                     ops.copy_channels_in(self.act[s.tid], s.c, u.buf, u.out.c, off)
                     off += s.c
             elif u.kind == "maxpool":
+                if getattr(u, "fused_this_pass", False):   # made by its producer's BatchNorm launch (pool_fuse)
+                    u.fused_this_pass = False
+                    continue
                 ops.maxpool_fwd(self.act[u.src.tid], u.k, u.stride, u.pad_t, u.pad_l, u.out.h, u.out.w, u.buf,
                                 u.out.c, 0, u.argmax if training else None)
             elif u.kind == "space_to_depth":

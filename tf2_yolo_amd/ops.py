@@ -935,6 +935,22 @@ def maxpool_bwd(dy, N, Ho, Wo, C, Cy, c_off, argmax, dx):
           "yolo_maxpool_bwd")
 
 
+def bn_act_maxpool2x2_fwd(y, C, scale, shift, act, argmax, out=None, planes=None, bn_bound=None, out_bound=None):
+    """BatchNormalization + activation + MaxPooling2D(2, 2) of the conv output y [N, 2 Ho, 2 Wo, C] in one pass
+    (yolo_bn_act_maxpool2x2_fwd): fp32 pooled tensor `out` and / or its planes, argmax as yolo_maxpool_fwd records it"""
+    n, h, w, c = y.shape
+    if c != C or h % 2 or w % 2 or C % 8 or argmax.numel() != n * (h // 2) * (w // 2) * C:
+        raise YoloHipError("bn_act_maxpool2x2_fwd: y must be [N, even, even, C % 8 == 0], argmax [N, H/2, W/2, C]")
+    if out is None and planes is None:
+        raise YoloHipError("bn_act_maxpool2x2_fwd: nothing to produce")
+    if planes is not None and planes.numel() < planes_bytes(n * (h // 2) * (w // 2), C):
+        raise YoloHipError("bn_act_maxpool2x2_fwd: planes buffer too small")
+    check(_lib.load().yolo_bn_act_maxpool2x2_fwd(_p(y), n, h // 2, w // 2, C, _p(scale), _p(shift), int(act), _p(out), _p(argmax),
+                                                 _p(planes), _p(bn_bound), _p(out_bound), _stream()),
+          "yolo_bn_act_maxpool2x2_fwd")
+    return out
+
+
 def maxpool2x2_bwd(dy, N, Ho, Wo, C, argmax, dx, accumulate):
     """backward of a 2x2 / stride-2 pool whose windows tile its [N, 2 Ho, 2 Wo, C] input: writes (accumulate False: no zero
     fill needed) or adds to every input position exactly once, without atomics"""
