@@ -77,3 +77,25 @@ def test_gloo_world2_allreduce_mean():
         assert scale == 0.5 and nb > 1
         assert np.allclose(g, expect)
         assert np.all(params == 0.0)                                  # rank 0's weights everywhere
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """`python bench.py --gpus 2` without a torchrun environment starts its own ranks (bench.launch_ranks); here there is no
+    GPU, so both ranks fail at their first device call: the launcher must stop, exit non-zero and print no JSON line. (The
+    working case -- two gloo ranks sharing one GPU -- is tests/test_gpu_dp.py.)"""
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("a GPU is present: the ranks would run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, YOLO_BENCH_SINGLE_DEVICE="1", YOLO_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extra-blocks"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "stopping the other ranks" in r.stderr or "exited with" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
