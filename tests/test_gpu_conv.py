@@ -955,7 +955,7 @@ WGRAD_WIN_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant", [1, 3])      # 1: v_mfma_f32_32x32x16_f16, 3: the same kernel on v_mfma_f32_16x16x32_f16
+@pytest.mark.parametrize("variant", [1, 3, 4])   # 1: v_mfma_f32_32x32x16_f16, 3: on v_mfma_f32_16x16x32_f16, 4: two pixel halves per workgroup (half the slabs)
 @pytest.mark.parametrize("case", WGRAD_WIN_CASES)
 def test_conv_wgrad_window_kernel(case, variant):
     """wgrad_win_kernel: all nine taps of 32 input channels from ONE ring of x pixels in LDS, borders by pointing invalid
