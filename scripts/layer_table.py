@@ -1,7 +1,7 @@
 """Per-layer account of the planes conv launches of the YOLOv3-416 bs-32 training step: device time INSIDE the two-stream
 step (HIP events around each launch, ops.KernelTimer) beside the same launch run ALONE (back to back on an idle chip) --
 the table VERDICT r02 #6 asks for (in-step vs standalone rate of the window / patch / filter-gradient kernels).
-usage: python scripts/layer_table.py out.json"""
+usage: python scripts/layer_table.py out.json [c3|c4]"""
 import json
 import os
 import sys
@@ -15,13 +15,22 @@ import yolov3
 from tf2_yolo_amd import labels, ops, optimizers
 
 out_path = sys.argv[1] if len(sys.argv) > 1 else None
-N, HW, C = 32, 416, 80
-yolo = yolov3.Yolo((HW, HW, 3), [f"c{i}" for i in range(C)])
-yolo.create_model(pretrained_body=None, seed=1234)
+CONFIG = sys.argv[2] if len(sys.argv) > 2 else "c3"      # c3: YOLOv3-416 bs 32 (default), c4: YOLOv4-608 bs 16
+if CONFIG == "c4":
+    import yolov4
+    from tf2_yolo_amd import graphs
+    N, HW, C = 16, 608, 80
+    yolo = yolov4.Yolo((HW, HW, 3), [f"c{i}" for i in range(C)])
+    yolo.create_model(anchors=graphs.V4_DEFAULT_ANCHORS, pretrained_body=None)
+else:
+    N, HW, C = 32, 416, 80
+    yolo = yolov3.Yolo((HW, HW, 3), [f"c{i}" for i in range(C)])
+    yolo.create_model(pretrained_body=None, seed=1234)
 m = yolo.model
 m.compile(optimizer=optimizers.Adam(learning_rate=1e-4), loss=yolo.loss())
 rng = np.random.default_rng(1234)
-x_h, ys_h = labels.synthetic_batch(rng, N, (HW, HW), C)
+x_h, ys_h = (labels.synthetic_batch(rng, N, (HW, HW), C, levels=3, finest_stride=8) if CONFIG == "c4"
+            else labels.synthetic_batch(rng, N, (HW, HW), C))
 x = torch.from_numpy(x_h).cuda()
 ys = [torch.from_numpy(y).cuda() for y in ys_h]
 for _ in range(3):
@@ -109,7 +118,7 @@ for k in by_kernel.values():
     for f in ("ms_in_step", "ms_one_stream", "ms_alone"):
         k["frac_of_833_" + f[3:]] = round(k["gflop"] / k[f] / 833.3, 3) if k[f] else None
         k[f] = round(k[f], 3)
-res = {"what": "YOLOv3-416 bs 32 training step, planes conv launches: us per launch inside the two-stream step, inside the step with "
+res = {"what": ("YOLOv4-608 bs 16" if CONFIG == "c4" else "YOLOv3-416 bs 32") + " training step, planes conv launches: us per launch inside the two-stream step, inside the step with "
                "the filter-gradient stream off, and alone (12 back-to-back launches of the same shape on random data)",
        "device": torch.cuda.get_device_name(0), "by_kernel": by_kernel, "layers": rows}
 print(json.dumps(res["by_kernel"], indent=1))
