@@ -207,3 +207,28 @@ def test_no_product_module_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+
+
+def test_header_is_plain_c_and_a_c_host_links_the_library(tmp_path):
+    """The boundary is a C-ABI: include/yolo_hip.h must compile as C99 (pedantic) and as C++, and a host written in C
+    (examples/c_host/abi_check.c: no Python, no torch) must link libyolo_hip.so and get the ABI version, status codes and
+    yolo_last_error() messages -- without a GPU (no compute call is made)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        import pytest
+        pytest.skip("no gcc")
+    hdr = os.path.join(ROOT, "include", "yolo_hip.h")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", hdr],
+                ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-x", "c++", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+    exe = str(tmp_path / "abi_check")
+    libdir = os.path.join(ROOT, "tf2_yolo_amd")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "c_host", "abi_check.c"), "-o", exe, "-L" + libdir, "-lyolo_hip",
+                        "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "abi 5" in r.stdout and "bad args" in r.stdout
