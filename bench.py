@@ -406,18 +406,23 @@ def launch_ranks(args):
     rd.start()
     code = 0
     alive = list(procs)
-    while alive:
-        for p in list(alive):
-            rc = p.poll()
-            if rc is None:
-                continue
-            alive.remove(p)
-            if rc != 0 and code == 0:
-                code = rc if rc > 0 else 1
-                print(f"[bench] rank {procs.index(p)} exited with {rc}: stopping the other ranks", file=sys.stderr, flush=True)
-                for q in alive:
-                    q.terminate()          # (exactly the PIDs started here)
-        time.sleep(0.2)
+    try:
+        while alive:
+            for p in list(alive):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                alive.remove(p)
+                if rc != 0 and code == 0:
+                    code = rc if rc > 0 else 1
+                    print(f"[bench] rank {procs.index(p)} exited with {rc}: stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in alive:
+                        q.terminate()          # (exactly the PIDs started here)
+            time.sleep(0.2)
+    finally:
+        for q in alive:                        # the launcher itself is going away (signal, exception): no orphaned ranks
+            if q.poll() is None:
+                q.terminate()
     rd.join(timeout=10)
     sys.stdout.write("".join(out0))
     sys.stdout.flush()
