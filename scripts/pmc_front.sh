@@ -21,4 +21,6 @@ run_one l2_fwd_3x3s2_416_32to64 gather_conv_planes_kernel fwd 416,32,64,3,2,32
 run_one l2_dgrad_3x3s2_416_32to64 gather_conv_planes_kernel dgrad 416,32,64,3,2,32
 run_one l5_fwd_3x3s2_208_64to128 gather_conv_planes_kernel fwd 208,64,128,3,2,32
 run_one l7_dgrad_3x3_104_64to128 gather_conv_planes_kernel dgrad 104,64,128,3,1,32
+run_one l2_wgrad_3x3s2_416_32to64 wgrad_planes_kernel wgrad 416,32,64,3,2,32
+run_one l4_wgrad_3x3_208_32to64 wgrad_planes_kernel wgrad 208,32,64,3,1,32
 python3 $R/scripts/pmc_json.py $OUT > $R/gpurun_out/${TAG}_layers_pmc.json
