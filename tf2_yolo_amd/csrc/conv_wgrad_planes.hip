@@ -373,7 +373,10 @@ static int launch_wp(WgradArgs& a, hipStream_t st) {
   }
   // (round 3, slabs instead of atomics, same finding: 512 / 768 workgroups for the 1x1 layers are 12-25 % slower than 256,
   // and a deeper DMA ring (NB = 4..6) changes nothing: these launches are not bound by bytes in flight)
-  long long target = a.ntaps == 1 ? 256 : (target_env > 0 ? target_env : 1024);   // (YOLO_WGRAD_TARGET: 3x3 layers only)
+  // (YOLO_WGRAD_TARGET_1X1: tuning knob for the 1x1 layers)
+  static const long long target_1x1_env = [] { const char* e = getenv("YOLO_WGRAD_TARGET_1X1"); return e ? atoll(e) : 0LL; }();
+  long long target = a.ntaps == 1 ? (target_1x1_env > 0 ? target_1x1_env : 256)
+                                  : (target_env > 0 ? target_env : 1024);   // (YOLO_WGRAD_TARGET: 3x3 layers only)
   if (target_env <= 0 && a.ntaps > 1) {
     const long long s1 = resident / tiles, s2 = 2LL * resident / tiles;
     if (s1 >= 1 && tiles * s1 * 10 >= 7LL * resident) target = tiles * s1;         // one round, at least 70 % full

@@ -878,9 +878,16 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
     if (resident <= 0) resident = 512;
   }
   if (!lds_from_zero) return 1;
-  // one round of the workgroups the chip holds; at least 8 stages per workgroup
+  // A QUARTER of the workgroups the chip holds at once (128 on 256 CUs; round 6), at least 8 stages per workgroup. Until
+  // round 5 the target was a full round of resident workgroups (two per CU). Alone the kernel prefers that; in the step it is
+  // a LEAF on a stream with slack, and every workgroup it keeps resident takes 65 KB of a CU's LDS from the compute stream's
+  // window data gradient -- the critical chain (the lesson of the two-half kernel below) -- while a quarter of the workgroups
+  // are a quarter of the slab bytes (19 instead of 75 MB written, 21 instead of 85 MB read back, per launch). Same-box A/B,
+  // 512 -> 128 workgroups: YOLOv3-416 28.80-28.90 -> 28.69-28.77 ms, YOLOv2-416 7.22-7.24 -> 7.03-7.07, YOLOv4-608 36.98-37.09
+  // -> 36.31-36.39; 160 / 256: within 0.1 ms of that; 96: C3 29.01; 64: C3 30.98; 768 / 1024: slower than 512
+  // (profiles/r06_j_wgrad_win_target_ab.log). YOLO_WGRAD_WIN_TARGET overrides.
   static const long long target_env = [] { const char* e = getenv("YOLO_WGRAD_WIN_TARGET"); return e ? atoll(e) : 0LL; }();
-  const long long target = target_env > 0 ? target_env : resident;
+  const long long target = target_env > 0 ? target_env : (resident >= 4 ? resident / 4 : resident);
   long long splits = target / tiles;
   const long long max_splits = (a.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
