@@ -878,16 +878,19 @@ static int launch_ww(WgradArgs& a, hipStream_t st) {
     if (resident <= 0) resident = 512;
   }
   if (!lds_from_zero) return 1;
-  // A QUARTER of the workgroups the chip holds at once (128 on 256 CUs; round 6), at least 8 stages per workgroup. Until
-  // round 5 the target was a full round of resident workgroups (two per CU). Alone the kernel prefers that; in the step it is
-  // a LEAF on a stream with slack, and every workgroup it keeps resident takes 65 KB of a CU's LDS from the compute stream's
-  // window data gradient -- the critical chain (the lesson of the two-half kernel below) -- while a quarter of the workgroups
-  // are a quarter of the slab bytes (19 instead of 75 MB written, 21 instead of 85 MB read back, per launch). Same-box A/B,
-  // 512 -> 128 workgroups: YOLOv3-416 28.80-28.90 -> 28.69-28.77 ms, YOLOv2-416 7.22-7.24 -> 7.03-7.07, YOLOv4-608 36.98-37.09
-  // -> 36.31-36.39; 160 / 256: within 0.1 ms of that; 96: C3 29.01; 64: C3 30.98; 768 / 1024: slower than 512
-  // (profiles/r06_j_wgrad_win_target_ab.log). YOLO_WGRAD_WIN_TARGET overrides.
+  // ONE workgroup per CU -- half of what the chip holds at once (256 on 256 CUs; round 6), at least 8 stages per workgroup.
+  // Until round 5 the target was a full round of resident workgroups (two per CU). Alone the kernel prefers that; in the step
+  // it is a LEAF on a stream with slack, and every workgroup it keeps resident takes 65 KB of a CU's LDS from the compute
+  // stream's window data gradient -- the critical chain (the lesson of the two-half kernel below) -- while half the workgroups
+  // are half the slab bytes (37 instead of 75 MB written, 43 instead of 85 MB read back, per launch). Same-box sweeps
+  // (profiles/r06_j_wgrad_win_target_ab.log), 512 -> 256 / 160 / 128 workgroups: YOLOv3-416 28.80-28.90 -> 28.72-28.79 / 28.70 /
+  // 28.69-28.77 ms; YOLOv2-416 7.22-7.24 -> 7.05-7.11 / 7.08 / 7.03-7.07; YOLOv4-608 36.98-37.09 -> 36.74-36.84 / 36.41 /
+  // 36.31-36.39; 96: C3 29.01; 64: C3 30.98; 768 / 1024: slower than 512. 256 is the default: the headline is flat from 128 to
+  // 256, and below 256 this kernel -- throttled on purpose -- becomes the one with the most device time in the step, so that
+  // the step's roofline line would describe a launch that is not trying to fill the chip. YOLO_WGRAD_WIN_TARGET=128 is the
+  // better setting for YOLOv4-608 (compute stream 98 % busy, filter-gradient stream with 20 % slack).
   static const long long target_env = [] { const char* e = getenv("YOLO_WGRAD_WIN_TARGET"); return e ? atoll(e) : 0LL; }();
-  const long long target = target_env > 0 ? target_env : (resident >= 4 ? resident / 4 : resident);
+  const long long target = target_env > 0 ? target_env : (resident >= 2 ? resident / 2 : resident);
   long long splits = target / tiles;
   const long long max_splits = (a.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
