@@ -643,10 +643,17 @@ def main():
         roof = None
         if timer is not None:
             agg = timer.summary()
-            name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
+            # the dominant kernel = the family with the most device time in the timed steps; families within 10 % of the top
+            # are ranked by their algorithmic FLOPs (the window forward / data gradient and the x-window filter gradient sit
+            # within 5 % of each other since round 6 launches the latter -- a leaf on the second stream -- on one workgroup per
+            # CU: box-to-box noise must not decide which of the two the line describes)
+            top_ms = max(v["ms"] for v in agg.values())
+            name, a = max(((k, v) for k, v in agg.items() if v["ms"] >= 0.9 * top_ms), key=lambda kv: kv[1]["flops"])
             achieved = a["flops"] / (a["ms"] * 1e-3) / 1e12
             peak = kernel_peak(name)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": round(peak, 1),
+                    "dominance_rule": "most device time over the timed steps; families within 10 % of the top ranked by algorithmic FLOPs",
+                    "most_device_time_kernel": max(agg.items(), key=lambda kv: kv[1]["ms"])[0],
                     "peak_basis": ("fp16 MFMA dense peak 2500 TFLOP/s / 3 passes per product (two scaled fp16 planes)"
                                    if "planes" in name else
                                    "bf16 MFMA dense peak 2500 TFLOP/s / 6 passes per fp32 product (exact 3-way split)"
