@@ -263,7 +263,7 @@ def _kink_census(version, y_true, pred_oracle, pred_dev, class_num):
                                                       (3, True, "416"), (4, True, "608"), (2, True, "416"),
                                                       (3, True, "tiny416"), (4, True, "608bs1"),
                                                       (3, True, "416c80bs8"), (4, True, "608refinit"),
-                                                      (3, True, "416c80bs32")])
+                                                      (3, True, "416c80bs32"), (4, True, "608c80bs4")])
 def test_model_parity(version, unbiased, true_c1):
     from tf2_yolo_amd import optimizers
     import conftest
@@ -294,6 +294,11 @@ def test_model_parity(version, unbiased, true_c1):
         # every parameter gradient against the float64 oracle's autograd (~75 GB of host memory for the two CPU graphs)
         y, model, fwd, loss_o, loss_g, x, ys = _setup(3, hw=416, N=32, unbiased=unbiased, class_num=80)
         assert [tuple(o.shape[1:]) for o in model.output] == [(13, 13, 255), (26, 26, 255), (52, 52, 255)] and x.shape[0] == 32
+    elif true_c1 == "608c80bs4":
+        # YOLOv4-608 with the benchmark's 80 classes (255-channel heads, CIoU loss at C = 80) at batch 4: every parameter
+        # gradient against the float64 oracle, as [3-True-416c80bs8] does for the headline graph
+        y, model, fwd, loss_o, loss_g, x, ys = _setup(4, hw=608, N=4, unbiased=unbiased, class_num=80)
+        assert sorted(tuple(o.shape[1:]) for o in model.output) == [(19, 19, 255), (38, 38, 255), (76, 76, 255)]
     elif true_c1 == "608refinit":
         # VERDICT r05 next #2c: YOLOv4-608 (bs 2) under the reference's OWN initialiser (N(0, 0.02) kernels, gamma 1, beta 0:
         # yolov4/models/backbone.py:63-111) instead of the he-normal kernels of the other cases; its fp32 floor is logged
