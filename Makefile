@@ -3,7 +3,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := tf2_yolo_amd/csrc
-SRCS  := $(CSRC)/runtime.hip $(CSRC)/probe.hip $(CSRC)/conv.hip $(CSRC)/conv_split.hip $(CSRC)/conv_wgrad_split.hip $(CSRC)/conv_planes.hip $(CSRC)/conv_win.hip $(CSRC)/conv_wgrad_planes.hip $(CSRC)/conv_wgrad_win.hip $(CSRC)/stem.hip $(CSRC)/bn_act.hip $(CSRC)/elementwise.hip \
+SRCS  := $(CSRC)/runtime.hip $(CSRC)/probe.hip $(CSRC)/conv.hip $(CSRC)/conv_split.hip $(CSRC)/conv_wgrad_split.hip $(CSRC)/conv_planes.hip $(CSRC)/conv_win.hip $(CSRC)/conv_small.hip $(CSRC)/conv_wgrad_planes.hip $(CSRC)/conv_wgrad_win.hip $(CSRC)/stem.hip $(CSRC)/bn_act.hip $(CSRC)/elementwise.hip \
          $(CSRC)/labels.hip $(CSRC)/loss.hip $(CSRC)/decode_nms.hip $(CSRC)/iou.hip $(CSRC)/measure.hip
 OBJS  := $(SRCS:.hip=.o)
 LIB   := tf2_yolo_amd/libyolo_hip.so

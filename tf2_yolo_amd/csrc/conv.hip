@@ -941,6 +941,8 @@ extern "C" int yolo_conv2d_fwd_infer_unit(const yolo_conv_desc* d, const void* x
   a.pl_res_n = residual != nullptr ? residual_n : 0;
   a.pl_out_words = out_words;
   YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_infer_unit: needs Cin %% 16 == 0 and Cout >= 32");
+  // few output pixels (bs-1 predict): the whole unit in ONE launch, K split across the waves of a workgroup (conv_small.hip)
+  if (conv_small_supported(a)) return launch_conv_small(a, as_stream(stream), out_n_host);
   if (int rc = launch_gather_planes(a, as_stream(stream))) return rc;
   // split-K launch: conv_split_reduce_kernel wrote the planes and one word of max|y| per workgroup. Otherwise (the tiles
   // filled the chip): the separate pass, its bound from the epilogue's per-channel maxima (+ the residual's bound)

@@ -150,6 +150,9 @@ int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, 
 int launch_split_planes_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st);
+// conv_small.hip: inference units with few output pixels in one launch
+bool conv_small_supported(const GatherConvArgs& a);
+int launch_conv_small(GatherConvArgs& a, hipStream_t st, int* nwg);
 bool gather_planes_supported(const GatherConvArgs& a);
 // conv_win.hip (3x3 stride-1 forward / data gradient with the input window kept in LDS); returns 1 = not covered
 int conv_split_parts(const GatherConvArgs& a, long long nb, int bm, int min_cb, int idle_div);
