@@ -681,16 +681,18 @@ def _planes_values(pl, rows, c):
     return (f[0] + f[1])[:rows] / float(hdr[1]), float(hdr[0]), float(hdr[1]), f[:, rows:]
 
 
-def _conv_small_takes(rows, cout, k):
+def _conv_small_takes(rows, cout, k, cin):
     """the launch policy of csrc/conv_small.hip (small_tile), environment overrides included"""
     on = int(os.environ.get("YOLO_CONV_SMALL", "1"))
-    if on == 0 or cout % 32 != 0 or not (k == 1 or (k == 3 and on == 3)):
+    if on == 0 or cout % 32 != 0 or k not in (1, 3):
         return False
     g11 = ((rows + 31) // 32) * (cout // 32)
     g22 = ((rows + 63) // 64) * (cout // 64) if cout % 64 == 0 else 1 << 40
     grid = int(os.environ.get("YOLO_CONV_SMALL_GRID", "0"))
     if os.environ.get("YOLO_CONV_SMALL_TILE"):
         return g11 <= min(grid or 2048, 4096)
+    if k == 3 and on != 3:
+        return 128 <= g22 <= (grid or 256) and 9 * (cin // 16) <= 72
     return g11 <= (grid or 256) or g22 <= (grid or 256)
 
 
@@ -750,7 +752,7 @@ def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
                                    in_words.view(torch.int32), res_bound, pl, out_words, out_bound)
     torch.cuda.synchronize()
     assert expect_onepass is None or (nw > 0) == expect_onepass
-    small = _conv_small_takes(rows, cout, k)   # (csrc/conv_small.hip: small_tile)
+    small = _conv_small_takes(rows, cout, k, cin)   # (csrc/conv_small.hip: small_tile)
     assert not small or nw > 0
     if k == 1 and cout % 32 == 0 and rows <= 2704 and not os.environ.get("YOLO_CONV_SMALL"):
         assert small   # the 1x1 cases of this list are what the kernel was written for

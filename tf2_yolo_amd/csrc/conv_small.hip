@@ -296,17 +296,17 @@ static int env_int(const char* name, int dflt) {
 //   3x3  26x26 256->512:  (1,1) 352: 26.7 | (2,1) 176: 22.8 | (2,2) 88: 26.6         before 21.2
 //   3x3  52x52 128->256:  (1,1) 680: 30.4 | (2,1) 344: 30.6 | (2,2) 172: 19.9        before 21-23
 // One workgroup per CU at a time (8 waves of 160-246 registers) takes in ~50-65 GB/s whatever the tile: launches of more
-// than 256 workgroups pay a second round, launches of few large tiles leave CUs without a stream. So: 1x1 units only (a 3x3
-// unit asks for 9x the bytes per output and is no faster than the split-K pair), the 32 x 32 tile while it gives at most
-// 256 workgroups, the 64 x 64 tile while THAT gives at most 256, else the kernels of the training step.
-// YOLO_CONV_SMALL: 0 off, 1 (default) 1x1 units, 3 also 3x3 units; YOLO_CONV_SMALL_TILE = 11 / 21 / 22 forces a tile and
+// than 256 workgroups pay a second round, launches of few large tiles leave CUs without a stream. So: 1x1 units take the
+// 32 x 32 tile while it gives at most 256 workgroups, the 64 x 64 tile while THAT gives at most 256, else the kernels of the
+// training step; a 3x3 unit asks for 9x the bytes per output and is no faster than the split-K pair except at 52x52.
+// YOLO_CONV_SMALL: 0 off, 1 (default) the policy below, 3 every 3x3 unit the grid limit allows too; YOLO_CONV_SMALL_TILE = 11 / 21 / 22 forces a tile and
 // YOLO_CONV_SMALL_GRID the largest launch (experiments).
 static int small_tile(const GatherConvArgs& a) {
   static const int on = env_int("YOLO_CONV_SMALL", 1);
   static const int tile_env = env_int("YOLO_CONV_SMALL_TILE", 0);
   static const int grid_env = env_int("YOLO_CONV_SMALL_GRID", 0);
   if (!on) return 0;
-  if (a.ntaps != 1 && !(a.ntaps == 9 && on == 3)) return 0;
+  if (a.ntaps != 1 && a.ntaps != 9) return 0;
   if ((a.Cs % 16) != 0 || (a.Cout % 32) != 0 || a.ldw != a.ntaps * a.Cs) return 0;
   if (a.stats != nullptr || a.accumulate || a.bwd_y != nullptr || a.ncls > 1) return 0;
   if (a.out_planes == nullptr || a.epi_scale == nullptr || a.pl_pred == nullptr || a.pl_out_words == nullptr) return 0;
@@ -321,6 +321,11 @@ static int small_tile(const GatherConvArgs& a) {
     return (tile_env == 22 && (a.Cout % 64) != 0) ? 21 : tile_env;
   }
   const long long cap = grid_env > 0 ? grid_env : 256;
+  if (a.ntaps == 9 && on != 3) {
+    // 3x3 units: only where the 64 x 64 tile fills at least half the chip in one round with short streams (at most 72
+    // steps = 128 input channels: the 52x52 layers of YOLOv3-416, 19.9 against 23.9 us); elsewhere the split-K pair wins
+    return (g22 <= cap && g22 >= 128 && a.ntaps * (a.Cs >> 4) <= 72) ? 22 : 0;
+  }
   if (g11 <= cap) return 11;
   if (g22 <= cap) return 22;
   return 0;

@@ -811,7 +811,9 @@ static int launch_win(GatherConvArgs& a, hipStream_t st) {
     hipLaunchKernelGGL((conv_win_kernel<WGM, NCH, false, false, false, 2, 0, true>), dim3(grid), dim3(128 * WGM), lds, st, a);
     return check_launch("conv_win_kernel(bn reduce)");
   }
-  a.split_parts = WGM == 2 ? conv_split_parts(a, nb, BM, 2, 2) : 1;
+  // (parts of at least 2 channel blocks = 18 stages; YOLO_WIN_SPLIT_MIN_CB = 1: twice the parts, half the stages)
+  static const int split_min_cb = [] { const char* e = getenv("YOLO_WIN_SPLIT_MIN_CB"); return e ? atoi(e) : 2; }();
+  a.split_parts = WGM == 2 ? conv_split_parts(a, nb, BM, split_min_cb, 2) : 1;
   if (a.split_parts > 1) {
     a.tile_order = 0;
     a.sk_grid = (int)(nb * a.split_parts);
