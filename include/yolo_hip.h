@@ -238,6 +238,22 @@ int yolo_stem_fwd_infer_unit(const yolo_conv_desc* d, const float* x, const floa
  * receives the fp32 concatenation. The three *_host arguments are HOST arrays of nsrc entries (device pointers inside). */
 int yolo_split_planes_concat(const float* const* srcs_host, const int* channels_host, const float* const* bounds_host,
                              int nsrc, long long rows, void* planes, float* dst32, float* out_bound, void* stream);
+/* The same with two things a bs-1 graph would otherwise pay a launch each for (round 6: no launch of a replayed graph costs
+ * less than ~4.5 us): bound_words_host[i] (HOST ints, NULL = all 1) = how many words bounds_host[i] points to, their maximum
+ * being the source's bound -- 1 = one float, more = the words a one-pass inference unit left (yolo_conv2d_fwd_infer_unit);
+ * upsample_host[i] != 0 (HOST ints, NULL = none) = source i is [N][H/2][W/2][channels] and is read through
+ * UpSampling2D(2) (nearest: pixel (y, x) of the result takes pixel (y/2, x/2); yolov3/models/darknet.py:87,92), the
+ * result's rows being N x H x W pixels. */
+int yolo_split_planes_concat_ex(const float* const* srcs_host, const int* channels_host, const float* const* bounds_host,
+                                const int* bound_words_host, const int* upsample_host, int H, int W, int nsrc,
+                                long long rows, void* planes, float* dst32, float* out_bound, void* stream);
+/* The detection head of YOLOv2 / v3 / v4 as one call: t = Conv2D(A (5 + C), 1) of x (bias, no BatchNormalization;
+ * yolov3/models/__init__.py:34-64, yolov4/models/__init__.py:35-65, yolov2/models/darknet.py:95-104) and y = the head's
+ * activation of t (yolo_head_act_fwd). Operands as planes (yolo_conv2d_fwd_planes). Launches with few output pixels (bs-1
+ * predict) and version v3 / v4 take ONE launch (csrc/conv_small.hip: the activation in the convolution's epilogue); anything
+ * else is yolo_conv2d_fwd_planes + yolo_head_act_fwd behind this entry. t and y are both written. */
+int yolo_conv2d_fwd_head_unit(const yolo_conv_desc* d, const void* x_planes, const void* w_planes, const float* bias,
+                              int A, int C, int version, const float* anchors, float* t, float* y, void* stream);
 /* yolo_conv2d_wgrad on pre-split operands (dw += ..., same contract; the bias gradient stays with
  * yolo_conv2d_wgrad_bias on the fp32 dy). Requires Cin % 16 == 0, Cout % 16 == 0, Cout >= 32, kh*kw*Cin >= 64.
  * Two kernels behind it, same results to fp32 summation order: 3x3 stride-1 'same' layers with Cout % 128 == 0 and

@@ -786,6 +786,38 @@ def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
     assert _relerr(z1.double(), z2.double()) < 2e-6
 
 
+@pytest.mark.parametrize("n,hw,cin,A,C,version", [(1, 13, 1024, 3, 80, 3), (1, 26, 512, 3, 80, 3), (1, 52, 256, 3, 80, 4),
+                                                  (2, 19, 128, 3, 20, 3), (1, 13, 1024, 5, 20, 2), (8, 52, 256, 3, 80, 3)])
+def test_head_unit_in_one_call(n, hw, cin, A, C, version):
+    """yolo_conv2d_fwd_head_unit (round 6): the head's 1x1 convolution (bias, Cout = A (5 + C): 255, 75, 125 -- not a
+    multiple of 16) and its activation; at few output pixels ONE launch (csrc/conv_small.hip, v3 / v4), otherwise
+    (v2's softmax, many pixels) convolution + yolo_head_act_fwd behind the same entry. Against those two calls: t to fp32
+    summation order, y to the activation's conditioning (yolov3/models/__init__.py:34-64)."""
+    from tf2_yolo_amd import ops
+    ops.ensure_conv_workspace()
+    g = torch.Generator().manual_seed(31)
+    cout = A * (5 + C)
+    x = torch.randn(n, hw, hw, cin, generator=g).float().cuda()
+    wk = (torch.randn(cout, cin, generator=g) / cin ** 0.5).float().cuda()
+    b = (torch.randn(cout, generator=g) * 0.5).float().cuda()
+    anchors = (torch.rand(A, 2, generator=g) + 0.1).float().cuda()
+    d = ops.conv_desc((n, hw, hw, cin), cout, 1, 1, 1, "same")
+    xp = ops.split_planes(x, n * hw * hw, cin)
+    wp = ops.split_planes(wk, cout, cin)
+    t_ref = ops.conv2d_fwd_planes(d, xp, wp, b)
+    y_ref = ops.head_act_fwd(t_ref, A, C, version, anchors)
+    t = torch.full_like(t_ref, float("nan"))
+    y = torch.full_like(t_ref, float("nan"))
+    ops.conv2d_fwd_head_unit(d, xp, wp, b, A, C, version, anchors, t, y)
+    torch.cuda.synchronize()
+    assert _relerr(t.double(), t_ref.double()) < 2e-6
+    ref64 = x.double().reshape(-1, cin) @ wk.double().t() + b.double()
+    assert _relerr(t.double().reshape(-1, cout), ref64) < 2e-6
+    # y: exactly the head activation of the t this call wrote
+    assert torch.equal(y, ops.head_act_fwd(t, A, C, version, anchors))
+    assert torch.allclose(y, y_ref, rtol=2e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("shape,act,with_y", [((2, 37, 45), "leaky", True), ((1, 64, 64), "mish", False),
                                               ((1, 416, 416), "leaky", False), ((3, 21, 130), "leaky", True)])
 def test_stem_inference_unit(shape, act, with_y):

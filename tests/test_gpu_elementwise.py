@@ -404,6 +404,55 @@ def test_split_planes_concat(chans):
     assert torch.equal(pl, pl2)
 
 
+@pytest.mark.parametrize("n,h,w,chans,up", [(1, 26, 26, (256, 512), (True, False)), (2, 52, 52, (128, 256), (True, False)),
+                                            (3, 6, 10, (24, 40, 16), (False, True, True)), (1, 14, 14, (64,), (True,))])
+def test_split_planes_concat_reads_through_upsampling(n, h, w, chans, up):
+    """yolo_split_planes_concat_ex (round 6): sources behind UpSampling2D(2) are read at half size, bounds come as WORDS
+    (their maximum is the bound). Planes, fp32 output and bound bit-identical to yolo_split_planes_concat on the explicitly
+    upsampled tensors (yolo_upsample2x_fwd) with the folded bounds (yolov3/models/darknet.py:87-93)."""
+    from tf2_yolo_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(14)
+    rows = n * h * w
+    half = [torch.randn(n, h // 2, w // 2, c, device="cuda", generator=g) * (1.0 + i) if f else None
+            for i, (c, f) in enumerate(zip(chans, up))]
+    def _up(t, c):
+        y = torch.empty(n, h, w, c, device="cuda")
+        ops.upsample2x_fwd(t, y, c, 0)
+        return y.reshape(rows, c)
+    full = [_up(t, c) if f else torch.randn(rows, c, device="cuda", generator=g) * 2.5 for t, c, f in zip(half, chans, up)]
+    srcs = [t if f else x for t, x, f in zip(half, full, up)]
+    # bounds: words (many, the maximum somewhere in the middle; the others smaller or zero), or one float
+    words, floats = [], []
+    for i, x in enumerate(full):
+        m = x.abs().max() * 1.5
+        if i % 2 == 0:
+            wds = torch.zeros(300 + 77 * i, device="cuda")
+            wds[torch.randint(0, wds.numel(), (50,), device="cuda", generator=g)] = m * 0.25
+            wds[123] = m
+            words.append(wds.view(torch.int32))
+        else:
+            words.append(m.reshape(1))
+        floats.append(m.reshape(1).clone())
+    C = sum(chans)
+    pl = torch.zeros(ops.planes_bytes(rows, C), device="cuda", dtype=torch.uint8)
+    d32 = torch.empty(rows, C, device="cuda")
+    ob = torch.zeros(1, device="cuda")
+    ops.split_planes_concat_ex(srcs, list(chans), words, rows, pl, upsample=list(up), hw=(h, w), dst32=d32, out_bound=ob)
+    pl_ref = torch.zeros_like(pl)
+    d32_ref = torch.empty_like(d32)
+    ob_ref = torch.zeros(1, device="cuda")
+    ops.split_planes_concat(full, list(chans), floats, rows, pl_ref, dst32=d32_ref, out_bound=ob_ref)
+    torch.cuda.synchronize()
+    assert torch.equal(d32, d32_ref) and torch.equal(d32, torch.cat(full, dim=1))
+    assert float(ob) == float(ob_ref)
+    body = ops.planes_bytes(rows, C) - 256
+    assert torch.equal(pl[:body + 12], pl_ref[:body + 12])
+    # planes only
+    pl2 = torch.zeros_like(pl)
+    ops.split_planes_concat_ex(srcs, list(chans), words, rows, pl2, upsample=list(up), hw=(h, w))
+    assert torch.equal(pl2[:body + 12], pl[:body + 12])
+
+
 @pytest.mark.parametrize("P,C,act", [(32 * 52 * 52, 256, 1), (32 * 13 * 13, 1024, 1), (4 * 19 * 19, 512, 2), (2 * 7 * 5, 32, 1),
                                      (16 * 26 * 26 + 3, 48, 1), (32 * 104 * 104, 64, 1)])
 def test_bn_backward_reduction_finished_by_its_own_launch(P, C, act):

@@ -73,6 +73,9 @@ SIGNATURES = {
     "yolo_stem_filter_prep": (c_int, [_P, _P, _P, _P]),
     "yolo_stem_fwd_infer_unit": (c_int, [POINTER(ConvDesc), _P, _P, c_int, _P, _P, _P, _P, c_int, _P, _P, _P, POINTER(c_int), _P]),
     "yolo_split_planes_concat": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), c_int, _LL, _P, _P, _P, _P]),
+    "yolo_split_planes_concat_ex": (c_int, [POINTER(c_void_p), POINTER(c_int), POINTER(c_void_p), POINTER(c_int), POINTER(c_int),
+                                            c_int, c_int, c_int, _LL, _P, _P, _P, _P]),
+    "yolo_conv2d_fwd_head_unit": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P]),
     "yolo_conv2d_fwd_absmax": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P]),
     "yolo_conv2d_dgrad_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, c_int, _P]),
     "yolo_conv2d_wgrad_planes": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P]),

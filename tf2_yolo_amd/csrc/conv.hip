@@ -1014,6 +1014,57 @@ extern "C" int yolo_split_planes_concat(const float* const* srcs_host, const int
                                     as_stream(stream));
 }
 
+extern "C" int yolo_split_planes_concat_ex(const float* const* srcs_host, const int* channels_host,
+                                           const float* const* bounds_host, const int* bound_words_host,
+                                           const int* upsample_host, int H, int W, int nsrc, long long rows, void* planes,
+                                           float* dst32, float* out_bound, void* stream) {
+  YOLO_REQUIRE(srcs_host && channels_host && bounds_host && planes && nsrc >= 1 && nsrc <= 4 && rows > 0,
+               "split_planes_concat: 1..4 sources, non-null tables");
+  int C = 0;
+  bool any_up = false;
+  for (int i = 0; i < nsrc; ++i) {
+    YOLO_REQUIRE(srcs_host[i] && bounds_host[i] && channels_host[i] > 0 && (channels_host[i] % 8) == 0,
+                 "split_planes_concat: every source needs a pointer, a bound and a channel count that is a multiple of 8");
+    YOLO_REQUIRE(bound_words_host == nullptr || (bound_words_host[i] >= 1 && bound_words_host[i] <= YOLO_INFER_BOUND_WORDS),
+                 "split_planes_concat: a bound is 1..%d words", YOLO_INFER_BOUND_WORDS);
+    any_up = any_up || (upsample_host != nullptr && upsample_host[i] != 0);
+    C += channels_host[i];
+  }
+  YOLO_REQUIRE((C % 16) == 0, "split_planes_concat: the concatenated channel count must be a multiple of 16");
+  YOLO_REQUIRE(!any_up || (H > 0 && W > 0 && (H % 2) == 0 && (W % 2) == 0 && rows % ((long long)H * W) == 0),
+               "split_planes_concat: an upsampled source needs even H, W with rows = N * H * W (H=%d W=%d rows=%lld)", H, W, rows);
+  return launch_split_planes_concat(srcs_host, channels_host, bounds_host, nsrc, rows, planes, dst32, out_bound,
+                                    as_stream(stream), bound_words_host, upsample_host, H, W);
+}
+
+extern "C" int yolo_conv2d_fwd_head_unit(const yolo_conv_desc* d, const void* x_planes, const void* w_planes,
+                                         const float* bias, int A, int C, int version, const float* anchors, float* t,
+                                         float* y, void* stream) {
+  if (int rc = validate_desc(d)) return rc;
+  YOLO_REQUIRE(x_planes && w_planes && t && y && A > 0 && C > 0, "conv_fwd_head_unit: bad args");
+  YOLO_REQUIRE(d->Cout == A * (5 + C), "conv_fwd_head_unit: Cout = %d is not A (5 + C) = %d", d->Cout, A * (5 + C));
+  GatherConvArgs a{};
+  a.src = reinterpret_cast<const float*>(x_planes);
+  a.wgt = reinterpret_cast<const float*>(w_planes);
+  a.bias = bias;
+  a.dst = t;
+  fill_fwd_args(d, a);
+  YOLO_REQUIRE(gather_planes_supported(a), "conv_fwd_head_unit: needs Cin %% 16 == 0 and Cout >= 32");
+  if ((version == YOLO_HEAD_V3 || version == YOLO_HEAD_V4) && anchors != nullptr) {
+    a.head_y = y;
+    a.head_anchors = anchors;
+    a.head_A = A;
+    a.head_C = C;
+    if (conv_small_head_supported(a)) {
+      int nwg = 0;
+      return launch_conv_small(a, as_stream(stream), &nwg);
+    }
+    a.head_y = nullptr;
+  }
+  if (int rc = launch_gather_planes(a, as_stream(stream))) return rc;
+  return yolo_head_act_fwd(t, (long long)d->N * d->Ho * d->Wo, A, C, version, anchors, y, stream);
+}
+
 extern "C" size_t yolo_planes_bytes(long long rows, int C) {
   if (rows <= 0 || C <= 0 || (C % 16) != 0) return 0;
   return (size_t)planes_bytes(rows, C);

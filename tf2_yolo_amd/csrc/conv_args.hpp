@@ -63,6 +63,12 @@ struct GatherConvArgs {
   const unsigned* pl_res_bound;
   int pl_in_n, pl_res_n;
   unsigned* pl_out_words;
+  // conv_small.hip, detection-head form (yolo_conv2d_fwd_head_unit): the 1x1 convolution of a YOLOv2/v3/v4 head (bias, no
+  // BatchNorm, Cout = A (5 + C), any Cout) and the head's activation in one launch: head_y = sigmoid(t) except channels 2, 3
+  // of every anchor's group: exp(t) * anchor (yolov3/models/__init__.py:58-67); dst (the raw t) is written only if non-null
+  float* head_y;
+  const float* head_anchors;
+  int head_A, head_C;
   // conv_win.hip, stream-K form: workgroups of the launch (0 = one tile per workgroup), part slabs, tile tickets
   int sk_grid;
   int tile_order;   // conv_win.hip: 0 = column tile fastest inside an XCD's run, 1 = row tile fastest
@@ -145,13 +151,15 @@ int launch_split_planes(const float* x, long long rows, int C, void* planes, hip
 int launch_split_planes_absmax(const float* x, long long rows, int C, const unsigned* absmax, const float* extra_bound, int extra_n,
                                void* planes, float* out_bound, hipStream_t st);
 int launch_split_planes_concat(const float* const* xs, const int* Cs, const float* const* bounds, int nsrc, long long rows,
-                               void* planes, float* dst32, float* out_bound, hipStream_t st);
+                               void* planes, float* dst32, float* out_bound, hipStream_t st,
+                               const int* bound_words = nullptr, const int* upsample = nullptr, int H = 0, int W = 0);
 int launch_split_planes_padded(const float* x, long long rows, int Csrc, int C, void* planes, hipStream_t st);
 int launch_split_planes_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_filter_transpose_batch(const void* jobs, int njobs, long long total_blocks, hipStream_t st);
 int launch_gather_planes(GatherConvArgs& a, hipStream_t st);
 // conv_small.hip: inference units with few output pixels in one launch
 bool conv_small_supported(const GatherConvArgs& a);
+bool conv_small_head_supported(const GatherConvArgs& a);
 int launch_conv_small(GatherConvArgs& a, hipStream_t st, int* nwg);
 bool gather_planes_supported(const GatherConvArgs& a);
 // conv_win.hip (3x3 stride-1 forward / data gradient with the input window kept in LDS); returns 1 = not covered

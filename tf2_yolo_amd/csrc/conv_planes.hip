@@ -143,9 +143,12 @@ __global__ __launch_bounds__(256) void split_planes_absmax_kernel(const float* _
 struct ConcatSrcs {
   const float* x[4];
   const float* bound[4];
-  int g_end[4];   // exclusive prefix ends in 8-channel groups
+  int bound_n[4];   // words at bound[i] whose maximum is the source's bound (1 = one float; more = what a one-pass inference unit left)
+  int up[4];        // 1 = source i has HALF the height and width of the result: UpSampling2D(2), nearest, read on the fly
+  int g_end[4];     // exclusive prefix ends in 8-channel groups
   int C[4];
   int n;
+  int H, W;         // the result's rows are N x H x W pixels (used when any up[i])
 };
 __global__ __launch_bounds__(256) void split_planes_concat_kernel(const ConcatSrcs cs, long long rows, int C,
                                                                  unsigned char* __restrict__ out, long long rows_padded,
@@ -153,7 +156,21 @@ __global__ __launch_bounds__(256) void split_planes_concat_kernel(const ConcatSr
   float b = 0.f;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
-    if (i < cs.n) b = fmaxf(b, cs.bound[i][0]);
+    if (i < cs.n) {
+      if (cs.bound_n[i] <= 1) {
+        b = fmaxf(b, cs.bound[i][0]);
+      } else {
+        // (the words of a one-pass unit: folded here instead of by a launch of their own -- 4.5 us in a bs-1 graph)
+        __shared__ float sb[4][4];
+        float m = 0.f;
+        for (int w = threadIdx.x; w < cs.bound_n[i]; w += 256) m = fmaxf(m, cs.bound[i][w]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) sb[i][threadIdx.x >> 6] = m;
+        __syncthreads();
+        b = fmaxf(b, fmaxf(fmaxf(sb[i][0], sb[i][1]), fmaxf(sb[i][2], sb[i][3])));
+      }
+    }
   const float bound = b * 1.001f + 1e-30f;
   unsigned* header = reinterpret_cast<unsigned*>(out + planes_body_bytes(rows, C));
   const float sc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bound));
@@ -185,7 +202,15 @@ __global__ __launch_bounds__(256) void split_planes_concat_kernel(const ConcatSr
     const long long row = row0 + 16 * u;
     v[u][0] = v[u][1] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (row < rows) {
-      const float* p = src + row * Cs + (g - g0) * 8;
+      long long srow = row;
+      if (cs.up[si]) {   // pixel (y, x) of the result reads pixel (y / 2, x / 2) of the half-size source
+        const int HW = cs.H * cs.W;
+        const long long n = row / HW;
+        const int rem = (int)(row - n * HW);
+        const int y = rem / cs.W, x = rem - y * cs.W;
+        srow = (n * (cs.H >> 1) + (y >> 1)) * (cs.W >> 1) + (x >> 1);
+      }
+      const float* p = src + srow * Cs + (g - g0) * 8;
       v[u][0] = *reinterpret_cast<const f32x4*>(p);
       v[u][1] = *reinterpret_cast<const f32x4*>(p + 4);
     }
@@ -673,12 +698,17 @@ int launch_gather_planes(GatherConvArgs& a, hipStream_t st) {
 }
 
 int launch_split_planes_concat(const float* const* xs, const int* Cs, const float* const* bounds, int nsrc, long long rows,
-                               void* planes, float* dst32, float* out_bound, hipStream_t st) {
+                               void* planes, float* dst32, float* out_bound, hipStream_t st, const int* bound_words,
+                               const int* upsample, int H, int W) {
   ConcatSrcs cs{};
   int C = 0;
+  cs.H = H;
+  cs.W = W;
   for (int i = 0; i < nsrc; ++i) {
     cs.x[i] = xs[i];
     cs.bound[i] = bounds[i];
+    cs.bound_n[i] = bound_words != nullptr ? bound_words[i] : 1;
+    cs.up[i] = upsample != nullptr ? upsample[i] : 0;
     cs.C[i] = Cs[i];
     C += Cs[i];
     cs.g_end[i] = C >> 3;

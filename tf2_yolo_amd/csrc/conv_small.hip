@@ -37,7 +37,9 @@ struct SmallBuf {
 // NT taps (1 or 9); tile = 32 TM pixels x 32 TN filters (TM x TN accumulators per wave: an operand fragment a wave has
 // loaded is used TN / TM times -- (1,1) asks L2 for 4 KB per 32 x 32 x 16 block product, (2,2) for 2 KB); CH steps per
 // register buffer (two buffers)
-template <int NT, int TM, int TN, int CH>
+// HEAD: the detection-head form (GatherConvArgs::head_y): any Cout (columns past it are masked), bias only, the head's
+// activation instead of BatchNorm / activation / residual / planes
+template <int NT, int TM, int TN, int CH, bool HEAD = false>
 __global__ __launch_bounds__(64 * SM_WAVES) void conv_small_kernel(const GatherConvArgs a) {
   constexpr int BMT = 32 * TM, BNT = 32 * TN;
   __shared__ float red[SM_WAVES][16][64];
@@ -115,14 +117,20 @@ __global__ __launch_bounds__(64 * SM_WAVES) void conv_small_kernel(const GatherC
       for (int e = 0; e < 4; ++e) rv[i][j][e] = 0.f;
   }
   if (fin) {
-    for (int w = tid; w < a.pl_in_n; w += 256) ib = fmaxf(ib, __builtin_bit_cast(float, a.pl_in_bound[w]));
-    if (a.pl_res_bound != nullptr)
-      for (int w = tid; w < a.pl_res_n; w += 256) rb = fmaxf(rb, __builtin_bit_cast(float, a.pl_res_bound[w]));
+    if constexpr (!HEAD) {
+      for (int w = tid; w < a.pl_in_n; w += 256) ib = fmaxf(ib, __builtin_bit_cast(float, a.pl_in_bound[w]));
+      if (a.pl_res_bound != nullptr)
+        for (int w = tid; w < a.pl_res_n; w += 256) rb = fmaxf(rb, __builtin_bit_cast(float, a.pl_res_bound[w]));
+    }
     unscale = reinterpret_cast<const float*>(srcp + a.src_bytes - PL_HEADER)[2] *
               reinterpret_cast<const float*>(wgtp + a.wgt_bytes - PL_HEADER)[2];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = tile_n * BNT + 32 * j + r;
+      if constexpr (HEAD) {
+        bv[j] = (a.bias != nullptr && col < a.Cout) ? a.bias[col] : 0.f;
+        continue;
+      }
       bv[j] = a.bias != nullptr ? a.bias[col] : 0.f;
       esc[j] = a.epi_scale[col];
       esh[j] = a.epi_shift[col];
@@ -203,6 +211,38 @@ __global__ __launch_bounds__(64 * SM_WAVES) void conv_small_kernel(const GatherC
     mma(b1);
   }
 
+  if constexpr (HEAD) {
+    // block by block: partials added in wave order by waves 0-3, bias, the head's activation, masked stores
+    const int D = 5 + a.head_C;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) red[wave][k][lane] = acc[i][j][k];
+        __syncthreads();
+        if (fin) {
+          const int col = tile_n * BNT + 32 * j + r;
+          const long long mrow = (long long)tile_m * BMT + 32 * i + 8 * wave + 4 * hf;
+          const int kk = col % D, an = col / D;
+          const float anc = (col < a.Cout && (kk == 2 || kk == 3)) ? a.head_anchors[an * 2 + (kk - 2)] : 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float sum = red[0][4 * wave + e][lane];
+#pragma unroll
+            for (int w = 1; w < SM_WAVES; ++w) sum += red[w][4 * wave + e][lane];
+            if (mrow + e < a.M && col < a.Cout) {
+              const float v = fmaf(sum, unscale, bv[j]);
+              if (a.dst != nullptr) a.dst[(mrow + e) * a.Cd + col] = v;
+              // (the expressions of head_fwd_pointwise_kernel, elementwise.hip)
+              a.head_y[(mrow + e) * a.Cd + col] = (kk == 2 || kk == 3) ? expf(v) * anc : 1.f / (1.f + expf(-v));
+            }
+          }
+        }
+        __syncthreads();
+      }
+    return;
+  }
   // scale of the outgoing planes from the a-priori bound (see conv_split_reduce_kernel); the words of the bound were
   // requested before the main loop and are first looked at here
   if (fin) {
@@ -333,13 +373,29 @@ static int small_tile(const GatherConvArgs& a) {
 
 bool conv_small_supported(const GatherConvArgs& a) { return small_tile(a) != 0; }
 
-template <int NT, int TM, int TN, int CH>
+template <int NT, int TM, int TN, int CH, bool HEAD = false>
 static int launch_small(GatherConvArgs& a, hipStream_t st, int* nwg) {
-  a.nblocks = (int)(((a.M + 32 * TM - 1) / (32 * TM)) * (a.Cout / (32 * TN)));
+  a.nblocks = (int)(((a.M + 32 * TM - 1) / (32 * TM)) * ((a.Cout + 32 * TN - 1) / (32 * TN)));
   *nwg = a.nblocks;
-  hipLaunchKernelGGL((conv_small_kernel<NT, TM, TN, CH>), dim3((unsigned)a.nblocks), dim3(64 * SM_WAVES), 0, st, a);
+  hipLaunchKernelGGL((conv_small_kernel<NT, TM, TN, CH, HEAD>), dim3((unsigned)a.nblocks), dim3(64 * SM_WAVES), 0, st, a);
   return check_launch("conv_small_kernel");
 }
+
+// the detection-head form: 1x1, stride 1, dense, bias, any Cout; 32 x 32 tiles while they give at most 256 workgroups, else
+// 64 x 64 while those do
+static int small_head_tile(const GatherConvArgs& a) {
+  static const int on = env_int("YOLO_CONV_SMALL", 1);
+  if (!on || a.head_y == nullptr || a.head_anchors == nullptr || a.head_A <= 0 || a.head_C <= 0) return 0;
+  if (a.ntaps != 1 || (a.Cs % 16) != 0 || a.ldw != a.Cs || a.Cout != a.head_A * (5 + a.head_C)) return 0;
+  if (a.sy != 1 || a.sx != 1 || a.Hg != a.Hs || a.Wg != a.Ws || a.taps[0].oy != 0 || a.taps[0].ox != 0) return 0;
+  if (a.stats != nullptr || a.accumulate || a.bwd_y != nullptr || a.ncls > 1 || a.epi_scale != nullptr || a.epi_res != nullptr) return 0;
+  if (a.osy != 1 || a.osx != 1 || a.ooy != 0 || a.oox != 0 || a.Hd != a.Hg || a.Wd != a.Wg || a.Cd != a.Cout) return 0;
+  const long long g11 = ((a.M + 31) / 32) * ((a.Cout + 31) / 32), g22 = ((a.M + 63) / 64) * ((a.Cout + 63) / 64);
+  if (g11 <= 256) return 11;
+  if (g22 <= 256) return 22;
+  return 0;
+}
+bool conv_small_head_supported(const GatherConvArgs& a) { return small_head_tile(a) != 0; }
 
 // *nwg = workgroups of the launch = words of max|dst| written to a.pl_out_words
 int launch_conv_small(GatherConvArgs& a, hipStream_t st, int* nwg) {
@@ -354,6 +410,13 @@ int launch_conv_small(GatherConvArgs& a, hipStream_t st, int* nwg) {
   a.zero_blk_src = (int)((rowsA + 15) / 16);
   a.zero_blk_wgt = (a.Cout + 15) / 16;
   a.split_parts = 1;
+  if (a.head_y != nullptr) {
+    const int ht = small_head_tile(a);
+    if (ht == 11) return launch_small<1, 1, 1, 4, true>(a, st, nwg);
+    if (ht == 22) return launch_small<1, 2, 2, 2, true>(a, st, nwg);
+    set_error("conv_small(head): launch not supported");
+    return YOLO_ERR_INVALID_ARG;
+  }
   const int tile = small_tile(a);
   if (tile == 0) {
     set_error("conv_small: launch not supported");

@@ -482,6 +482,22 @@ class Network:
         for i, u in enumerate(self.units):
             u.pred_off = 2 * i
         self._infer_onepass = os.environ.get("YOLO_INFER_ONEPASS", "1") != "0"
+        # round 6, bs-1 predict (no launch of the replayed graph costs less than ~4.5 us: DESIGN.md section 3.10):
+        # (a) an UpSampling2D(2) whose only reader is a Concatenate is read THROUGH by the concat's planes pass (inference),
+        # which also takes the sources' bounds as the words the one-pass units left instead of a fold launch per source
+        # (yolo_split_planes_concat_ex); (b) a conv + BN unit nobody reads as planes (the FPN's lateral 1x1 in front of the
+        # upsampling) still runs as a one-pass unit into planes of its own that nobody reads -- one launch instead of four;
+        # (c) the heads: convolution + activation in one call (yolo_conv2d_fwd_head_unit). YOLO_INFER_SMALL_FUSE=0: off
+        self._infer_small_fuse = os.environ.get("YOLO_INFER_SMALL_FUSE", "1") != "0"
+        self._up_producer = {}
+        for u in self.units:
+            u.concat_reads_through = False
+            if u.kind == "upsample" and self._n_consumers.get(u.out.tid, 0) == 1 and u.out.tid not in out_tids:
+                cs = consumers.get(u.out.tid, [])
+                if (len(cs) == 1 and cs[0].kind == "concat" and u.out.h == 2 * u.src.h and u.out.w == 2 * u.src.w
+                        and u.out.c == u.src.c):
+                    self._up_producer[u.out.tid] = u
+        self._xplanes_infer = {}
 
     # ---- construction -------------------------------------------------------------------
     def _declare_params(self):
@@ -644,6 +660,7 @@ class Network:
         # planes of the activations that feed planes-capable convs (kept from forward for the filter
         # gradient), one scratch for the planes of the current layer's dy in backward
         self._xplanes = {}
+        self._xplanes_infer = {}
         dyp = 0
         for u in self.units:
             if u.kind not in ("conv", "head"):
@@ -933,23 +950,49 @@ class Network:
                         raise YoloHipError("residual without BN is not used by any reference graph")
             elif u.kind == "head":
                 xin = self.act[u.src.tid]
+                if not training and self._infer_small_fuse and self._fuse_infer and u.planes_fwd:
+                    ops.conv2d_fwd_head_unit(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes],
+                                             P.view(u.p_bias.name), u.A, u.C, u.version, self._anchors_dev.get(u.name),
+                                             u.t, u.yact)
+                    continue
                 self._conv_fwd(u, xin, P.view(u.p_kernel.name), P.view(u.p_bias.name), u.t)
                 ops.head_act_fwd(u.t, u.A, u.C, u.version, self._anchors_dev.get(u.name), out=u.yact)
             elif u.kind == "upsample":
+                if (not training and self._infer_small_fuse and self._concat_planes
+                        and u.out.tid in self._up_producer):
+                    u.concat_reads_through = True   # (the Concatenate behind it reads the half-size tensor itself)
+                    continue
                 ops.upsample2x_fwd(self.act[u.src.tid], u.buf, u.out.c, 0)
             elif u.kind == "concat":
                 pl = self._xplanes.get(u.out.tid) if self._concat_planes else None
                 slots = [self._bound_alias.get(s.tid, s.tid) for s in u.srcs]
+                ups = [self._up_producer.get(s.tid) for s in u.srcs]
+                ups = [p if (p is not None and p.concat_reads_through) else None for p in ups]
                 if (pl is not None and len(u.srcs) <= 4 and all(sl in self._tbound_set for sl in slots)
                         and all(s.c % 8 == 0 for s in u.srcs)):
                     tb = self._tbound
-                    ops.split_planes_concat([self.act[s.tid] for s in u.srcs], [s.c for s in u.srcs],
-                                            [self._tb_float(sl) for sl in slots], self.batch * u.out.h * u.out.w, pl,
-                                            dst32=u.buf if u.f32_needed else None,
-                                            out_bound=tb[u.out.tid:u.out.tid + 1])
+                    if any(p is not None for p in ups):
+                        ops.split_planes_concat_ex([self.act[p.src.tid] if p is not None else self.act[s.tid]
+                                                    for s, p in zip(u.srcs, ups)], [s.c for s in u.srcs],
+                                                   [self._tb_words(sl) for sl in slots], self.batch * u.out.h * u.out.w, pl,
+                                                   upsample=[p is not None for p in ups], hw=(u.out.h, u.out.w),
+                                                   dst32=u.buf if u.f32_needed else None,
+                                                   out_bound=tb[u.out.tid:u.out.tid + 1])
+                        for p in ups:
+                            if p is not None:
+                                p.concat_reads_through = False
+                    else:
+                        ops.split_planes_concat([self.act[s.tid] for s in u.srcs], [s.c for s in u.srcs],
+                                                [self._tb_float(sl) for sl in slots], self.batch * u.out.h * u.out.w, pl,
+                                                dst32=u.buf if u.f32_needed else None,
+                                                out_bound=tb[u.out.tid:u.out.tid + 1])
                     self._xp_valid.add(u.out.tid)
                     self._tbound_set.add(u.out.tid)
                     continue
+                for p in ups:   # (this Concatenate cannot read through after all: make the upsampled tensors now)
+                    if p is not None:
+                        ops.upsample2x_fwd(self.act[p.src.tid], p.buf, p.out.c, 0)
+                        p.concat_reads_through = False
                 off = 0
                 for s in u.srcs:
                     ops.copy_channels_in(self.act[s.tid], s.c, u.buf, u.out.c, off)
@@ -1002,6 +1045,17 @@ class Network:
         if not u.planes_fwd or u.cout % 16 != 0:
             return False
         pl = self._xplanes.get(u.out.tid)
+        own_planes = pl is not None
+        if pl is None and self._infer_small_fuse and self._infer_onepass:
+            # nobody reads this unit's result as planes (the FPN's lateral 1x1 conv in front of UpSampling2D): at few
+            # output pixels the one-pass unit is still ONE launch where conv + reduce + bound + BatchNorm apply are four --
+            # it writes planes of its own that nobody reads
+            rows = self.batch * u.out.h * u.out.w
+            if rows <= 4096:
+                pl = self._xplanes_infer.get(u.out.tid)
+                if pl is None:
+                    pl = self._xplanes_infer[u.out.tid] = torch.zeros(ops.planes_bytes(rows, u.cout), device=self.device,
+                                                                     dtype=torch.uint8)
         if pl is None or (u.residual is not None and u.residual.tid not in self._tbound_set):
             return False
         if not self._infer_scale_valid:
@@ -1025,8 +1079,11 @@ class Network:
             if nw:
                 self._tword_n[u.out.tid] = nw
             self._tbound_set.add(u.out.tid)
-            self._xp_valid.add(u.out.tid)
+            if own_planes:
+                self._xp_valid.add(u.out.tid)
             return True
+        if not own_planes:
+            return False
         ops.conv2d_fwd_planes_epi(u.desc, self._xp(u.src), self._wplanes[u.wp_off:u.wp_off + u.wp_bytes], bias, epi, scale,
                                   shift, residual=res, out=u.a, absmax=amax)
         ops.split_planes_absmax(u.a, self.batch * u.out.h * u.out.w, u.cout, amax, pl,

@@ -569,6 +569,49 @@ def split_planes_concat(srcs, channels, bounds, rows, planes, dst32=None, out_bo
     return planes
 
 
+def split_planes_concat_ex(srcs, channels, bounds, rows, planes, upsample=None, hw=(0, 0), dst32=None, out_bound=None):
+    """split_planes_concat with (a) bounds given as WORDS -- bounds[i] is a device tensor of 1..4096 four-byte words whose
+    maximum is the source's bound (one float, or what a one-pass inference unit left) -- and (b) sources read through
+    UpSampling2D(2): upsample[i] true = srcs[i] is [N][H/2][W/2][channels[i]], hw = (H, W) of the result
+    (include/yolo_hip.h: yolo_split_planes_concat_ex)"""
+    n = len(srcs)
+    _chk_f32(*srcs)
+    C = sum(channels)
+    up = [bool(f) for f in (upsample or [False] * n)]
+    if planes.numel() < planes_bytes(rows, C):
+        raise YoloHipError("split_planes_concat_ex: planes buffer too small")
+    for t, c, f in zip(srcs, channels, up):
+        if t.numel() != (rows // 4 if f else rows) * c:
+            raise YoloHipError("split_planes_concat_ex: source size does not match rows x channels")
+    for b in bounds:
+        if b.dtype not in (torch.float32, torch.int32) or not 1 <= b.numel() <= INFER_BOUND_WORDS:
+            raise YoloHipError("split_planes_concat_ex: a bound is 1..4096 four-byte words")
+    xs = (c_void_p * n)(*[t.data_ptr() for t in srcs])
+    bs = (c_void_p * n)(*[b.data_ptr() for b in bounds])
+    cs = (ctypes.c_int * n)(*[int(c) for c in channels])
+    bn = (ctypes.c_int * n)(*[int(b.numel()) for b in bounds])
+    us = (ctypes.c_int * n)(*[int(f) for f in up])
+    if _tape.ACTIVE is not None:
+        _tape.ACTIVE.keep.extend(list(srcs) + list(bounds))
+    check(_lib.load().yolo_split_planes_concat_ex(xs, cs, bs, bn, us, int(hw[0]), int(hw[1]), n, int(rows), _p(planes),
+                                                  _p(dst32), _p(out_bound), _stream()), "yolo_split_planes_concat_ex")
+    return planes
+
+
+def conv2d_fwd_head_unit(d, xp, wp, bias, A, C, version, anchors_dev, t, y):
+    """detection head: t = 1x1 convolution (+ bias) on planes operands, y = the head's activation of t; one launch where the
+    launch has few output pixels (include/yolo_hip.h: yolo_conv2d_fwd_head_unit)"""
+    _chk_f32(t, y)
+    n = d.N * d.Ho * d.Wo * d.Cout
+    if t.numel() != n or y.numel() != n:
+        raise YoloHipError("conv2d_fwd_head_unit: output size does not match the descriptor")
+    if xp.numel() < planes_bytes(d.N * d.H * d.W, d.Cin) or wp.numel() < planes_bytes(d.Cout, d.kh * d.kw * d.Cin):
+        raise YoloHipError("conv2d_fwd_head_unit: planes buffers do not match the descriptor")
+    check(_lib.load().yolo_conv2d_fwd_head_unit(ctypes.byref(d), _p(xp), _p(wp), _p(bias), int(A), int(C), int(version),
+                                                _p(anchors_dev), _p(t), _p(y), _stream()), "yolo_conv2d_fwd_head_unit")
+    return y
+
+
 class BnReduce:
     """What yolo_conv2d_dgrad_planes_bnred needs to fold the BatchNormalization-backward reduction of the tensor it
     completes into its epilogue (include/yolo_hip.h): the pre-BN tensor y of the unit that PRODUCED the tensor, that unit's
