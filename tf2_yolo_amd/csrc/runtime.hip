@@ -81,7 +81,7 @@ extern "C" int yolo_set_debug_buffer(void* p, size_t bytes) {
 
 extern "C" const char* yolo_last_error(void) { return yolo::g_err; }
 
-extern "C" int yolo_abi_version(void) { return 5; }   // 5: round 6 added yolo_bn_act_bwd_reduce_fold_ld (the reduction finished by its own launch), option key 8 (timing experiments); 4: round 5 added yolo_conv2d_dgrad_planes_bnred, yolo_bn_act_bwd_sum_partials, yolo_bnred_slots_cap, option key 7, yolo_allreduce_bucket; 3: round 4 added yolo_bn_act_bwd_reduce_bound_ld / _apply_planes_ld (dout with a row pitch), option key 6; 2: round 3 added yolo_cal_iou, yolo_nms_select, yolo_adam_step_dev, yolo_bn_finalize_offset, the wgrad workspace, yolo_mfma_probe
+extern "C" int yolo_abi_version(void) { return 5; }   // 5: round 6 added yolo_bn_act_bwd_reduce_fold_ld (the reduction finished by its own launch), option key 8 (timing experiments), yolo_maxpool2x2_bwd, yolo_bn_act_maxpool2x2_fwd, yolo_split_planes_concat_ex, yolo_conv2d_fwd_head_unit; 4: round 5 added yolo_conv2d_dgrad_planes_bnred, yolo_bn_act_bwd_sum_partials, yolo_bnred_slots_cap, option key 7, yolo_allreduce_bucket; 3: round 4 added yolo_bn_act_bwd_reduce_bound_ld / _apply_planes_ld (dout with a row pitch), option key 6; 2: round 3 added yolo_cal_iou, yolo_nms_select, yolo_adam_step_dev, yolo_bn_finalize_offset, the wgrad workspace, yolo_mfma_probe
 
 // ---- gradient exchange: the thin RCCL wrapper of SURVEY.md section 8b ----
 // For a host that OWNS an RCCL communicator (a C++ trainer, a binding that creates its communicators itself): in-place
