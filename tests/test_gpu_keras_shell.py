@@ -395,6 +395,45 @@ def test_captured_step_is_bit_identical_to_eager_steps(mode, monkeypatch):
     assert res[True][0][0] != res[True][0][3]       # (the second batch really went through the graphs)
 
 
+def test_replayed_steps_do_not_depend_on_how_far_the_host_runs_ahead():
+    """A loop that does not synchronise per step (bench.py's timed region, Model.fit between loss read-outs) enqueues several
+    steps before the GPU has started the first: the optimizer's scalars (Adam's bias-corrected learning rate of step t)
+    are uploaded asynchronously, so every step in flight needs a pinned row of its own. Until round 6 there was ONE: step
+    t's upload read the scalars of step t + 1 .. t + 3 (scripts/step_repro.py, REPRO_SYNC=0). Here the GPU is held busy
+    while eight replayed steps are enqueued; weights, moving statistics and Adam moments must equal those of eight
+    synchronised steps bit for bit."""
+    import yolov3
+    from tf2_yolo_amd import labels
+    from tf2_yolo_amd.optimizers import Adam
+
+    def make():
+        y = yolov3.Yolo((96, 96, 3), list("abcdefgh"))
+        y.create_model(anchors=A9, pretrained_body=None, seed=11)
+        y.model.compile(optimizer=Adam(learning_rate=1e-3), loss=y.loss())
+        return y.model
+    x, ys = labels.synthetic_batch(np.random.default_rng(3), 4, (96, 96), 8)
+    x, ys = torch.from_numpy(x).cuda(), [torch.from_numpy(a).cuda() for a in ys]
+    busy = torch.randn(4096, 4096, device="cuda")
+    res = []
+    for ahead in (False, True):
+        m = make()
+        for _ in range(3):                      # two eager steps and the recording
+            m.train_step_device(x, ys)
+            torch.cuda.synchronize()
+        assert m._step_graphs is not None
+        if ahead:
+            for _ in range(60):                 # ~0.1 s of matrix products in front of the replays
+                busy = (busy @ busy) * 1e-3
+        for _ in range(8):
+            m.train_step_device(x, ys)
+            if not ahead:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        res.append((m.net.params.data.clone(), m.net.state.data.clone(), m.optimizer.m.clone(), m.optimizer.v.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_batch_too_large_for_32_bit_operand_offsets_is_refused_up_front():
     """every conv kernel addresses an operand through a buffer descriptor with 32-bit offsets: a batch whose largest
     activation would reach 4 GiB is refused by Network.allocate, with the largest batch that fits, before anything is

@@ -43,9 +43,18 @@ class Adam(Optimizer):
     # ---- the form a captured hipGraph replays (capture.py): the five scalars live in device memory ----
     capturable = True
 
+    _HYPER_SLOTS = 64
+
     def _hyper_buffers(self):
         if getattr(self, "_hyper_dev", None) is None:
-            self._hyper_host = torch.zeros(5, dtype=torch.float32).pin_memory()
+            # A RING of pinned rows, one per step in flight: the upload is asynchronous and reads its row when the stream
+            # gets to it, which can be several steps after the host wrote it (a loop that does not synchronise per step runs
+            # ahead of the GPU by as many launches as the queue holds). One row re-written every step -- the form until round
+            # 6 -- let step k's upload read the scalars of step k + 1 .. k + 3: a learning rate with the wrong bias
+            # correction, a different one from run to run (scripts/step_repro.py with REPRO_SYNC=0: all parameters of
+            # YOLOv2-416 differ after the third step by 4e-6 .. 1e-5, the loss after 11 steps takes one of four values).
+            self._hyper_host = torch.zeros(self._HYPER_SLOTS, 5, dtype=torch.float32).pin_memory()
+            self._hyper_events = [None] * self._HYPER_SLOTS
             self._hyper_dev = torch.zeros(5, dtype=torch.float32, device="cuda")
         return self._hyper_host, self._hyper_dev
 
@@ -53,10 +62,17 @@ class Adam(Optimizer):
         """host side of one captured step: advance the step counter, upload {lr_t, beta1, beta2, eps, grad_scale}
         (lr_t computed exactly as yolo_adam_step computes it) on the current stream, ahead of the replay that reads it"""
         self.iterations += 1
-        host, dev = self._hyper_buffers()
+        ring, dev = self._hyper_buffers()
+        slot = self.iterations % self._HYPER_SLOTS
+        if self._hyper_events[slot] is not None:
+            self._hyper_events[slot].synchronize()   # (its upload of 64 steps ago has long run: returns at once)
+        host = ring[slot]
         host[0] = ops.adam_lr_t(self.learning_rate, self.iterations, self.beta_1, self.beta_2)
         host[1], host[2], host[3], host[4] = self.beta_1, self.beta_2, self.epsilon, float(grad_scale)
         dev.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._hyper_events[slot] = ev
 
     def step_captured(self):
         """enqueue (inside a stream capture) the update with the scalars read from the device"""
