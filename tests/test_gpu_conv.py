@@ -97,6 +97,42 @@ def test_conv_dgrad_wgrad(case):
         assert _relerr(dx2.double().cpu(), 2 * x.grad) < TOL
 
 
+@pytest.mark.parametrize("case", [CASES[6], CASES[4], CASES[11], CASES[7], (4, 112, 112, 3, 64, 7, 2, "same", False),
+                                  (2, 40, 40, 24, 40, 3, 1, "same", True)])
+def test_conv_wgrad_exact_kernel_reproducible(case):
+    """yolo_conv2d_wgrad on fp32 operands (the 7x7 RGB stem of YOLOv1.5, heads narrower than 32 filters, channel counts the
+    planes kernels do not take): with the wgrad workspace registered the splits of the pixel contraction go to slabs and are
+    added IN ORDER (wgrad_exact_reduce_kernel) instead of meeting in fp32 atomics -- until round 6 this kernel's gradients
+    differed in the last bit from run to run (scripts/step_repro.py c1: conv1_conv/kernel after ONE step). Two runs
+    bit-identical, accumulating onto dw, equal to the atomic form to summation order and to the float64 oracle to 1e-4."""
+    from tf2_yolo_amd import _lib, ops
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=41)
+    wk.requires_grad_(True)
+    ref = L.conv2d(x, wk, None, stride=s, padding=pad)
+    g = torch.Generator().manual_seed(42)
+    dy = torch.randn(ref.shape, generator=g, dtype=torch.float64)
+    ref.backward(dy)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    xd, dyd = x.float().cuda(), dy.float().cuda()
+
+    def run():
+        dw = torch.full((cout, k, k, cin), 0.5, device="cuda")
+        ops.conv2d_wgrad(d, xd, dyd, dw, None)
+        torch.cuda.synchronize()
+        return dw
+    lib = _lib.load()
+    _lib.check(lib.yolo_set_wgrad_workspace(None, 0), "yolo_set_wgrad_workspace")     # atomics
+    ops._WGRAD_WS = None
+    dw_a = run()
+    ops.ensure_wgrad_workspace()
+    dw1, dw2 = run(), run()
+    assert torch.equal(dw1, dw2)
+    want = _krsc(wk.grad)
+    assert _relerr((dw1 - 0.5).double().cpu(), want) < TOL
+    assert _relerr((dw1 - 0.5).double(), (dw_a - 0.5).double()) < 1e-5
+
+
 def test_conv_rejects_bad_descriptor():
     from tf2_yolo_amd import ops
     from tf2_yolo_amd._lib import YoloHipError

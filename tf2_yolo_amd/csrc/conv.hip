@@ -640,6 +640,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a
     for (int kt = 0; kt < nk; ++kt) slice(kt, S0{}, S0{});
   }
 
+  if (a.slabs != nullptr) {
+    // reproducible form (yolo_set_wgrad_workspace): the tile's partial to slab (split, tile) in [BM][BN] order, every
+    // element (the slab is BM x BN whatever the tensor's edge); wgrad_exact_reduce_kernel adds the splits in order
+    float* slab = a.slabs + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (BM * BN);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          slab[((wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)) * BN + (wn * TN + j) * 32 + (lane & 31)] =
+              acc[i][j][r];
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int cj = j0 + (wn * TN + j) * 32 + (lane & 31);
@@ -652,6 +666,21 @@ __global__ __launch_bounds__(64 * WGM * WGN) void wgrad_kernel(const WgradArgs a
         if (cok && co < a.Cout) atomicAdd(&a.dw[(long long)co * a.ldw + cj], acc[i][j][r]);
       }
     }
+  }
+}
+
+// dw += the slabs of wgrad_kernel's reproducible form, splits added in order: one thread per filter element
+__global__ __launch_bounds__(256) void wgrad_exact_reduce_kernel(const WgradArgs a, const int BM, const int BN) {
+  const int cols = a.ntaps * a.Cs;
+  const long long n = (long long)a.Cout * cols;
+  const long long tiles = (long long)a.tiles_co * a.tiles_j;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int co = (int)(e / cols), cj = (int)(e - (long long)co * cols);
+    const long long tile = (long long)(cj / BN) * a.tiles_co + co / BM;   // (= blockIdx.x of wgrad_kernel: column tile * tiles_co + row tile)
+    const float* p = a.slabs + (size_t)tile * (BM * BN) + (size_t)(co % BM) * BN + (cj % BN);
+    float s = 0.f;
+    for (int sp = 0; sp < a.splits; ++sp) s += p[(size_t)sp * tiles * (BM * BN)];
+    a.dw[(long long)co * a.ldw + cj] += s;
   }
 }
 
@@ -671,7 +700,28 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st) {
   long long chunk = (a.M + splits - 1) / splits;
   chunk = (chunk + 31) / 32 * 32;
   splits = (a.M + chunk - 1) / chunk;
+  // reproducible form: the slabs of all workgroups must fit the registered workspace (fewer, longer splits otherwise);
+  // without a workspace (or YOLO_WGRAD_DETERMINISTIC=0) the splits meet in fp32 atomics, as until round 6 -- the 7x7 RGB
+  // stem of YOLOv1.5 and every layer whose channel counts keep it off the planes kernels took this path, and its
+  // gradients differed in the last bit from run to run (scripts/step_repro.py c1)
+  a.slabs = nullptr;
+  static const bool det_env = [] { const char* e = getenv("YOLO_WGRAD_DETERMINISTIC"); return !(e && atoi(e) == 0); }();
+  size_t ws_bytes = 0;
+  unsigned char* ws = reinterpret_cast<unsigned char*>(wgrad_workspace(&ws_bytes));
+  if (det_env && ws != nullptr && ws_bytes > WGRAD_WS_COLSUM_BYTES) {
+    const long long cap = (long long)((ws_bytes - WGRAD_WS_COLSUM_BYTES) / ((size_t)BM * BN * 4));
+    if (cap >= tiles) {
+      if (tiles * splits > cap) {
+        splits = cap / tiles;
+        chunk = (a.M + splits - 1) / splits;
+        chunk = (chunk + 31) / 32 * 32;
+        splits = (a.M + chunk - 1) / chunk;
+      }
+      a.slabs = reinterpret_cast<float*>(ws + WGRAD_WS_COLSUM_BYTES);
+    }
+  }
   a.chunk = chunk;
+  a.splits = (int)splits;
   if (tiles > 0x7fffffffLL || splits > 65535) {
     set_error("wgrad: bad grid %lld x %lld", tiles, splits);
     return YOLO_ERR_INVALID_ARG;
@@ -679,7 +729,13 @@ static int launch_wgrad(WgradArgs& a, hipStream_t st) {
   constexpr size_t lds = 2 * 32 * (BM + BN) * sizeof(float);
   hipLaunchKernelGGL((wgrad_kernel<BM, BN, WGM, WGN, ASCALAR, BSCALAR>), dim3((unsigned)tiles, (unsigned)splits),
                      dim3(NT), lds, st, a);
-  return check_launch("wgrad_kernel");
+  if (int rc = check_launch("wgrad_kernel")) return rc;
+  if (a.slabs != nullptr) {
+    const long long n = (long long)a.Cout * cols;
+    hipLaunchKernelGGL(wgrad_exact_reduce_kernel, dim3((unsigned)stream_grid(n, 256)), dim3(256), 0, st, a, BM, BN);
+    return check_launch("wgrad_exact_reduce_kernel");
+  }
+  return YOLO_OK;
 }
 
 template <bool ASCALAR, bool BSCALAR>
