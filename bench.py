@@ -116,7 +116,7 @@ def pmc_from_profile(kernel):
                                                     "SIMDs over GRBM_GUI_ACTIVE / 8 XCDs)"}
 
 
-def cpu_baseline(threads, n=BATCH, timed=1):
+def cpu_baseline(threads, n=BATCH, timed=1, weights=None, batch=None):
     """Bounded sample of the SAME workload on the host CPU: training steps (forward, loss, autograd backward) of the torch-CPU
     restatement of the reference graph, fp32, at the benchmark's own batch of 32 (rounds 4-5 ran batch 16). One warm-up step
     OUTSIDE the timer (oneDNN primitive creation, allocator growth, page faults), then `timed` steps of ~17 s each;
@@ -125,10 +125,17 @@ def cpu_baseline(threads, n=BATCH, timed=1):
     from oracle import models as OM
     from tf2_yolo_amd import graphs, labels
     torch.set_num_threads(threads)
-    rng = np.random.default_rng(1234)
-    x, ys = labels.synthetic_batch(rng, n, (HW, HW), CLASSES)
-    b = graphs.build_yolov3((HW, HW, 3), CLASSES)
-    w = {k: torch.from_numpy(v) for k, v in labels.synthetic_keras_weights(b, 1234).items()}
+    if batch is not None:     # the device run's own batch (rank 0) and, below, its initial weights: the first-step losses of the
+        x, ys = batch         # two executions can then be compared (this CPU step is the oracle's, in fp32)
+        n = x.shape[0]
+    else:
+        rng = np.random.default_rng(1234)
+        x, ys = labels.synthetic_batch(rng, n, (HW, HW), CLASSES)
+    if weights is not None:
+        w = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in weights.items()}
+    else:
+        b = graphs.build_yolov3((HW, HW, 3), CLASSES)
+        w = {k: torch.from_numpy(v) for k, v in labels.synthetic_keras_weights(b, 1234).items()}
     for v in w.values():
         v.requires_grad_(True)
     anchors = graphs.V3_DEFAULT_ANCHORS
@@ -137,6 +144,8 @@ def cpu_baseline(threads, n=BATCH, timed=1):
     xt = torch.from_numpy(x)
     yts = [torch.from_numpy(y) for y in ys]
 
+    losses = []
+
     def step():
         for v in w.values():
             v.grad = None
@@ -144,12 +153,14 @@ def cpu_baseline(threads, n=BATCH, timed=1):
         outs, _ = OM.yolov3_forward(w, xt, anchors, training=True)
         total = sum(f(y, o) for f, y, o in zip(lossf, yts, outs))
         total.backward()
+        losses.append(float(total.detach()))
         return time.perf_counter() - t0
 
     warm = step()
     times = sorted(step() for _ in range(timed))
     dt = times[len(times) // 2] if len(times) % 2 else 0.5 * (times[len(times) // 2 - 1] + times[len(times) // 2])
     return {"value": round(n / dt, 4), "unit": "images/s", "cores": threads, "kind": "port", "batch": n,
+            "loss": losses[0], "weights": "the device run's initial weights and batch" if weights is not None else "synthetic_keras_weights(1234)",
             "step_seconds": {"warmup_untimed": round(warm, 2), "timed": [round(t, 2) for t in times]},
             "sample": f"{timed} timed training step(s) after 1 untimed warm-up step (fwd+loss+autograd bwd, no optimizer) of the "
                       f"torch-CPU/oneDNN fp32 restatement of the reference YOLOv3 graph at the benchmark's batch {n}, 416x416 C=80, "
@@ -504,9 +515,15 @@ def main():
     # tf2_yolo_amd/capture.py, and the capture itself must not fall into the timed region)
     warm_run = max(args.warmup, 3)
     loss_first = None
+    # the initial weights, for the CPU oracle's step at the end (cpu_baseline): its loss on the same weights and batch is
+    # compared with the device's first-step loss -- an oracle-anchored check inside the benchmark line itself
+    w0 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.plain:
+        w0 = {f"{n}/{i}": np.array(a, dtype=np.float32, copy=True) for n in model.layer_names()
+              for i, a in enumerate(model.get_layer(n).get_weights())}
     for i in range(warm_run):
         b0, _ = model.train_step_device(x, ys)
-        if i == 0 and args.plain:     # (the strict-fp32 block compares the two arithmetics on the very first step)
+        if i == 0 and (args.plain or w0 is not None):     # (the strict-fp32 block compares the two arithmetics on the very first step)
             loss_first = float(sum(b[0].item() for b in b0))
     barrier()
     captured = getattr(model, "_step_graphs", None) is not None
@@ -732,7 +749,14 @@ def main():
                 cores = len(os.sched_getaffinity(0))
             except AttributeError:
                 cores = os.cpu_count() or 1
-            out["cpu_baseline"] = cpu_baseline(min(cores, 16))   # the GPU box's CPU share is 16 cores
+            cb = cpu_baseline(min(cores, 16), weights=w0, batch=(x_h, ys_h) if w0 is not None else None)   # the GPU box's CPU share is 16 cores
+            if w0 is not None and loss_first is not None:
+                rel = abs(cb["loss"] - loss_first) / max(abs(cb["loss"]), 1.0)
+                cb["first_step_loss_check"] = {
+                    "what": "loss of the device's FIRST training step against the CPU oracle's fp32 step on the same initial "
+                            "weights and the same batch (training-mode BatchNorm, the three losses summed)",
+                    "device": loss_first, "cpu_oracle_fp32": cb["loss"], "rel_diff": rel, "agree_to_1e-4": bool(rel < 1e-4)}
+            out["cpu_baseline"] = cb
         # LAST key: the figures of the informational blocks once more, flat and short (a record that keeps only the tail
         # of this line still holds them)
         try:
@@ -760,6 +784,9 @@ def main():
                                               "gpu_soft_nms_ms")}
             ref5 = c5.get("cpu_reference") or {}
             sm["c5_cpu_reference_ms"] = {k: ref5.get(k) for k in ("candidates", "decode_ms", "nms_ms", "diou_nms_ms", "soft_nms_ms")}
+            chk = (out.get("cpu_baseline") or {}).get("first_step_loss_check")
+            if chk:
+                sm["first_step_loss_rel_diff_vs_cpu_oracle"] = chk["rel_diff"]
             out["summary"] = sm
         except Exception as e:
             out["summary"] = {"error": repr(e)}
