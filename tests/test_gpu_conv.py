@@ -822,6 +822,69 @@ def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
     assert _relerr(z1.double(), z2.double()) < 2e-6
 
 
+def _small_fuzz_cases():
+    import random
+    rnd = random.Random(20261005)
+    cases = []
+    while len(cases) < 24:
+        k = rnd.choice([1, 1, 3])
+        s_ = rnd.choice([1, 1, 2])
+        n = rnd.choice([1, 1, 2, 3])
+        h, w = rnd.randint(5, 30), rnd.randint(5, 30)
+        cin = 16 * rnd.randint(1, 12)
+        cout = 32 * rnd.randint(1, 8)
+        pad = rnd.choice(["same", "same", "valid"])
+        if pad == "valid" and (h < k + 1 or w < k + 1):
+            continue
+        cases.append((n, h, w, cin, cout, k, s_, pad, rnd.random() < 0.3))
+    return cases
+
+
+@pytest.mark.parametrize("case", _small_fuzz_cases())
+def test_conv_small_kernel_random_shapes(case):
+    """yolo_conv2d_fwd_infer_unit on 24 random small shapes (1x1 and 3x3, strides 1 / 2, 'same' / 'valid', 1-3 images, odd
+    sizes, Cin = 16 .. 192, Cout = 32 .. 256, with and without a residual): whichever kernel the policy picks
+    (csrc/conv_small.hip for the 1x1 units and, under YOLO_CONV_SMALL=3 -- scripts/gpu/r6aw.sh runs the file that way too --
+    for every 3x3 unit) against the float64 oracle and the fused-epilogue convolution of the training kernels."""
+    from tf2_yolo_amd import ops
+    ops.ensure_conv_workspace()
+    n, h, w, cin, cout, k, s, pad, bias = case
+    x, wk, b = _mk(case, seed=51)
+    g = torch.Generator().manual_seed(52)
+    d = ops.conv_desc((n, h, w, cin), cout, k, k, s, pad)
+    rows = n * d.Ho * d.Wo
+    xd, wd = x.float().cuda(), _krsc(wk).float().cuda()
+    bd = None if b is None else b.float().cuda()
+    scale = (torch.rand(cout, generator=g) + 0.5).float().cuda()
+    shift = (torch.randn(cout, generator=g) * 0.3).float().cuda()
+    with_res = (h + w) % 2 == 0
+    res = torch.randn(n, d.Ho, d.Wo, cout, generator=g).float().cuda() if with_res else None
+    xp = ops.split_planes(xd, n * h * w, cin)
+    wp = ops.split_planes(wd, cout, k * k * cin)
+    amax0 = torch.zeros(cout, device="cuda", dtype=torch.int32)
+    y_ref = ops.conv2d_fwd_planes_epi(d, xp, wp, bd, ops.EPI_AFFINE_LEAKY, scale, shift, residual=res, absmax=amax0)
+    pred = torch.zeros(2, device="cuda")
+    ops.conv_pred_bound(wd, cout, k * k * cin, scale, shift, bd, pred)
+    y = torch.full_like(y_ref, float("nan"))
+    pl = torch.zeros(ops.planes_bytes(rows, cout), device="cuda", dtype=torch.uint8)
+    out_words = torch.full((ops.INFER_BOUND_WORDS,), -1, device="cuda", dtype=torch.int32)
+    nw = ops.conv2d_fwd_infer_unit(d, xp, wp, bd, ops.EPI_AFFINE_LEAKY, scale, shift, res, y,
+                                   torch.zeros(cout, device="cuda", dtype=torch.int32), pred, xd.abs().max().reshape(1),
+                                   res.abs().max().reshape(1) if with_res else None, pl, out_words, torch.zeros(1, device="cuda"))
+    torch.cuda.synchronize()
+    assert _relerr(y.double(), y_ref.double()) < 2e-6
+    ref = L.conv2d(x, wk, b, stride=s, padding=pad)
+    z = ref.permute(0, 1, 2, 3) * scale.double().cpu() + shift.double().cpu()
+    z = torch.where(z > 0, z, 0.1 * z) + (res.double().cpu() if with_res else 0.0)
+    assert _relerr(y.double().cpu(), z) < 1e-5
+    vals, bound, sc, tail = _planes_values(pl.cpu(), rows, cout)
+    assert (tail == 0).all() and bound >= float(y.abs().max())
+    yd = y.double().cpu().reshape(rows, cout)
+    assert ((vals - yd).abs() <= torch.maximum(2.0 ** -22 * yd.abs(), torch.tensor(2.0 ** -25 / sc, dtype=torch.float64))).all()
+    if nw:
+        assert float(out_words[:nw].view(torch.float32).max()) == float(y.abs().max())
+
+
 @pytest.mark.parametrize("n,hw,cin,A,C,version", [(1, 13, 1024, 3, 80, 3), (1, 26, 512, 3, 80, 3), (1, 52, 256, 3, 80, 4),
                                                   (2, 19, 128, 3, 20, 3), (1, 13, 1024, 5, 20, 2), (8, 52, 256, 3, 80, 3)])
 def test_head_unit_in_one_call(n, hw, cin, A, C, version):
