@@ -39,13 +39,30 @@ struct SmallBuf {
 // register buffer (two buffers)
 // HEAD: the detection-head form (GatherConvArgs::head_y): any Cout (columns past it are masked), bias only, the head's
 // activation instead of BatchNorm / activation / residual / planes
+// Epilogue: ALL blocks' partials go to LDS at once (TM TN x 32 KB), then the 4 TM TN quarter-blocks (8 rows x 32 columns
+// each) are shared out over the eight waves -- task t = wave, wave + 8: block t / 4, rows 8 (t % 4) + 4 (lane / 32) + e of
+// column lane % 32, the mapping of a thread of conv_split_reduce_kernel -- two barriers per launch whatever the tile
+// (block after block, finished by four of the waves: 2 TM TN barriers and 11.5 us for a 64 x 64 tile's launch instead of 10).
+template <int TM, int TN, int NT>
+struct SmallLds {
+  static constexpr int NB = TM * TN;
+  static constexpr int RED = 0;                                   // float [NB][8][16][64]
+  static constexpr int T32 = RED + NB * SM_WAVES * 16 * 64 * 4;   // float [NB][32][33]
+  static constexpr int AOFF = T32 + NB * 32 * 33 * 4;             // unsigned [NT][32 TM]
+  static constexpr int MX = AOFF + NT * 32 * TM * 4;              // float [3][8]
+  static constexpr int BYTES = MX + 3 * SM_WAVES * 4;
+};
+
 template <int NT, int TM, int TN, int CH, bool HEAD = false>
 __global__ __launch_bounds__(64 * SM_WAVES) void conv_small_kernel(const GatherConvArgs a) {
-  constexpr int BMT = 32 * TM, BNT = 32 * TN;
-  __shared__ float red[SM_WAVES][16][64];
-  __shared__ unsigned s_aoff[NT > 1 ? NT : 1][BMT];
-  __shared__ float t32[32][33];
-  __shared__ float s_mx[3][4];
+  constexpr int BMT = 32 * TM, BNT = 32 * TN, NB = TM * TN;
+  constexpr int NTASK = (4 * NB + SM_WAVES - 1) / SM_WAVES;      // quarter-blocks per wave
+  using LDS = SmallLds<TM, TN, NT>;
+  extern __shared__ unsigned char smem[];
+  float (*red)[SM_WAVES][16][64] = reinterpret_cast<float (*)[SM_WAVES][16][64]>(smem + LDS::RED);
+  float (*t32)[32][33] = reinterpret_cast<float (*)[32][33]>(smem + LDS::T32);
+  unsigned (*s_aoff)[BMT] = reinterpret_cast<unsigned (*)[BMT]>(smem + LDS::AOFF);
+  float (*s_mx)[SM_WAVES] = reinterpret_cast<float (*)[SM_WAVES]>(smem + LDS::MX);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hf = lane >> 5;
@@ -102,45 +119,36 @@ __global__ __launch_bounds__(64 * SM_WAVES) void conv_small_kernel(const GatherC
   // steps past the end multiply by the all-zero block of the weights (no branch in the loop)
   const unsigned bzero = (unsigned)(a.zero_blk_wgt * (a.ldw >> 4)) * PL_RECORD + (unsigned)(r & 15) * 16 + lane_unit;
 
-  // what the epilogue needs besides the sums is requested first (waves 0-3 finish the blocks: wave q holds rows
-  // 8q + 4 (lane >> 5) + e of column lane & 31 of a 32 x 32 block, as a thread of conv_split_reduce_kernel)
-  const bool fin = wave < 4;
-  float ib = 0.f, rb = 0.f, unscale = 1.f;
-  float bv[TN], esc[TN], esh[TN];
-  float rv[TM][TN][4];
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    bv[j] = 0.f; esc[j] = 1.f; esh[j] = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) rv[i][j][e] = 0.f;
+  // what the epilogue needs besides the sums is requested first, per quarter-block of this wave
+  float ib = 0.f, rb = 0.f;
+  const float unscale = reinterpret_cast<const float*>(srcp + a.src_bytes - PL_HEADER)[2] *
+                        reinterpret_cast<const float*>(wgtp + a.wgt_bytes - PL_HEADER)[2];
+  float bv[NTASK], esc[NTASK], esh[NTASK], rv[NTASK][4];
+  if constexpr (!HEAD) {
+    for (int w = tid; w < a.pl_in_n; w += 64 * SM_WAVES) ib = fmaxf(ib, __builtin_bit_cast(float, a.pl_in_bound[w]));
+    if (a.pl_res_bound != nullptr)
+      for (int w = tid; w < a.pl_res_n; w += 64 * SM_WAVES) rb = fmaxf(rb, __builtin_bit_cast(float, a.pl_res_bound[w]));
   }
-  if (fin) {
-    if constexpr (!HEAD) {
-      for (int w = tid; w < a.pl_in_n; w += 256) ib = fmaxf(ib, __builtin_bit_cast(float, a.pl_in_bound[w]));
-      if (a.pl_res_bound != nullptr)
-        for (int w = tid; w < a.pl_res_n; w += 256) rb = fmaxf(rb, __builtin_bit_cast(float, a.pl_res_bound[w]));
-    }
-    unscale = reinterpret_cast<const float*>(srcp + a.src_bytes - PL_HEADER)[2] *
-              reinterpret_cast<const float*>(wgtp + a.wgt_bytes - PL_HEADER)[2];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = tile_n * BNT + 32 * j + r;
+  for (int k = 0; k < NTASK; ++k) {
+    const int t = wave + SM_WAVES * k;
+    bv[k] = 0.f; esc[k] = 1.f; esh[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) rv[k][e] = 0.f;
+    if (t < 4 * NB) {
+      const int b = t >> 2, q = t & 3, bi = b / TN, bj = b - bi * TN;
+      const int col = tile_n * BNT + 32 * bj + r;
       if constexpr (HEAD) {
-        bv[j] = (a.bias != nullptr && col < a.Cout) ? a.bias[col] : 0.f;
-        continue;
-      }
-      bv[j] = a.bias != nullptr ? a.bias[col] : 0.f;
-      esc[j] = a.epi_scale[col];
-      esh[j] = a.epi_shift[col];
-      if (a.epi_res != nullptr) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const long long mrow = (long long)tile_m * BMT + 32 * i + 8 * wave + 4 * hf;
+        bv[k] = (a.bias != nullptr && col < a.Cout) ? a.bias[col] : 0.f;
+      } else {
+        bv[k] = a.bias != nullptr ? a.bias[col] : 0.f;
+        esc[k] = a.epi_scale[col];
+        esh[k] = a.epi_shift[col];
+        if (a.epi_res != nullptr) {
+          const long long mrow = (long long)tile_m * BMT + 32 * bi + 8 * q + 4 * hf;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            if (mrow + e < a.M) rv[i][j][e] = a.epi_res[(mrow + e) * a.Cd + col];
+            if (mrow + e < a.M) rv[k][e] = a.epi_res[(mrow + e) * a.Cd + col];
         }
       }
     }
@@ -211,41 +219,15 @@ __global__ __launch_bounds__(64 * SM_WAVES) void conv_small_kernel(const GatherC
     mma(b1);
   }
 
-  if constexpr (HEAD) {
-    // block by block: partials added in wave order by waves 0-3, bias, the head's activation, masked stores
-    const int D = 5 + a.head_C;
+  // every wave's partial of every block to LDS; the words of the a-priori bound (requested before the main loop) are
+  // first looked at here
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int k = 0; k < 16; ++k) red[wave][k][lane] = acc[i][j][k];
-        __syncthreads();
-        if (fin) {
-          const int col = tile_n * BNT + 32 * j + r;
-          const long long mrow = (long long)tile_m * BMT + 32 * i + 8 * wave + 4 * hf;
-          const int kk = col % D, an = col / D;
-          const float anc = (col < a.Cout && (kk == 2 || kk == 3)) ? a.head_anchors[an * 2 + (kk - 2)] : 0.f;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float sum = red[0][4 * wave + e][lane];
-#pragma unroll
-            for (int w = 1; w < SM_WAVES; ++w) sum += red[w][4 * wave + e][lane];
-            if (mrow + e < a.M && col < a.Cout) {
-              const float v = fmaf(sum, unscale, bv[j]);
-              if (a.dst != nullptr) a.dst[(mrow + e) * a.Cd + col] = v;
-              // (the expressions of head_fwd_pointwise_kernel, elementwise.hip)
-              a.head_y[(mrow + e) * a.Cd + col] = (kk == 2 || kk == 3) ? expf(v) * anc : 1.f / (1.f + expf(-v));
-            }
-          }
-        }
-        __syncthreads();
-      }
-    return;
-  }
-  // scale of the outgoing planes from the a-priori bound (see conv_split_reduce_kernel); the words of the bound were
-  // requested before the main loop and are first looked at here
-  if (fin) {
+      for (int k = 0; k < 16; ++k) red[i * TN + j][wave][k][lane] = acc[i][j][k];
+  if constexpr (!HEAD) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       ib = fmaxf(ib, __shfl_xor(ib, o, 64));
@@ -257,67 +239,89 @@ __global__ __launch_bounds__(64 * SM_WAVES) void conv_small_kernel(const GatherC
     }
   }
   __syncthreads();
-  const float in_b = fmaxf(fmaxf(s_mx[1][0], s_mx[1][1]), fmaxf(s_mx[1][2], s_mx[1][3]));
-  const float res_b = fmaxf(fmaxf(s_mx[2][0], s_mx[2][1]), fmaxf(s_mx[2][2], s_mx[2][3]));
-  const float bnd = (a.pl_pred[0] * in_b + a.pl_pred[1] + res_b) * 1.001f + 1e-30f;
-  const float psc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bnd));
-  if (blockIdx.x == 0 && tid == 0) {
-    unsigned* header = reinterpret_cast<unsigned*>(a.out_planes + planes_body_bytes(a.M, a.Cout));
-    header[0] = __builtin_bit_cast(unsigned, bnd);
-    reinterpret_cast<float*>(header)[1] = psc;
-    reinterpret_cast<float*>(header)[2] = 1.f / psc;
+  float psc = 1.f;
+  if constexpr (!HEAD) {
+    // scale of the outgoing planes from the a-priori bound (see conv_split_reduce_kernel)
+    float in_b = 0.f, res_b = 0.f;
+#pragma unroll
+    for (int w = 0; w < SM_WAVES; ++w) {
+      in_b = fmaxf(in_b, s_mx[1][w]);
+      res_b = fmaxf(res_b, s_mx[2][w]);
+    }
+    const float bnd = (a.pl_pred[0] * in_b + a.pl_pred[1] + res_b) * 1.001f + 1e-30f;
+    psc = planes_scale_from_bound(__builtin_bit_cast(unsigned, bnd));
+    if (blockIdx.x == 0 && tid == 0) {
+      unsigned* header = reinterpret_cast<unsigned*>(a.out_planes + planes_body_bytes(a.M, a.Cout));
+      header[0] = __builtin_bit_cast(unsigned, bnd);
+      reinterpret_cast<float*>(header)[1] = psc;
+      reinterpret_cast<float*>(header)[2] = 1.f / psc;
+    }
   }
-  // block by block: the partials of the eight waves added in wave order by waves 0-3 (the other four only keep the
-  // barriers company), epilogue, fp32 store, planes through t32
+  // this wave's quarter-blocks: the eight partials added in wave order, epilogue, fp32 store
   float mxf = 0.f;
+  const int D = HEAD ? 5 + a.head_C : 1;
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int k = 0; k < NTASK; ++k) {
+    const int t = wave + SM_WAVES * k;
+    if (t < 4 * NB) {
+      const int b = t >> 2, q = t & 3, bi = b / TN, bj = b - bi * TN;
+      const int col = tile_n * BNT + 32 * bj + r;
+      const long long mrow = (long long)tile_m * BMT + 32 * bi + 8 * q + 4 * hf;
+      float anc = 0.f;
+      int kk = 0;
+      if constexpr (HEAD) {
+        kk = col % D;
+        if (col < a.Cout && (kk == 2 || kk == 3)) anc = a.head_anchors[(col / D) * 2 + (kk - 2)];
+      }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
+      for (int e = 0; e < 4; ++e) {
+        float sum = red[b][0][4 * q + e][lane];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) red[wave][k][lane] = acc[i][j][k];
-      __syncthreads();
-      if (fin) {
-        const int col = tile_n * BNT + 32 * j + r;
-        const long long mrow = (long long)tile_m * BMT + 32 * i + 8 * wave + 4 * hf;
-        const int rl = 8 * wave + 4 * hf;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float sum = red[0][4 * wave + e][lane];
-#pragma unroll
-          for (int w = 1; w < SM_WAVES; ++w) sum += red[w][4 * wave + e][lane];
+        for (int w = 1; w < SM_WAVES; ++w) sum += red[b][w][4 * q + e][lane];
+        if constexpr (HEAD) {
+          if (mrow + e < a.M && col < a.Cout) {
+            const float v = fmaf(sum, unscale, bv[k]);
+            if (a.dst != nullptr) a.dst[(mrow + e) * a.Cd + col] = v;
+            // (the expressions of head_fwd_pointwise_kernel, elementwise.hip)
+            a.head_y[(mrow + e) * a.Cd + col] = (kk == 2 || kk == 3) ? expf(v) * anc : 1.f / (1.f + expf(-v));
+          }
+        } else {
           float v = 0.f;
           if (mrow + e < a.M) {
-            v = fmaf(sum, unscale, bv[j]);
-            v = act_fwd(fmaf(esc[j], v, esh[j]), a.epi_act);
-            v += rv[i][j][e];
+            v = fmaf(sum, unscale, bv[k]);
+            v = act_fwd(fmaf(esc[k], v, esh[k]), a.epi_act);
+            v += rv[k][e];
             a.dst[(mrow + e) * a.Cd + col] = v;
             mxf = fmaxf(mxf, fabsf(v));
           }
-          t32[rl + e][r] = v;
-        }
-      }
-      __syncthreads();
-      if (tid < 128) {
-        const int rr = tid >> 2, g = tid & 3;
-        const long long mo = (long long)tile_m * BMT + 32 * i + rr;
-        const int c0 = tile_n * BNT + 32 * j + g * 8;
-        if (mo < a.M) {
-          const f32x4 o0 = {t32[rr][g * 8 + 0], t32[rr][g * 8 + 1], t32[rr][g * 8 + 2], t32[rr][g * 8 + 3]};
-          const f32x4 o1 = {t32[rr][g * 8 + 4], t32[rr][g * 8 + 5], t32[rr][g * 8 + 6], t32[rr][g * 8 + 7]};
-          store_planes8(a.out_planes, mo, c0 >> 3, a.Cout, o0, o1, psc);
+          t32[b][8 * q + 4 * hf + e][r] = v;
         }
       }
     }
-  // max|dst| of this workgroup's tile: ONE word per workgroup, a plain store
-  if (fin) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o, 64));
-    if (lane == 0) s_mx[0][wave] = mxf;
   }
+  if constexpr (HEAD) return;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mxf = fmaxf(mxf, __shfl_xor(mxf, o, 64));
+  if (lane == 0) s_mx[0][wave] = mxf;
   __syncthreads();
-  if (tid == 0)
-    a.pl_out_words[blockIdx.x] = __builtin_bit_cast(unsigned, fmaxf(fmaxf(s_mx[0][0], s_mx[0][1]), fmaxf(s_mx[0][2], s_mx[0][3])));
+  // the finished blocks as planes (through t32: one (row, 8-channel group) unit per thread and turn)
+  for (int u = tid; u < NB * 128; u += 64 * SM_WAVES) {
+    const int b = u >> 7, rr = (u >> 2) & 31, g = u & 3, bi = b / TN, bj = b - bi * TN;
+    const long long mo = (long long)tile_m * BMT + 32 * bi + rr;
+    const int c0 = tile_n * BNT + 32 * bj + g * 8;
+    if (mo < a.M) {
+      const f32x4 o0 = {t32[b][rr][g * 8 + 0], t32[b][rr][g * 8 + 1], t32[b][rr][g * 8 + 2], t32[b][rr][g * 8 + 3]};
+      const f32x4 o1 = {t32[b][rr][g * 8 + 4], t32[b][rr][g * 8 + 5], t32[b][rr][g * 8 + 6], t32[b][rr][g * 8 + 7]};
+      store_planes8(a.out_planes, mo, c0 >> 3, a.Cout, o0, o1, psc);
+    }
+  }
+  // max|dst| of this workgroup's tile: ONE word per workgroup, a plain store
+  if (tid == 0) {
+    float m = 0.f;
+#pragma unroll
+    for (int w = 0; w < SM_WAVES; ++w) m = fmaxf(m, s_mx[0][w]);
+    a.pl_out_words[blockIdx.x] = __builtin_bit_cast(unsigned, m);
+  }
 }
 
 static int env_int(const char* name, int dflt) {
@@ -377,7 +381,14 @@ template <int NT, int TM, int TN, int CH, bool HEAD = false>
 static int launch_small(GatherConvArgs& a, hipStream_t st, int* nwg) {
   a.nblocks = (int)(((a.M + 32 * TM - 1) / (32 * TM)) * ((a.Cout + 32 * TN - 1) / (32 * TN)));
   *nwg = a.nblocks;
-  hipLaunchKernelGGL((conv_small_kernel<NT, TM, TN, CH, HEAD>), dim3((unsigned)a.nblocks), dim3(64 * SM_WAVES), 0, st, a);
+  constexpr int lds = SmallLds<TM, TN, NT>::BYTES;   // (up to 150 KB: the 64 x 64 tile's four blocks at once)
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_small_kernel<NT, TM, TN, CH, HEAD>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_small_kernel<NT, TM, TN, CH, HEAD>), dim3((unsigned)a.nblocks), dim3(64 * SM_WAVES), lds, st, a);
   return check_launch("conv_small_kernel");
 }
 
