@@ -4,10 +4,10 @@ mkdir -p gpurun_out/r6ai
 export TMPDIR=/tmp
 R=$PWD
 for T in 11 21 22; do
-  YOLO_CONV_SMALL_TILE=$T timeout -k 10 300 python -m pytest tests/test_gpu_conv.py -x -q -k "inference_unit" > gpurun_out/r6ai/test_$T.log 2>&1 || { tail -30 gpurun_out/r6ai/test_$T.log; exit 1; }
+  YOLO_CONV_SMALL=3 YOLO_CONV_SMALL_TILE=$T timeout -k 10 300 python -m pytest tests/test_gpu_conv.py -x -q -k "inference_unit" > gpurun_out/r6ai/test_$T.log 2>&1 || { tail -30 gpurun_out/r6ai/test_$T.log; exit 1; }
   tail -1 gpurun_out/r6ai/test_$T.log
   rm -rf /tmp/r6ai
-  ( cd /tmp && YOLO_CONV_SMALL_TILE=$T YOLO_CONV_SMALL_GRID=4096 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/r6ai -- python3 $R/scripts/infer_bs1_graph.py > $R/gpurun_out/r6ai/run_$T.log 2>&1 )
+  ( cd /tmp && YOLO_CONV_SMALL=3 YOLO_CONV_SMALL_TILE=$T YOLO_CONV_SMALL_GRID=4096 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/r6ai -- python3 $R/scripts/infer_bs1_graph.py > $R/gpurun_out/r6ai/run_$T.log 2>&1 )
   f=$(find /tmp/r6ai -name "*kernel_trace.csv" | head -1)
   python3 - "$f" <<'P' > gpurun_out/r6ai/small_by_grid_$T.txt
 import csv, sys, collections
