@@ -728,7 +728,8 @@ def _conv_small_takes(rows, cout, k, cin):
     if os.environ.get("YOLO_CONV_SMALL_TILE"):
         return g11 <= min(grid or 2048, 4096)
     if k == 3 and on != 3:
-        return 128 <= g22 <= (grid or 256) and 9 * (cin // 16) <= 72
+        cap, steps = (grid or 256), 9 * (cin // 16)
+        return g22 >= 128 and ((g22 <= cap and steps <= 72) or (g22 <= 2 * cap and steps <= 36))
     return g11 <= (grid or 256) or g22 <= (grid or 256)
 
 
@@ -746,6 +747,7 @@ def _conv_small_takes(rows, cout, k, cin):
     ((1, 40, 40, 32, 64, 3, 1, "same", False), False, None),     # 18 steps on eight waves: ragged
     ((1, 20, 20, 16, 32, 1, 1, "same", False), True, None),      # ONE step: seven waves multiply by the zero block
     ((1, 26, 26, 128, 64, 1, 2, "same", False), False, None),    # 1x1 stride 2
+    ((1, 104, 104, 64, 128, 3, 1, "same", False), True, None),   # 338 workgroups of 64 x 64: two rounds
 ])
 def test_inference_unit_writes_its_planes(case, with_res, expect_onepass):
     """yolo_conv2d_fwd_infer_unit: y bit-identical to the fused-epilogue convolution, its planes (scaled by the a-priori

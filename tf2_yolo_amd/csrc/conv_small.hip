@@ -368,7 +368,10 @@ static int small_tile(const GatherConvArgs& a) {
   if (a.ntaps == 9 && on != 3) {
     // 3x3 units: only where the 64 x 64 tile fills at least half the chip in one round with short streams (at most 72
     // steps = 128 input channels: the 52x52 layers of YOLOv3-416, 19.9 against 23.9 us); elsewhere the split-K pair wins
-    return (g22 <= cap && g22 >= 128 && a.ntaps * (a.Cs >> 4) <= 72) ? 22 : 0;
+    // (... and the 104x104 ones, 36 steps: 338 workgroups in two short rounds, 27.6 against 30 us)
+    const int steps = a.ntaps * (a.Cs >> 4);
+    static const int two_rounds = env_int("YOLO_CONV_SMALL_2R", 1);
+    return (g22 >= 128 && ((g22 <= cap && steps <= 72) || (two_rounds && g22 <= 2 * cap && steps <= 36))) ? 22 : 0;
   }
   if (g11 <= cap) return 11;
   if (g22 <= cap) return 22;
