@@ -434,6 +434,53 @@ def test_replayed_steps_do_not_depend_on_how_far_the_host_runs_ahead():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("ver", [1, 2, 4])
+def test_training_is_bit_reproducible_for_every_version(ver):
+    """Two models of one configuration from one seed, seven steps each on one batch, the host NOT waiting for the GPU between
+    steps: weights, BatchNorm moving statistics and Adam moments bit-identical (scripts/step_repro.py does this at the
+    benchmark's sizes). v1.5: the 7x7 RGB stem's filter gradient runs on the fp32-input kernel, whose splits met in fp32
+    atomics until round 6; v2: bias in front of BatchNorm, the passthrough route; v4: Mish, SPP's overlapping pools, PAN."""
+    import torch as _t
+    from tf2_yolo_amd import labels
+    from tf2_yolo_amd.optimizers import Adam
+
+    def make():
+        _t.manual_seed(77)
+        np.random.seed(77)
+        rng = np.random.default_rng(7)
+        if ver == 2:
+            import yolov2
+            y = yolov2.Yolo((96, 96, 3), ["a", "b", "c"])
+            y.create_model()
+            x, ys = labels.synthetic_batch(rng, 4, (96, 96), 3, levels=1, finest_stride=32)
+            loss = y.loss()
+        elif ver == 1:
+            import yolov1_5
+            y = yolov1_5.Yolo((128, 128, 3), ["a"])
+            y.create_model()
+            x, ys = labels.synthetic_batch(rng, 4, (128, 128), 1, levels=1, finest_stride=64)
+            loss = y.loss(binary_weight=0.5)
+        else:
+            import yolov4
+            y = yolov4.Yolo((96, 96, 3), ["a", "b"])
+            y.create_model(anchors=A9, pretrained_body=None)
+            x, ys = labels.synthetic_batch(rng, 4, (96, 96), 2)
+            loss = y.loss()
+        y.model.compile(optimizer=Adam(learning_rate=1e-3), loss=loss)
+        return y.model, _t.from_numpy(x).cuda(), [_t.from_numpy(a).cuda() for a in ys]
+    res = []
+    for _ in range(2):
+        m, x, ys = make()
+        p0 = m.net.params.data.clone()
+        for _ in range(7):
+            m.train_step_device(x, ys)
+        _t.cuda.synchronize()
+        res.append((p0, m.net.params.data.clone(), m.net.state.data.clone(), m.optimizer.m.clone(), m.optimizer.v.clone()))
+    assert not _t.equal(res[0][0], res[0][1])          # (it trained)
+    for a, b in zip(*res):
+        assert _t.equal(a, b)
+
+
 def test_batch_too_large_for_32_bit_operand_offsets_is_refused_up_front():
     """every conv kernel addresses an operand through a buffer descriptor with 32-bit offsets: a batch whose largest
     activation would reach 4 GiB is refused by Network.allocate, with the largest batch that fits, before anything is
