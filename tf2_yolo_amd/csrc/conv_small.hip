@@ -5,10 +5,10 @@
 // kernels (conv_win.hip, conv_planes.hip) then run split-K -- every tile by up to 32 workgroups, each a latency-bound stream
 // of 8 KB stages through an LDS ring -- and a second launch adds the parts and runs the epilogue: 9.6-16 us + 6.9 us per
 // layer, 69 such pairs = 1.4 of the 1.5 ms of Model.predict (profiles/r06_e_c5_bs1_kernel_stats.csv). Nothing in such a
-// layer is re-used inside a tile often enough to be worth a trip through LDS, and what bounds it is how many bytes one
-// workgroup has in flight. So here:
-//   * tile = 32 pixels x 32 filters, ONE v_mfma_f32_32x32x16_f16 accumulator per wave; a 13x13 1024->512 layer is 96 tiles,
-//     a 52x52 3x3 128->256 layer 680 -- the chip is filled without splitting K across workgroups;
+// layer is re-used inside a tile often enough to be worth a trip through LDS, and no launch of the replayed graph costs
+// less than ~4.5 us however little it does: one launch per unit instead of two. So here:
+//   * tile = 32 pixels x 32 filters, ONE v_mfma_f32_32x32x16_f16 accumulator per wave (a 13x13 1024->512 layer is 96 tiles),
+//     or 64 x 64 with four (a 52x52 3x3 128->256 layer is 172) -- the chip is filled without splitting K across workgroups;
 //   * K is split across the EIGHT WAVES of the workgroup instead (16-channel steps s = wave, wave + 8, ...): every wave
 //     accumulates its own 32 x 32 partial, the partials are added in wave order through LDS (32 KB) -- bitwise reproducible;
 //   * operands go global -> registers: the planes format (planes.hpp) was laid out so that the 16-byte unit a lane needs for
@@ -20,7 +20,9 @@
 //     the tap falls outside the image) -- nine per-lane byte offsets in an LDS table, one ds_read_b32 per step;
 //   * the epilogue is conv_split_reduce_kernel's (conv_win.hip): unscale, bias, folded BN, activation, residual, fp32 store,
 //     planes scaled from the a-priori bound (GatherConvArgs::pl_pred), one word of max|dst| per workgroup.
-// Used by yolo_conv2d_fwd_infer_unit when the launch has at most YOLO_CONV_SMALL_GRID (default 2048) tiles.
+// Used by yolo_conv2d_fwd_infer_unit and yolo_conv2d_fwd_head_unit for the launches small_tile / small_head_tile (below)
+// pick: a workgroup streams ~50-65 GB/s whatever its tile and however many loads it keeps in flight, so a launch pays when it
+// fits ONE round of at most 256 workgroups with few bytes each -- the 1x1 units, the heads, the 52x52 / 104x104 3x3 units.
 #include "act.hpp"
 #include "planes.hpp"
 #include <cstdlib>
